@@ -1,0 +1,215 @@
+"""ctypes binding of the CPU oracle (oracle/libpmaf_oracle.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py. The product path (libpmaf_hip.so and the host
+layers above it) never imports this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int32)
+
+
+def build():
+    """Compile the oracle with gcc (no-op if the .so is newer than its sources)."""
+    so = os.path.join(_HERE, "libpmaf_oracle.so")
+    srcs = [os.path.join(_HERE, f) for f in ("pmaf_oracle.c", "pmaf_oracle.h", "Makefile")]
+    if os.path.exists(so) and all(os.path.getmtime(so) >= os.path.getmtime(s) for s in srcs):
+        return so
+    subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "libpmaf_oracle.so"])
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        L = C.CDLL(build())
+        L.orc_create.restype = C.c_void_p
+        L.orc_create.argtypes = [C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, _dp, _dp, _ip, _dp]
+        L.orc_destroy.argtypes = [C.c_void_p]
+        L.orc_set_initial_position.argtypes = [C.c_void_p, _dp]
+        L.orc_set_real_position.argtypes = [C.c_void_p, _dp]
+        L.orc_rollout.argtypes = [C.c_void_p]
+        L.orc_rollout_range.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.orc_evaluate.restype = C.c_int
+        L.orc_evaluate.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double, _dp]
+        L.orc_move_real.argtypes = [C.c_void_p, _dp, C.c_double, C.c_int, C.c_int]
+        L.orc_reset_agents.argtypes = [C.c_void_p, _dp, _dp, _dp]
+        L.orc_tick.restype = C.c_int
+        L.orc_tick.argtypes = [C.c_void_p, _dp, C.c_double, _dp, _dp]
+        L.orc_link_force.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _dp, _dp]
+        L.orc_get_paths.argtypes = [C.c_void_p, _dp, _ip]
+        for name in ("orc_get_costs", "orc_get_path_lengths", "orc_get_min_obs_dist",
+                     "orc_get_agent_vel", "orc_get_rot_vecs"):
+            getattr(L, name).argtypes = [C.c_void_p, _dp]
+        L.orc_get_success.argtypes = [C.c_void_p, _ip]
+        L.orc_get_known.argtypes = [C.c_void_p, _ip]
+        L.orc_get_real_state.argtypes = [C.c_void_p, _dp, _dp, _dp]
+        L.orc_get_real_known.argtypes = [C.c_void_p, _ip, _dp]
+        L.orc_get_real_path.restype = C.c_int
+        L.orc_get_real_path.argtypes = [C.c_void_p, _dp, C.c_int]
+        L.orc_dist_from_goal.restype = C.c_double
+        L.orc_dist_from_goal.argtypes = [C.c_void_p]
+        L.orc_best_type.argtypes = [C.c_void_p]
+        L.orc_best_id.argtypes = [C.c_void_p]
+        L.orc_agent_steps.restype = C.c_int64
+        L.orc_agent_steps.argtypes = [C.c_void_p]
+        _LIB = L
+    return _LIB
+
+
+def _d(a):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    return a, a.ctypes.data_as(_dp)
+
+
+class OraclePlanner:
+    """Same method names as the host-side planner mirror (PmafPlanner) so the
+    parity tests drive both with one scenario script."""
+
+    def __init__(self, scene, mgr_init_pos=(0.0, 0.0, 0.0)):
+        s = scene
+        L = lib()
+        self.N, self.n_obs, self.cap = int(s["n_agents"]), int(s["obstacles"].shape[0]), int(s["max_prediction_steps"])
+        scal, scal_p = _d([s["dt"], s["velocity_max"], s["approach_dist"], s["detect_shell_rad"],
+                           s.get("agent_mass", 1.0), s.get("radius", 0.05)])
+        goal, goal_p = _d(s["goal"])
+        ip, ip_p = _d(mgr_init_pos)
+        obs, obs_p = _d(s["obstacles"])
+        gains, gains_p = _d(np.stack([np.broadcast_to(np.asarray(s[k], dtype=np.float64), (self.N,))
+                                      for k in ("k_attr", "k_circ", "k_repel", "k_damp")]))
+        types = s.get("agent_types")
+        if types is not None:
+            types = np.ascontiguousarray(types, dtype=np.int32)
+            types_p = types.ctypes.data_as(_ip)
+        else:
+            types_p = None
+        rv, rv_p = _d(s["random_vecs"])
+        assert rv.shape == (self.N, self.n_obs, 3)
+        self._h = L.orc_create(self.N, self.n_obs, self.cap, scal_p, goal_p, ip_p, obs_p, gains_p, types_p, rv_p)
+        if not self._h:
+            raise ValueError("orc_create failed")
+        self._L = L
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.orc_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def set_initial_position(self, pos):
+        _, p = _d(pos)
+        self._L.orc_set_initial_position(self._h, p)
+
+    def set_real_position(self, pos):
+        _, p = _d(pos)
+        self._L.orc_set_real_position(self._h, p)
+
+    def rollout(self):
+        self._L.orc_rollout(self._h)
+
+    def rollout_range(self, a0, a1):
+        self._L.orc_rollout_range(self._h, a0, a1)
+
+    def evaluate(self, cost_gains, ws):
+        _, w = _d(ws)
+        g = [float(x) for x in cost_gains]
+        return self._L.orc_evaluate(self._h, g[0], g[1], g[2], g[3], w)
+
+    def move_real(self, obstacles, dt, steps, agent_id):
+        _, o = _d(obstacles)
+        self._L.orc_move_real(self._h, o, float(dt), int(steps), int(agent_id))
+
+    def reset_agents(self, pos, vel, obstacles):
+        _, p = _d(pos)
+        _, v = _d(vel)
+        _, o = _d(obstacles)
+        self._L.orc_reset_agents(self._h, p, v, o)
+
+    def tick(self, obstacles, dt, cost_gains, ws):
+        _, o = _d(obstacles)
+        _, g = _d(cost_gains)
+        _, w = _d(ws)
+        return self._L.orc_tick(self._h, o, float(dt), g, w)
+
+    def link_force(self, link_pos, k_r_force, obstacles):
+        lp, lp_p = _d(link_pos)
+        _, k = _d(k_r_force)
+        _, o = _d(obstacles)
+        out = np.zeros_like(lp)
+        self._L.orc_link_force(self._h, lp.shape[0], lp_p, k, o, out.ctypes.data_as(_dp))
+        return out
+
+    def paths(self):
+        paths = np.zeros((self.N, self.cap, 3))
+        n = np.zeros(self.N, dtype=np.int32)
+        self._L.orc_get_paths(self._h, paths.ctypes.data_as(_dp), n.ctypes.data_as(_ip))
+        return paths, n
+
+    def _vec(self, fn, shape):
+        out = np.zeros(shape)
+        getattr(self._L, fn)(self._h, out.ctypes.data_as(_dp))
+        return out
+
+    def costs(self):
+        return self._vec("orc_get_costs", (self.N,))
+
+    def path_lengths(self):
+        return self._vec("orc_get_path_lengths", (self.N,))
+
+    def min_obs_dist(self):
+        return self._vec("orc_get_min_obs_dist", (self.N,))
+
+    def agent_vel(self):
+        return self._vec("orc_get_agent_vel", (self.N, 3))
+
+    def rot_vecs(self):
+        return self._vec("orc_get_rot_vecs", (self.N, self.n_obs, 3))
+
+    def success(self):
+        out = np.zeros(self.N, dtype=np.int32)
+        self._L.orc_get_success(self._h, out.ctypes.data_as(_ip))
+        return out
+
+    def known(self):
+        out = np.zeros((self.N, self.n_obs), dtype=np.int32)
+        self._L.orc_get_known(self._h, out.ctypes.data_as(_ip))
+        return out
+
+    def real_state(self):
+        pos, vel, force = np.zeros(3), np.zeros(3), np.zeros(3)
+        self._L.orc_get_real_state(self._h, pos.ctypes.data_as(_dp), vel.ctypes.data_as(_dp),
+                                   force.ctypes.data_as(_dp))
+        return pos, vel, force
+
+    def real_known(self):
+        known = np.zeros(self.n_obs, dtype=np.int32)
+        rot = np.zeros((self.n_obs, 3))
+        self._L.orc_get_real_known(self._h, known.ctypes.data_as(_ip), rot.ctypes.data_as(_dp))
+        return known, rot
+
+    def real_path(self):
+        n = self._L.orc_get_real_path(self._h, None, 0)
+        out = np.zeros((n, 3))
+        self._L.orc_get_real_path(self._h, out.ctypes.data_as(_dp), n)
+        return out
+
+    def dist_from_goal(self):
+        return self._L.orc_dist_from_goal(self._h)
+
+    def best_type(self):
+        return self._L.orc_best_type(self._h)
+
+    def best_id(self):
+        return self._L.orc_best_id(self._h)
+
+    def agent_steps(self):
+        return self._L.orc_agent_steps(self._h)

@@ -1,0 +1,123 @@
+/*
+ * pmaf_oracle.h -- TEST INFRASTRUCTURE ONLY (not product code).
+ *
+ * CPU restatement, in plain C, of the reference's predictive multi-agent
+ * circular-field planner tick (bimanual_planning_ros: CfAgent / CfManager).
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load this library; the product (libpmaf_hip.so) never links or calls it.
+ *
+ * PARITY UNPINNED: the reference ships no tests, golden vectors or fixtures
+ * for this path, and its sources need Eigen3/dqrobotics/ROS headers that are
+ * absent from this image, so no reference build exists to pin against (see
+ * DESIGN.md "Oracle"). The restatement follows the reference line by line
+ * (each function cites the file:line it follows, B/ =
+ * /root/reference/src/bimanual_planning_ros/) and is additionally checked
+ * against the probe numbers recorded in SURVEY.md section 8(c).
+ *
+ * Conventions: all arithmetic IEEE double, compiled with -ffp-contract=off.
+ * obstacles are flat [n_obs][7] = px,py,pz,vx,vy,vz,r; the LAST obstacle
+ * (index n_obs-1) is the repulsive-only one (B/src/cf_agent.cpp:159-181),
+ * indices 0..n_obs-2 generate circular fields (B/src/cf_agent.cpp:75).
+ */
+#ifndef PMAF_ORACLE_H
+#define PMAF_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Agent types: values of CfAgent::Type, B/include/bimanual_planning_ros/cf_agent.h:59-68 */
+enum {
+  ORC_REAL_AGENT = 0,
+  ORC_GOAL_HEURISTIC = 1,
+  ORC_OBSTACLE_HEURISTIC = 2,
+  ORC_GOAL_OBSTACLE_HEURISTIC = 3,
+  ORC_VEL_HEURISTIC = 4,
+  ORC_RANDOM_AGENT = 5,
+  ORC_HAD_HEURISTIC = 6
+};
+
+typedef struct orc_planner orc_planner;
+
+/*
+ * CfManager::init on a default-constructed manager
+ * (B/src/cf_manager.cpp:41-124). scal = {dt (= prediction_freq_multiple *
+ * delta_t), velocity_max, approach_dist, detect_shell_rad, agent_mass,
+ * radius}. gains = [4][n_agents] rows k_attr,k_circ,k_repel,k_damp.
+ * types may be NULL -> reference population layout (cf_manager.cpp:70-104):
+ * Had, Goal, Obstacle, GoalObstacle, Vel, then Random. random_vecs =
+ * [n_agents][n_obs][3] unit vectors (only Random agents' rows are read);
+ * replaces std::random_device (B/src/helper_functions.cpp:7-13).
+ * mgr_init_pos = CfManager::init_pos_ at the time of init (agents are
+ * constructed at that position).
+ */
+orc_planner *orc_create(int n_agents, int n_obs, int max_prediction_steps,
+                        const double *scal, const double *goal,
+                        const double *mgr_init_pos, const double *obstacles,
+                        const double *gains, const int32_t *types,
+                        const double *random_vecs);
+void orc_destroy(orc_planner *p);
+
+/* CfManager::setInitialPosition, B/src/cf_manager.cpp:226-236 */
+void orc_set_initial_position(orc_planner *p, const double *pos);
+/* CfManager::setRealEEAgentPosition, B/src/cf_manager.cpp:216-218 */
+void orc_set_real_position(orc_planner *p, const double *pos);
+
+/*
+ * startPrediction + every agent's cfPrediction inner loop run to completion
+ * (guard false) + stopPrediction. B/src/cf_agent.cpp:302-341.
+ */
+void orc_rollout(orc_planner *p);
+/* As orc_rollout but only agents [a0,a1) -- used by the threaded CPU baseline. */
+void orc_rollout_range(orc_planner *p, int a0, int a1);
+
+/* CfManager::evaluateAgents, B/src/cf_manager.cpp:293-356. ws = [xmax,xmin,ymax,ymin,zmax,zmin] */
+int orc_evaluate(orc_planner *p, double k_goal_dist, double k_path_len,
+                 double k_safe_dist, double k_workspace, const double *ws);
+/* CfManager::moveRealEEAgent, B/src/cf_manager.cpp:257-263 */
+void orc_move_real(orc_planner *p, const double *obstacles, double dt,
+                   int steps, int agent_id);
+/* CfManager::resetEEAgents, B/src/cf_manager.cpp:246-255 */
+void orc_reset_agents(orc_planner *p, const double *pos, const double *vel,
+                      const double *obstacles);
+/* the planCallback sequence stop/evaluate/move/reset/start+complete,
+ * B/src/panda_bimanual_control.cpp:336-352. Returns best index. */
+int orc_tick(orc_planner *p, const double *obstacles, double dt,
+             const double *cost_gains, const double *ws);
+
+/* CfManager::getLinkForce -> CfAgent::bodyForce, B/src/cf_manager.cpp:169-182,
+ * B/src/cf_agent.cpp:229-234. link_pos [n][3], k_r_force [n], out [n][3]. */
+void orc_link_force(orc_planner *p, int n, const double *link_pos,
+                    const double *k_r_force, const double *obstacles,
+                    double *out);
+
+/* getters (B/src/cf_manager.cpp:184-214, cf_manager.h:73-92) */
+int orc_n_agents(const orc_planner *p);
+int orc_n_obs(const orc_planner *p);
+int orc_capacity(const orc_planner *p);
+void orc_get_paths(const orc_planner *p, double *paths /*[N][cap][3]*/,
+                   int32_t *n_points /*[N]*/);
+void orc_get_costs(const orc_planner *p, double *costs /*[N]*/);
+void orc_get_path_lengths(const orc_planner *p, double *out /*[N]*/);
+void orc_get_min_obs_dist(const orc_planner *p, double *out /*[N]*/);
+void orc_get_success(const orc_planner *p, int32_t *out /*[N]*/);
+void orc_get_agent_vel(const orc_planner *p, double *out /*[N][3]*/);
+void orc_get_rot_vecs(const orc_planner *p, double *out /*[N][n_obs][3]*/);
+void orc_get_known(const orc_planner *p, int32_t *out /*[N][n_obs]*/);
+void orc_get_real_state(const orc_planner *p, double *pos, double *vel,
+                        double *force);
+void orc_get_real_known(const orc_planner *p, int32_t *known /*[n_obs]*/,
+                        double *rot /*[n_obs][3]*/);
+int orc_get_real_path(const orc_planner *p, double *out, int max_points);
+double orc_dist_from_goal(const orc_planner *p);
+int orc_best_type(const orc_planner *p); /* -1 if no best agent yet */
+int orc_best_id(const orc_planner *p);   /* 1-based agent ID, 0 if none */
+/* total agent-steps executed by orc_rollout calls so far (for timing) */
+int64_t orc_agent_steps(const orc_planner *p);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,208 @@
+/*
+ * pmaf.h -- C-ABI of the MI355X-native predictive multi-agent circular-field
+ * planner tick (libpmaf_hip.so, hand-written HIP kernels for gfx950).
+ *
+ * This is the drop-in boundary for ONE path of the reference
+ * (riddhiman13/predictive-multi-agent-framework, package bimanual_planning_ros):
+ * the per-tick forward rollout of N virtual agents over an H-step horizon,
+ * scoring, best-agent selection and the real agent's single step. The
+ * reference has no FFI for it -- ghostplanner::cfplanner::CfManager is a plain
+ * C++ class compiled into the planner node -- so every entry point below cites
+ * the CfManager / CfAgent member it replaces (B/ = src/bimanual_planning_ros/).
+ * The C++ facade in include/bimanual_planning_ros/cf_manager.h re-creates the
+ * reference's class surface on top of these calls.
+ *
+ * Conventions
+ *  - all arithmetic is IEEE double; flat row-major arrays; plain pointers.
+ *  - a handle batches P independent populations ("scenes": one CfManager
+ *    each); every array argument carries a leading [P] dimension. The
+ *    reference's single-manager use is P = 1.
+ *  - obstacles are [P][n_obstacles][7] = px,py,pz,vx,vy,vz,radius. The LAST
+ *    obstacle of a population is the repulsive-only one
+ *    (B/src/cf_agent.cpp:159-181, reference README.md:80); the others generate
+ *    circular fields (B/src/cf_agent.cpp:75).
+ *  - agent index is 0-based (as returned by CfManager::evaluateAgents), agent
+ *    IDs inside the handle are 1-based like the reference.
+ *  - every function returns PMAF_OK (0) or a negative pmaf_status; the message
+ *    is available from pmaf_last_error(). Nothing throws across the ABI.
+ *  - a handle is not thread-safe (neither is CfManager: all calls come from the
+ *    single-threaded ROS spinner, B/src/panda_bimanual_control.cpp:475).
+ *  - there is NO CPU fallback: without a HIP device pmaf_create fails with
+ *    PMAF_ERR_DEVICE.
+ */
+#ifndef PMAF_H
+#define PMAF_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PMAF_ABI_VERSION 1
+
+typedef enum pmaf_status {
+  PMAF_OK = 0,
+  PMAF_ERR_INVALID = -1, /* bad argument (NULL, size <= 0, empty obstacle list ...) */
+  PMAF_ERR_DEVICE = -2,  /* HIP runtime / no device */
+  PMAF_ERR_STATE = -3,   /* call not valid in the handle's current state */
+  PMAF_ERR_NOMEM = -4
+} pmaf_status;
+
+/* values of CfAgent::Type, B/include/bimanual_planning_ros/cf_agent.h:59-68 */
+typedef enum pmaf_agent_type {
+  PMAF_REAL_AGENT = 0,
+  PMAF_GOAL_HEURISTIC = 1,
+  PMAF_OBSTACLE_HEURISTIC = 2,
+  PMAF_GOAL_OBSTACLE_HEURISTIC = 3,
+  PMAF_VEL_HEURISTIC = 4,
+  PMAF_RANDOM_AGENT = 5,
+  PMAF_HAD_HEURISTIC = 6
+} pmaf_agent_type;
+
+typedef struct pmaf_planner pmaf_planner;
+
+/*
+ * Arguments of CfManager::init (B/src/cf_manager.cpp:41-124,
+ * B/include/bimanual_planning_ros/cf_manager.h:93-102) for P populations.
+ */
+typedef struct pmaf_params {
+  int32_t abi_version;          /* PMAF_ABI_VERSION */
+  int32_t n_populations;        /* P >= 1 */
+  int32_t n_agents;             /* N = k_a_ee.size() per population */
+  int32_t n_obstacles;          /* obstacles.size() = M+1 >= 1 per population */
+  int32_t max_prediction_steps; /* path capacity in points (H+1) */
+  int32_t device;               /* HIP device ordinal; -1 = current device */
+  int32_t lanes_per_agent;      /* 0 = auto; else 1,2,4,8,16,32,64 */
+  int32_t reserved;
+  double dt;                    /* prediction_freq_multiple * delta_t */
+  double velocity_max;
+  double approach_dist;
+  double detect_shell_rad;
+  double agent_mass;            /* reference default 1.0 */
+  double radius;                /* reference default 0.05 */
+  const double *goal;           /* [P][3] */
+  const double *init_pos;       /* [P][3] CfManager::init_pos_ when init runs (agents are built there); NULL = zeros */
+  const double *obstacles;      /* [P][n_obstacles][7] */
+  const double *k_attr;         /* [P][N] k_a_ee */
+  const double *k_circ;         /* [P][N] k_c_ee */
+  const double *k_repel;        /* [P][N] k_r_ee */
+  const double *k_damp;         /* [P][N] k_d_ee */
+  const int32_t *agent_types;   /* [N] or NULL = reference layout Had,Goal,Obstacle,GoalObstacle,Vel,Random... (cf_manager.cpp:70-104) */
+  const double *random_vecs;    /* [P][N][n_obstacles][3] unit vectors for Random agents (replaces std::random_device, B/src/helper_functions.cpp:7-13); NULL = all zero */
+} pmaf_params;
+
+/* CfManager::init / ~CfManager */
+int pmaf_create(const pmaf_params *params, pmaf_planner **out);
+int pmaf_destroy(pmaf_planner *h);
+const char *pmaf_last_error(void);
+int pmaf_abi_version(void);
+
+/* CfManager::setInitialPosition, B/src/cf_manager.cpp:226-236. pos [P][3] */
+int pmaf_set_initial_position(pmaf_planner *h, const double *pos);
+/* CfManager::setRealEEAgentPosition, B/src/cf_manager.cpp:216-218 (closed loop). pos [P][3] */
+int pmaf_set_real_position(pmaf_planner *h, const double *pos);
+
+/* CfManager::startPrediction (cf_manager.h:57-61): asynchronous launch of the
+ * agent x horizon rollout kernel on the handle's stream. Rollouts always run
+ * to their guard (full horizon or goal reached, B/src/cf_agent.cpp:310-311). */
+int pmaf_start(pmaf_planner *h);
+/* CfManager::stopPrediction (B/src/cf_manager.cpp:126-140): stream sync. */
+int pmaf_stop(pmaf_planner *h);
+
+/* CfManager::evaluateAgents, B/src/cf_manager.cpp:293-356.
+ * cost_gains = {k_goal_dist,k_path_len,k_safe_dist,k_workspace},
+ * ws = {xmax,xmin,ymax,ymin,zmax,zmin}; best_idx [P] out. */
+int pmaf_evaluate(pmaf_planner *h, const double *cost_gains, const double *ws,
+                  int32_t *best_idx);
+/* CfManager::moveRealEEAgent, B/src/cf_manager.cpp:257-263. obstacles
+ * [P][n_obstacles][7] live obstacles; agent_id [P]. */
+int pmaf_move_real(pmaf_planner *h, const double *obstacles, double dt,
+                   int32_t steps, const int32_t *agent_id);
+/* CfManager::resetEEAgents, B/src/cf_manager.cpp:246-255. pos, vel [P][3]. */
+int pmaf_reset_agents(pmaf_planner *h, const double *pos, const double *vel,
+                      const double *obstacles);
+/*
+ * The planCallback sequence stop -> evaluate -> moveRealEEAgent(1 step) ->
+ * resetEEAgents(next pos, next vel) -> start
+ * (B/src/panda_bimanual_control.cpp:336-352) as two back-to-back launches.
+ * Returns once best_idx / next_pos / next_vel (each [P], [P][3], [P][3]; may be
+ * NULL) are on the host; the new rollout keeps running asynchronously, like
+ * the reference's prediction threads. obstacles may be NULL (= unchanged).
+ */
+int pmaf_tick(pmaf_planner *h, const double *obstacles, double dt,
+              const double *cost_gains, const double *ws, int32_t *best_idx,
+              double *next_pos, double *next_vel);
+
+/* CfManager::getLinkForce -> CfAgent::bodyForce, B/src/cf_manager.cpp:169-182,
+ * B/src/cf_agent.cpp:229-234: repel-only force of population `pop`'s last
+ * obstacle at n link points. link_pos [n][3], k_r_force [n], out [n][3]. */
+int pmaf_link_force(pmaf_planner *h, int32_t pop, int32_t n,
+                    const double *link_pos, const double *k_r_force,
+                    const double *obstacles, double *out);
+
+/* ---- getters (all synchronise with the running rollout first) ---- */
+/* getPredictedPaths / getNumPredictionSteps: paths [P][N][cap][3], n_points [P][N] */
+int pmaf_get_paths(pmaf_planner *h, double *paths, int32_t *n_points);
+/* costs of the last pmaf_evaluate / pmaf_tick, [P][N] */
+int pmaf_get_costs(pmaf_planner *h, double *costs);
+/* getPredictedPathLengths, B/src/cf_manager.cpp:192-198, [P][N] */
+int pmaf_get_path_lengths(pmaf_planner *h, double *out);
+/* CfAgent::getMinObsDist, [P][N] */
+int pmaf_get_min_obs_dist(pmaf_planner *h, double *out);
+/* getAgentSuccess, B/src/cf_manager.cpp:208-214, [P][N] (0/1) */
+int pmaf_get_success(pmaf_planner *h, int32_t *out);
+/* CfAgent::getVelocity of every predicted agent, [P][N][3] */
+int pmaf_get_agent_velocities(pmaf_planner *h, double *out);
+/* field_rotation_vecs_ [P][N][n_obstacles][3] and known_obstacles_ [P][N][n_obstacles] */
+int pmaf_get_rotation_vectors(pmaf_planner *h, double *rot, int32_t *known);
+/* getNextPosition / getNextVelocity / getEEForce (cf_manager.h:74-79), each [P][3], may be NULL */
+int pmaf_get_real_state(pmaf_planner *h, double *pos, double *vel, double *force);
+/* RealCfAgent known_obstacles_ [P][n_obstacles], field_rotation_vecs_ [P][n_obstacles][3] */
+int pmaf_get_real_known(pmaf_planner *h, int32_t *known, double *rot);
+/* getPlannedTrajectory (cf_manager.h:90-92) of population pop: copies up to
+ * max_points points into out [max_points][3]; *n_total = path size. */
+int pmaf_get_real_path(pmaf_planner *h, int32_t pop, double *out,
+                       int32_t max_points, int32_t *n_total);
+/* getDistFromGoal (cf_manager.h:87-89), [P] */
+int pmaf_get_dist_from_goal(pmaf_planner *h, double *out);
+/* getBestAgentType (cf_manager.h:73): type [P] (-1 = none yet), id [P] 1-based (0 = none) */
+int pmaf_get_best(pmaf_planner *h, int32_t *type, int32_t *id);
+/* getPredictionTimes (B/src/cf_manager.cpp:200-206): duration of the last
+ * rollout launch in ns, from HIP events on the handle's stream, [P][N] (all
+ * agents of a launch share it). Requires pmaf_set_profiling(h, 1). */
+int pmaf_get_prediction_times_ns(pmaf_planner *h, double *out);
+
+/* ---- state transfer / sharding support (no reference equivalent) ---- */
+/* restore hysteresis reference (best_agent_ survives CfManager::init): id
+ * 1-based [P] (0 = none), type [P], rand [P][n_obstacles][3] */
+int pmaf_set_best(pmaf_planner *h, const int32_t *id, const int32_t *type,
+                  const double *rand_vecs);
+/*
+ * Winner record of each population after the last evaluate/tick, written to
+ * DEVICE memory `dst` (e.g. the send buffer of an RCCL all-gather):
+ * per population {double cost; double idx; double n_points; double type;
+ * double path[cap][3]} = (4 + 3*cap) doubles. Enqueued on the handle's stream;
+ * pmaf_stop() or a stream-ordered consumer makes it visible.
+ */
+int pmaf_write_winner_records(pmaf_planner *h, void *dst_device, size_t bytes);
+size_t pmaf_winner_record_doubles(const pmaf_planner *h);
+/* the hipStream_t the handle launches on (as void*), for stream-ordered consumers */
+void *pmaf_stream(pmaf_planner *h);
+
+/* ---- measurement ---- */
+/* enable HIP-event timing of every rollout launch */
+int pmaf_set_profiling(pmaf_planner *h, int32_t enable);
+/* accumulated rollout-kernel time (ms), launches and agent-steps since the last reset_stats */
+int pmaf_get_kernel_stats(pmaf_planner *h, double *rollout_ms, int64_t *launches,
+                          int64_t *agent_steps);
+int pmaf_reset_kernel_stats(pmaf_planner *h);
+/* chosen lanes-per-agent and grid of the rollout kernel */
+int pmaf_get_launch_config(pmaf_planner *h, int32_t *lanes_per_agent,
+                           int32_t *n_blocks, int32_t *lds_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PMAF_H */

@@ -1,0 +1,14 @@
+#!/bin/bash
+# Builds libpmaf_hip.so (HIP kernels + C-ABI) for gfx950, in-tree.
+# -ffp-contract=off: no FMA contraction, so the kernels keep the reference's
+# double-precision operation order (see pmaf_device.hpp).
+set -e
+cd "$(dirname "$0")"
+HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
+OUT=../lib
+mkdir -p "$OUT"
+$HIPCC --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared \
+  -ffp-contract=off -fno-fast-math \
+  -Wall -Wno-unused-function ${PMAF_EXTRA_FLAGS} \
+  -o "$OUT/libpmaf_hip.so" pmaf_hip.hip
+echo "built $OUT/libpmaf_hip.so"

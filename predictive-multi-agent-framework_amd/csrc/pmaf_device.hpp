@@ -1,0 +1,351 @@
+// pmaf_device.hpp -- gfx950 device functions of the circular-field agent step.
+//
+// One agent is evaluated by a group of LPA lanes of a wave64 (LPA = 1..64, a
+// power of two): the lanes split the O(M) obstacle sweep of
+// CfAgent::circForce / attractorForceScaling (B/src/cf_agent.cpp:72-108,
+// 195-227; B/ = reference src/bimanual_planning_ros/), the O(1) terms
+// (repelForce :159-181, attractorForce :183-193, updatePositionAndVelocity
+// :253-268) are evaluated redundantly by every lane of the group so no
+// broadcast is needed. Obstacles live in LDS as structure-of-arrays (one
+// copy per wave: every agent's private obstacle copy in the reference evolves
+// identically, cf_agent.cpp:270-276).
+//
+// Floating point: IEEE double, no FMA contraction (-ffp-contract=off), true
+// divisions and square roots, and the reference's operation order (see
+// oracle/pmaf_oracle.c header), so results are bit-identical to the CPU
+// restatement except through exp() (attractorForceScaling :220).
+//
+// The sequential `force_ += curr_force` of circForce (:106) is reproduced by
+// adding the non-zero per-obstacle terms in ascending obstacle index
+// (ballot + ordered lane walk) -- adding the zero terms of out-of-shell
+// obstacles is an exact no-op.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace pmaf {
+
+struct V3 { double x, y, z; };
+
+__device__ __forceinline__ V3 mk(double x, double y, double z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ V3 operator-(V3 a) { return mk(-a.x, -a.y, -a.z); }
+__device__ __forceinline__ V3 operator*(double s, V3 a) { return mk(s * a.x, s * a.y, s * a.z); }
+__device__ __forceinline__ V3 operator*(V3 a, double s) { return mk(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ V3 operator/(V3 a, double s) { return mk(a.x / s, a.y / s, a.z / s); }
+__device__ __forceinline__ double dot(V3 a, V3 b) {
+#ifdef PMAF_DOT_RIGHT_ASSOC
+  return a.x * b.x + (a.y * b.y + a.z * b.z);
+#else
+  return (a.x * b.x + a.y * b.y) + a.z * b.z;
+#endif
+}
+__device__ __forceinline__ double sqn(V3 a) { return dot(a, a); }
+__device__ __forceinline__ double norm(V3 a) { return __builtin_sqrt(sqn(a)); }
+__device__ __forceinline__ V3 normalized(V3 a) {
+  double z = sqn(a);
+  if (z > 0.0) return a / __builtin_sqrt(z);
+  return a;
+}
+__device__ __forceinline__ V3 cross(V3 a, V3 b) {
+  return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+// std::max(a,b) / std::min(a,b) semantics incl. NaN behaviour
+__device__ __forceinline__ double smax(double a, double b) { return (a < b) ? b : a; }
+__device__ __forceinline__ double smin(double a, double b) { return (b < a) ? b : a; }
+
+enum : int { T_REAL = 0, T_GOAL = 1, T_OBST = 2, T_GOALOBST = 3, T_VEL = 4, T_RANDOM = 5, T_HAD = 6 };
+
+// population-wide scalars (CfManager::init arguments)
+struct PopConst {
+  double dt, vel_max, approach, shell, mass, rad;
+};
+
+// LDS-resident obstacle table, structure of arrays, n_obs entries each
+struct ObsTab {
+  double *px, *py, *pz, *vx, *vy, *vz, *r;
+  __device__ __forceinline__ V3 pos(int i) const { return mk(px[i], py[i], pz[i]); }
+  __device__ __forceinline__ V3 vel(int i) const { return mk(vx[i], vy[i], vz[i]); }
+};
+
+__device__ __forceinline__ ObsTab carve_obstab(double *base, int n_obs) {
+  ObsTab t;
+  t.px = base; t.py = base + n_obs; t.pz = base + 2 * n_obs;
+  t.vx = base + 3 * n_obs; t.vy = base + 4 * n_obs; t.vz = base + 5 * n_obs;
+  t.r = base + 6 * n_obs;
+  return t;
+}
+
+// ---- cross-lane helpers -------------------------------------------------
+__device__ __forceinline__ double readlane_d(double v, int lane) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_readlane(lo, lane);
+  hi = __builtin_amdgcn_readlane(hi, lane);
+  return __hiloint2double(hi, lo);
+}
+
+template <int LPA>
+__device__ __forceinline__ double group_min(double v) {
+#pragma unroll
+  for (int off = LPA / 2; off > 0; off >>= 1) {
+    double o = __shfl_xor(v, off);
+    v = (o < v) ? o : v;
+  }
+  return v;
+}
+
+// (value, index) argmin with "first index wins" among equal values
+template <int LPA>
+__device__ __forceinline__ void group_argmin(double &d, int &idx) {
+#pragma unroll
+  for (int off = LPA / 2; off > 0; off >>= 1) {
+    double od = __shfl_xor(d, off);
+    int oi = __shfl_xor(idx, off);
+    bool take = (od < d) || (od == d && oi < idx);
+    d = take ? od : d;
+    idx = take ? oi : idx;
+  }
+}
+
+// F += c over the lanes of each group that have has_c set, in ascending lane
+// (= ascending obstacle index within the tile) order.
+template <int LPA>
+__device__ __forceinline__ void ordered_accumulate(V3 &F, V3 c, bool has_c, int grp) {
+  unsigned long long m = __ballot(has_c);
+  if (LPA == 64) {
+    while (m) {
+      int src = __ffsll((long long)m) - 1;
+      m &= m - 1;
+      F.x = F.x + readlane_d(c.x, src);
+      F.y = F.y + readlane_d(c.y, src);
+      F.z = F.z + readlane_d(c.z, src);
+    }
+  } else if (LPA == 1) {
+    if (has_c) F = F + c;
+  } else {
+    const unsigned long long gm = (LPA >= 64) ? ~0ull : ((1ull << LPA) - 1ull);
+    unsigned long long sub = (m >> (grp * LPA)) & gm;
+    while (__any(sub != 0ull)) {
+      int src = grp * LPA + (sub ? (__ffsll((long long)sub) - 1) : 0);
+      double cx = __shfl(c.x, src), cy = __shfl(c.y, src), cz = __shfl(c.z, src);
+      if (sub) {
+        F.x = F.x + cx; F.y = F.y + cy; F.z = F.z + cz;
+      }
+      sub &= sub - 1ull;
+    }
+  }
+}
+
+// ---- heuristics ----------------------------------------------------------
+// currentVector, B/src/cf_agent.cpp:389-406 (Goal), 414-426 (Obstacle),
+// 463-475 (GoalObstacle), 520-537 (Vel), 545-557 (Random), 585-597 (Had).
+// to_obs = normalized(obstacle - agent_pos), identical to the value the
+// reference recomputes inside each currentVector.
+__device__ __forceinline__ V3 current_vector(int type, V3 agent_vel, V3 goal_vec, V3 to_obs, V3 rot) {
+  if (type == T_GOAL) {
+    V3 cur = goal_vec - to_obs * dot(to_obs, goal_vec);
+    if (norm(cur) < 1e-10) cur = mk(0.0, 0.0, 1.0);
+    return normalized(cur);
+  } else if (type == T_VEL) {
+    V3 nvel = normalized(agent_vel);
+    V3 cur = nvel - to_obs * dot(nvel, to_obs);
+    if (norm(cur) < 1e-10) cur = mk(0.0, 0.0, 1.0);
+    return normalized(cur);
+  } else if (type == T_OBST || type == T_GOALOBST || type == T_RANDOM || type == T_HAD) {
+    return normalized(cross(to_obs, rot));
+  }
+  return mk(0.0, 0.0, 0.0);
+}
+
+// nearest other field obstacle by centre distance, cf_agent.cpp:434-446 / :480-492
+__device__ __forceinline__ int closest_other(const ObsTab &T, int n_obs, int id) {
+  double min_dist = 100.0;
+  int closest = 0;
+  V3 oid = T.pos(id);
+  for (int i = 0; i < n_obs - 1; i++) {
+    if (i != id) {
+      double d = norm(oid - T.pos(i));
+      if (min_dist > d) { min_dist = d; closest = i; }
+    }
+  }
+  return closest;
+}
+
+// calculateRotationVector, B/src/cf_agent.cpp:408-412 (Goal), 428-461
+// (Obstacle), 477-518 (GoalObstacle), 539-543 (Vel), 559-566 (Random),
+// 599-611 (Had)
+__device__ __forceinline__ V3 calc_rot_vec(int type, V3 agent_pos, V3 goal_pos, const ObsTab &T,
+                                           int n_obs, int id, V3 rand_vec) {
+  if (type == T_GOAL || type == T_VEL) return mk(0.0, 0.0, 1.0);
+  if (type == T_OBST) {
+    if (n_obs < 2) return mk(0.0, 0.0, 1.0);
+    int c = closest_other(T, n_obs, id);
+    V3 obstacle_vec = T.pos(c) - T.pos(id);
+    V3 to_obs = normalized(T.pos(id) - agent_pos);
+    V3 cur = to_obs * dot(obstacle_vec, to_obs) - obstacle_vec;
+    return normalized(cross(cur, to_obs));
+  }
+  if (type == T_GOALOBST) {
+    int c = closest_other(T, n_obs, id);
+    V3 obstacle_vec = T.pos(c) - T.pos(id);
+    V3 to_obs = normalized(T.pos(id) - agent_pos);
+    V3 obst_cur = to_obs * dot(obstacle_vec, to_obs) - obstacle_vec;
+    V3 goal_vec = goal_pos - agent_pos;
+    V3 goal_cur = goal_vec - to_obs * dot(to_obs, goal_vec);
+    V3 cur = normalized(goal_cur) + normalized(obst_cur);
+    if (norm(cur) < 1e-10) cur = mk(0.0, 0.0, 1.0);
+    cur = normalized(cur);
+    return normalized(cross(cur, to_obs));
+  }
+  if (type == T_RANDOM) {
+    V3 goal_vec = normalized(goal_pos - agent_pos);
+    return cross(goal_vec, rand_vec);
+  }
+  if (type == T_HAD) {
+    V3 obs_pos = T.pos(id);
+    V3 goal_vec = goal_pos - agent_pos;
+    V3 rob_obs = obs_pos - agent_pos;
+    double gn = norm(goal_vec);
+    V3 d = (agent_pos + goal_vec * (dot(rob_obs, goal_vec) / (gn * gn))) - obs_pos;
+    V3 c = cross(d, goal_vec);
+    return c / norm(c);
+  }
+  return mk(0.0, 0.0, 0.0);
+}
+
+// ---- circForce + attractorForceScaling over the group's lanes ------------
+// act: this lane's agent takes a step AND its gate is open (uniform in the
+// group). Must be called by all 64 lanes of the wave.
+// rot_g / rand_g: this agent's rotation / random vectors in global memory,
+// component-major [3][n_obs]. known_bits: bit t <-> obstacle t*LPA+sub.
+template <int LPA, bool REAL>
+__device__ __forceinline__ void circ_and_scale(bool act, int sub, int grp, int type, V3 p, V3 v,
+                                               V3 goal, V3 g, const PopConst &C, double k_circ,
+                                               const ObsTab &T, int n_obs, double *rot_g,
+                                               const double *rand_g, unsigned long long &known_bits,
+                                               double &min_obs, V3 &F, double &scale) {
+  if (!__any(act)) return;
+  const int M = n_obs - 1;
+  const int ntiles = (M + LPA - 1) / LPA;
+  V3 gn = normalized(g);
+  double lane_min = min_obs;
+  double best_d = C.shell;
+  int best_i = 0x7fffffff;
+  for (int t = 0; t < ntiles; t++) {
+    int i = t * LPA + sub;
+    bool valid = act && (i < M);
+    int ii = valid ? i : 0;
+    V3 op = T.pos(ii);
+    V3 ov = T.vel(ii);
+    double orad = T.r[ii];
+    V3 ro = op - p;
+    V3 rv = v - ov;
+    double z = sqn(ro);
+    double s = __builtin_sqrt(z);
+    V3 ron = (z > 0.0) ? (ro / s) : ro;
+    bool skip = (dot(ron, gn) < -0.01) && (dot(ro, rv) < -0.01);
+    double d = s - (C.rad + orad);
+    d = smax(d, 1e-5);
+    // attractorForceScaling's sweep (:201-211) ignores the skip test
+    if (valid && d < best_d) { best_d = d; best_i = i; }
+    V3 c = mk(0.0, 0.0, 0.0);
+    bool has_c = false;
+    if (valid && !skip) {
+      if (!REAL) {
+        if (d < lane_min) lane_min = d;
+      }
+      if (d < C.shell) {
+        V3 rot;
+        if (!((known_bits >> t) & 1ull)) {
+          V3 rnd = mk(0.0, 0.0, 0.0);
+          if (type == T_RANDOM) rnd = mk(rand_g[i], rand_g[n_obs + i], rand_g[2 * n_obs + i]);
+          rot = calc_rot_vec(type, p, goal, T, n_obs, i, rnd);
+          rot_g[i] = rot.x; rot_g[n_obs + i] = rot.y; rot_g[2 * n_obs + i] = rot.z;
+          known_bits |= (1ull << t);
+        } else {
+          rot = mk(rot_g[i], rot_g[n_obs + i], rot_g[2 * n_obs + i]);
+        }
+        double vn = norm(rv);
+        if (vn != 0) {
+          V3 nv = rv / vn;
+          V3 cur = current_vector(type, rv, g, ron, rot);
+          c = (k_circ / (d * d)) * cross(nv, cross(cur, nv));
+          has_c = true;
+        }
+      }
+    }
+    ordered_accumulate<LPA>(F, c, has_c, grp);
+  }
+  if (!REAL) {
+    lane_min = group_min<LPA>(lane_min);
+    if (act) min_obs = lane_min;
+  }
+  group_argmin<LPA>(best_d, best_i);
+  // attractorForceScaling, B/src/cf_agent.cpp:195-227 (only if |F| > 1e-5, :319)
+  if (act && norm(F) > 1e-5) {
+    if (best_i == 0x7fffffff) {
+      scale = 1;
+    } else if (dot(g, v) <= 0.0 && norm(v) < C.vel_max - 0.1 * C.vel_max && norm(g) > 0.15) {
+      scale = 0.0;
+    } else {
+      double w1 = 1 - exp(-__builtin_sqrt(best_d) / C.shell);
+      V3 ro = T.pos(best_i) - p;
+      double w2 = 1 - (dot(g, ro) / (norm(g) * norm(ro)));
+      w2 = w2 * w2;
+      scale = w1 * w2;
+    }
+  }
+}
+
+// repelForce (:159-181) + attractorForce (:183-193) + updatePositionAndVelocity
+// (:253-268): O(1) per agent, evaluated by every lane of the group.
+__device__ __forceinline__ void finish_step(V3 p, V3 &v, V3 goal_vec, V3 &F, double scale,
+                                            const PopConst &C, double k_attr, double k_repel,
+                                            double k_damp, double dt, V3 sent_pos, double sent_rad,
+                                            V3 &new_pos) {
+  {
+    V3 ro = sent_pos - p;
+    V3 dist_vec = -ro;
+    double d = norm(dist_vec) - (C.rad + sent_rad);
+    d = smax(d, 1e-5);
+    V3 repel = mk(0.0, 0.0, 0.0);
+    if (d < C.shell) {
+      V3 otr = normalized(p - sent_pos);
+      double t = 1.0 / d - 1.0 / C.shell;
+      double dd = d * d;
+      repel = ((k_repel * otr) * t) / dd;
+    }
+    V3 total = mk(0.0, 0.0, 0.0) + repel;
+    F = F + total;
+  }
+  if (k_attr != 0.0) {
+    V3 vel_des = (k_attr / k_damp) * goal_vec;
+    double scale_lim = smin(1.0, C.vel_max / norm(vel_des));
+    vel_des = vel_des * scale_lim;
+    F = F + (scale * k_damp) * (vel_des - v);
+  }
+  V3 acc = F / C.mass;
+  double an = norm(acc);
+  if (an > 13.0) acc = acc * (13.0 / an);
+  V3 half = ((0.5 * acc) * dt) * dt;
+  new_pos = (p + half) + (v * dt);
+  V3 nv = v + acc * dt;
+  double vn = norm(nv);
+  if (vn > C.vel_max) nv = nv * (C.vel_max / vn);
+  v = nv;
+}
+
+// workspace-box penalty of one path point, B/src/cf_manager.cpp:302-324;
+// adds up to three terms to cost in x,y,z order.
+__device__ __forceinline__ void ws_cost_add(double &cost, V3 q, const double *ws, double k_ws) {
+  double t;
+  if (q.x > ws[0]) { t = fabs(q.x - ws[0]) * k_ws; cost += t * t; }
+  else if (q.x < ws[1]) { t = fabs(q.x - ws[1]) * k_ws; cost += t * t; }
+  if (q.y > ws[2]) { t = fabs(q.y - ws[2]) * k_ws; cost += t * t; }
+  else if (q.y < ws[3]) { t = fabs(q.y - ws[3]) * k_ws; cost += t * t; }
+  if (q.z > ws[4]) { t = fabs(q.z - ws[4]) * k_ws; cost += t * t; }
+  else if (q.z < ws[5]) { t = fabs(q.z - ws[5]) * k_ws; cost += t * t; }
+}
+
+}  // namespace pmaf

@@ -1,0 +1,1183 @@
+// pmaf_hip.hip -- libpmaf_hip.so: HIP kernels (gfx950) + C-ABI (include/pmaf.h)
+// of the predictive multi-agent circular-field planner tick.
+//
+// Kernels
+//   k_rollout<LPA>  agent x horizon rollout (CfAgent::cfPrediction,
+//                   B/src/cf_agent.cpp:302-341) for all agents of all
+//                   populations in one launch, with the per-path cost terms of
+//                   CfManager::evaluateAgents (B/src/cf_manager.cpp:302-333)
+//                   accumulated on the fly. One wave64 per block, 64/LPA agents
+//                   per wave, obstacle table in LDS advanced once per step.
+//   k_manager       one wave per population: evaluateAgents' cost assembly +
+//                   argmin + hysteresis (:325-353), RealCfAgent::cfPlanner
+//                   single step (B/src/cf_agent.cpp:343-366) and
+//                   resetEEAgents (B/src/cf_manager.cpp:246-255).
+//   k_score         re-scores stored paths (used before the first rollout and
+//                   when evaluate is called with other workspace gains).
+//   k_link_force    CfAgent::bodyForce (B/src/cf_agent.cpp:229-234).
+//   k_winner        packs winner records for sharded runs.
+// There is no CPU fallback in this library.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/pmaf.h"
+#include "pmaf_device.hpp"
+
+using namespace pmaf;
+
+// ---------------------------------------------------------------------------
+// device-side views
+// ---------------------------------------------------------------------------
+struct DevView {
+  int P, N, n_obs, cap;
+  PopConst C;
+  // per population
+  const double *goal;        // [P][3]
+  double *agent_init_pos;    // [P][3]  CfAgent::init_pos_ (gate)
+  double *start_pos;         // [P][3]  position all agents start the next rollout from
+  double *start_vel;         // [P][3]
+  double *obs_start;         // [P][7][n_obs] SoA: agents' private obstacle copies at rollout start
+  int32_t *known_start;      // [P][n_obs]
+  double *obs_live;          // [P][7][n_obs] SoA: live obstacles (moveRealEEAgent / resetEEAgents argument)
+  // per agent
+  const double *k_attr, *k_circ, *k_repel, *k_damp;  // [P][N]
+  const int32_t *types;      // [N]
+  double *rot;               // [P][N][3][n_obs]  field_rotation_vecs_
+  const double *rnd;         // [P][N][3][n_obs]  random_vecs_
+  double *paths;             // [P][N][cap][3]
+  int32_t *n_points;         // [P][N]
+  double *agent_vel;         // [P][N][3]
+  double *min_obs;           // [P][N]
+  double *cost_ws;           // [P][N]  sum of workspace penalties over the path
+  double *path_len;          // [P][N]
+  double *goal_dist;         // [P][N]
+  int32_t *reached;          // [P][N]
+  int32_t *known_out;        // [P][N][n_obs] known_obstacles_ after the rollout
+  double *costs;             // [P][N]
+  // real agent
+  double *real_pos, *real_vel, *real_force, *real_init_pos;  // [P][3]
+  int32_t *real_known;       // [P][n_obs]
+  double *real_rot;          // [P][3][n_obs]
+  // best agent copy
+  int32_t *has_best, *best_id, *best_type;  // [P]
+  double *best_rnd;          // [P][3][n_obs]
+  int32_t *best_idx;         // [P] last evaluate result
+  unsigned long long *step_counter;  // [1] agent-steps executed by all rollouts
+};
+
+struct CostParams {
+  double k_goal_dist, k_path_len, k_safe_dist, k_workspace;
+  double ws[6];
+};
+
+// ---------------------------------------------------------------------------
+// k_rollout
+// ---------------------------------------------------------------------------
+template <int LPA>
+__global__ __launch_bounds__(64) void k_rollout(DevView D, CostParams CP) {
+  extern __shared__ double smem[];
+  const int lane = threadIdx.x;
+  const int pop = blockIdx.y;
+  constexpr int APW = 64 / LPA;  // agents per wave
+  const int sub = lane % LPA;
+  const int grp = lane / LPA;
+  const int a = blockIdx.x * APW + grp;
+  const bool active = a < D.N;
+  const int aa = active ? a : 0;
+  const int n_obs = D.n_obs;
+  const PopConst C = D.C;
+
+  ObsTab T = carve_obstab(smem, n_obs);
+  int32_t *s_known = reinterpret_cast<int32_t *>(smem + 7 * n_obs);
+  {
+    const double *src = D.obs_start + (size_t)pop * 7 * n_obs;
+    for (int i = lane; i < 7 * n_obs; i += 64) smem[i] = src[i];
+    const int32_t *ks = D.known_start + (size_t)pop * n_obs;
+    for (int i = lane; i < n_obs; i += 64) s_known[i] = ks[i];
+  }
+  __syncthreads();
+
+  const size_t pa = (size_t)pop * D.N + aa;
+  const V3 goal = mk(D.goal[pop * 3], D.goal[pop * 3 + 1], D.goal[pop * 3 + 2]);
+  const V3 init_pos = mk(D.agent_init_pos[pop * 3], D.agent_init_pos[pop * 3 + 1], D.agent_init_pos[pop * 3 + 2]);
+  V3 p = mk(D.start_pos[pop * 3], D.start_pos[pop * 3 + 1], D.start_pos[pop * 3 + 2]);
+  V3 v = mk(D.start_vel[pop * 3], D.start_vel[pop * 3 + 1], D.start_vel[pop * 3 + 2]);
+  const double k_attr = D.k_attr[pa], k_circ = D.k_circ[pa], k_repel = D.k_repel[pa], k_damp = D.k_damp[pa];
+  const int type = D.types[aa];
+  double *rot_g = D.rot + pa * 3 * n_obs;
+  const double *rnd_g = D.rnd + pa * 3 * n_obs;
+  double *path = D.paths + pa * (size_t)D.cap * 3;
+
+  const int M = n_obs - 1;
+  const int ntiles = (M + LPA - 1) / LPA;
+  unsigned long long known_bits = 0ull;
+  for (int t = 0; t < ntiles; t++) {
+    int i = t * LPA + sub;
+    if (i < M && s_known[i]) known_bits |= (1ull << t);
+  }
+
+  double min_obs = C.shell;
+  double cost_ws = 0.0;
+  double path_len = 0.0;
+  int n = 1;
+  bool ran = false;
+  ws_cost_add(cost_ws, p, CP.ws, CP.k_workspace);
+  if (active && sub == 0) { path[0] = p.x; path[1] = p.y; path[2] = p.z; }
+
+  while (true) {
+    V3 g = goal - p;
+    double dg = norm(g);
+    bool run = active && (dg > 0.1) && (n < D.cap);
+    if (!__any(run)) break;
+    // gate, B/src/cf_agent.cpp:315-317
+    bool gate = !(dg < C.approach || (norm(v) < 0.5 * C.vel_max && norm(p - init_pos) < 0.2));
+    V3 F = mk(0.0, 0.0, 0.0);
+    double scale = 1.0;
+    circ_and_scale<LPA, false>(run && gate, sub, grp, type, p, v, goal, g, C, k_circ, T, n_obs, rot_g,
+                               rnd_g, known_bits, min_obs, F, scale);
+    V3 new_pos;
+    V3 nv = v;
+    finish_step(p, nv, g, F, scale, C, k_attr, k_repel, k_damp, C.dt, T.pos(n_obs - 1), T.r[n_obs - 1], new_pos);
+    if (run) {
+      path_len += norm(new_pos - p);
+      p = new_pos;
+      v = nv;
+      ws_cost_add(cost_ws, p, CP.ws, CP.k_workspace);
+      if (sub == 0) { path[n * 3] = p.x; path[n * 3 + 1] = p.y; path[n * 3 + 2] = p.z; }
+      n++;
+      ran = true;
+    }
+    // predictObstacles, B/src/cf_agent.cpp:270-276 (shared copy, once per step)
+    __syncthreads();
+    for (int i = lane; i < n_obs; i += 64) {
+      T.px[i] = T.px[i] + T.vx[i] * C.dt;
+      T.py[i] = T.py[i] + T.vy[i] * C.dt;
+      T.pz[i] = T.pz[i] + T.vz[i] * C.dt;
+    }
+    __syncthreads();
+  }
+
+  if (active) {
+    // known_obstacles_ of this agent after the rollout (getter only)
+    int32_t *ko = D.known_out + pa * n_obs;
+    for (int t = 0; t < ntiles; t++) {
+      int i = t * LPA + sub;
+      if (i < M) ko[i] = (int32_t)((known_bits >> t) & 1ull);
+    }
+    if (sub == 0) {
+      ko[M] = s_known[M];
+      D.n_points[pa] = n;
+      D.agent_vel[pa * 3] = v.x; D.agent_vel[pa * 3 + 1] = v.y; D.agent_vel[pa * 3 + 2] = v.z;
+      D.min_obs[pa] = min_obs;
+      D.cost_ws[pa] = cost_ws;
+      D.path_len[pa] = path_len;
+      double dgf = norm(goal - p);
+      D.goal_dist[pa] = dgf;
+      if (ran) D.reached[pa] = dgf < 0.100001;  // B/src/cf_agent.cpp:330-337
+      atomicAdd(D.step_counter, (unsigned long long)(n - 1));
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// k_score: cost terms from stored paths (one thread per agent)
+// ---------------------------------------------------------------------------
+__global__ void k_score(DevView D, CostParams CP) {
+  int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= D.P * D.N) return;
+  int pop = idx / D.N;
+  const double *path = D.paths + (size_t)idx * D.cap * 3;
+  int n = D.n_points[idx];
+  double cost = 0.0, len = 0.0;
+  V3 prev = mk(path[0], path[1], path[2]);
+  ws_cost_add(cost, prev, CP.ws, CP.k_workspace);
+  for (int k = 1; k < n; k++) {
+    V3 q = mk(path[k * 3], path[k * 3 + 1], path[k * 3 + 2]);
+    ws_cost_add(cost, q, CP.ws, CP.k_workspace);
+    len += norm(q - prev);
+    prev = q;
+  }
+  V3 goal = mk(D.goal[pop * 3], D.goal[pop * 3 + 1], D.goal[pop * 3 + 2]);
+  D.cost_ws[idx] = cost;
+  D.path_len[idx] = len;
+  D.goal_dist[idx] = norm(goal - prev);
+}
+
+// ---------------------------------------------------------------------------
+// k_manager: evaluate / real step / reset, one wave per population
+// ---------------------------------------------------------------------------
+struct ManagerArgs {
+  int do_select, do_move, do_reset;
+  int reset_from_real;     // 1: reset to the real agent's state, 0: reset_in
+  double dt_real;
+  const int32_t *agent_id; // [P] gains index for the real step; NULL = best_idx of this launch
+  const double *reset_in;  // [P][6] pos, vel
+  double *out;             // [P][8] host-visible: best_idx, next_pos[3], next_vel[3], dist_from_goal
+};
+
+__global__ __launch_bounds__(64) void k_manager(DevView D, CostParams CP, ManagerArgs A) {
+  extern __shared__ double smem[];
+  const int lane = threadIdx.x;
+  const int pop = blockIdx.x;
+  const int n_obs = D.n_obs;
+  const int N = D.N;
+  const PopConst C = D.C;
+  const V3 goal = mk(D.goal[pop * 3], D.goal[pop * 3 + 1], D.goal[pop * 3 + 2]);
+  int best = D.best_idx[pop];
+
+  if (A.do_select) {
+    // cost assembly + argmin, B/src/cf_manager.cpp:325-343
+    double lmin = 1.7976931348623157e308;
+    int lidx = 0x7fffffff;
+    for (int a = lane; a < N; a += 64) {
+      size_t pa = (size_t)pop * N + a;
+      double cost = D.cost_ws[pa];
+      double gd = D.goal_dist[pa];
+      if (gd > C.approach) cost += gd * CP.k_goal_dist;
+      cost += D.path_len[pa] * CP.k_path_len;
+      double mo = D.min_obs[pa];
+      cost += CP.k_safe_dist / mo;
+      if (mo < 2e-5) cost += 10000.0;
+      D.costs[pa] = cost;
+      if (cost < lmin) { lmin = cost; lidx = a; }
+    }
+    group_argmin<64>(lmin, lidx);
+    int min_idx = (lidx == 0x7fffffff) ? 0 : lidx;
+    __syncthreads();  // costs visible to the whole wave
+    // hysteresis, :344-353
+    bool take;
+    if (D.has_best[pop]) {
+      int bi = D.best_id[pop] - 1;
+      double cb = D.costs[(size_t)pop * N + bi];
+      double cm = D.costs[(size_t)pop * N + min_idx];
+      if (cm < 0.9 * cb) take = true;
+      else { take = false; min_idx = bi; }
+    } else {
+      take = true;
+    }
+    __syncthreads();
+    if (take) {  // best_agent_ = makeCopy()
+      const double *src = D.rnd + ((size_t)pop * N + min_idx) * 3 * n_obs;
+      double *dst = D.best_rnd + (size_t)pop * 3 * n_obs;
+      for (int i = lane; i < 3 * n_obs; i += 64) dst[i] = src[i];
+      if (lane == 0) {
+        D.has_best[pop] = 1;
+        D.best_id[pop] = min_idx + 1;
+        D.best_type[pop] = D.types[min_idx];
+      }
+    }
+    best = min_idx;
+    if (lane == 0) D.best_idx[pop] = best;
+    __syncthreads();
+  }
+
+  V3 rp = mk(D.real_pos[pop * 3], D.real_pos[pop * 3 + 1], D.real_pos[pop * 3 + 2]);
+  V3 rv = mk(D.real_vel[pop * 3], D.real_vel[pop * 3 + 1], D.real_vel[pop * 3 + 2]);
+
+  if (A.do_move) {
+    // RealCfAgent::cfPlanner one step, B/src/cf_agent.cpp:343-366
+    ObsTab T = carve_obstab(smem, n_obs);
+    const double *src = D.obs_live + (size_t)pop * 7 * n_obs;
+    for (int i = lane; i < 7 * n_obs; i += 64) smem[i] = src[i];
+    __syncthreads();
+    int gid = A.agent_id ? A.agent_id[pop] : best;
+    size_t pg = (size_t)pop * N + gid;
+    double k_attr = D.k_attr[pg], k_circ = D.k_circ[pg], k_repel = D.k_repel[pg], k_damp = D.k_damp[pg];
+    int htype = D.best_type[pop];
+    V3 init_pos = mk(D.real_init_pos[pop * 3], D.real_init_pos[pop * 3 + 1], D.real_init_pos[pop * 3 + 2]);
+    int32_t *rk = D.real_known + (size_t)pop * n_obs;
+    const int M = n_obs - 1;
+    const int ntiles = (M + 63) / 64;
+    unsigned long long kb = 0ull;
+    for (int t = 0; t < ntiles; t++) {
+      int i = t * 64 + lane;
+      if (i < M && rk[i]) kb |= (1ull << t);
+    }
+    V3 g = goal - rp;
+    double dg = norm(g);
+    bool gate = !(dg < C.approach || (norm(rv) < 0.5 * C.vel_max && norm(rp - init_pos) < 0.2));
+    V3 F = mk(0.0, 0.0, 0.0);
+    double scale = 1.0, dummy_min = C.shell;
+    circ_and_scale<64, true>(gate, lane, 0, htype, rp, rv, goal, g, C, k_circ, T, n_obs,
+                             D.real_rot + (size_t)pop * 3 * n_obs, D.best_rnd + (size_t)pop * 3 * n_obs, kb,
+                             dummy_min, F, scale);
+    V3 new_pos;
+    finish_step(rp, rv, g, F, scale, C, k_attr, k_repel, k_damp, A.dt_real, T.pos(n_obs - 1), T.r[n_obs - 1], new_pos);
+    rp = new_pos;
+    for (int t = 0; t < ntiles; t++) {
+      int i = t * 64 + lane;
+      if (i < M) rk[i] = (int32_t)((kb >> t) & 1ull);
+    }
+    if (lane == 0) {
+      D.real_pos[pop * 3] = rp.x; D.real_pos[pop * 3 + 1] = rp.y; D.real_pos[pop * 3 + 2] = rp.z;
+      D.real_vel[pop * 3] = rv.x; D.real_vel[pop * 3 + 1] = rv.y; D.real_vel[pop * 3 + 2] = rv.z;
+      D.real_force[pop * 3] = F.x; D.real_force[pop * 3 + 1] = F.y; D.real_force[pop * 3 + 2] = F.z;
+    }
+    __syncthreads();
+  }
+
+  if (A.do_reset) {
+    // resetEEAgents, B/src/cf_manager.cpp:246-255
+    V3 sp, sv;
+    if (A.reset_from_real) { sp = rp; sv = rv; }
+    else {
+      const double *in = A.reset_in + pop * 6;
+      sp = mk(in[0], in[1], in[2]);
+      sv = mk(in[3], in[4], in[5]);
+    }
+    // setVelocity clamp, B/src/cf_agent.cpp:54-61
+    double vn = norm(sv);
+    if (vn > C.vel_max) sv = (C.vel_max / vn) * sv;
+    // setObstacles, :63-70: position and velocity from the live obstacles,
+    // radius keeps its init value; known flags from the real agent
+    const double *live = D.obs_live + (size_t)pop * 7 * n_obs;
+    double *st = D.obs_start + (size_t)pop * 7 * n_obs;
+    for (int i = lane; i < 6 * n_obs; i += 64) st[i] = live[i];
+    const int32_t *rk = D.real_known + (size_t)pop * n_obs;
+    int32_t *ks = D.known_start + (size_t)pop * n_obs;
+    for (int i = lane; i < n_obs; i += 64) ks[i] = rk[i];
+    for (int a = lane; a < N; a += 64) {
+      size_t pa = (size_t)pop * N + a;
+      double *path = D.paths + pa * (size_t)D.cap * 3;
+      path[0] = sp.x; path[1] = sp.y; path[2] = sp.z;
+      D.n_points[pa] = 1;
+      D.agent_vel[pa * 3] = sv.x; D.agent_vel[pa * 3 + 1] = sv.y; D.agent_vel[pa * 3 + 2] = sv.z;
+      D.min_obs[pa] = C.shell;
+      int32_t *ko = D.known_out + pa * n_obs;
+      for (int i = 0; i < n_obs; i++) ko[i] = rk[i];
+    }
+    if (lane == 0) {
+      D.start_pos[pop * 3] = sp.x; D.start_pos[pop * 3 + 1] = sp.y; D.start_pos[pop * 3 + 2] = sp.z;
+      D.start_vel[pop * 3] = sv.x; D.start_vel[pop * 3 + 1] = sv.y; D.start_vel[pop * 3 + 2] = sv.z;
+    }
+  }
+
+  if (lane == 0 && A.out) {
+    double *o = A.out + pop * 8;
+    o[0] = (double)best;
+    o[1] = rp.x; o[2] = rp.y; o[3] = rp.z;
+    o[4] = rv.x; o[5] = rv.y; o[6] = rv.z;
+    o[7] = norm(goal - rp);
+  }
+}
+
+// CfAgent::bodyForce -> repelForce, B/src/cf_agent.cpp:229-234, 159-181
+__global__ void k_link_force(int n, const double *link_pos, const double *k_r, const double *sent /*7*/,
+                             double rad, double shell, double *out) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  V3 p = mk(link_pos[3 * i], link_pos[3 * i + 1], link_pos[3 * i + 2]);
+  V3 sp = mk(sent[0], sent[1], sent[2]);
+  V3 ro = sp - p;
+  V3 dist_vec = -ro;
+  double d = norm(dist_vec) - (rad + sent[6]);
+  d = smax(d, 1e-5);
+  V3 repel = mk(0.0, 0.0, 0.0);
+  if (d < shell) {
+    V3 otr = normalized(p - sp);
+    double t = 1.0 / d - 1.0 / shell;
+    double dd = d * d;
+    repel = ((k_r[i] * otr) * t) / dd;
+  }
+  V3 F = mk(0.0, 0.0, 0.0) + (mk(0.0, 0.0, 0.0) + repel);
+  out[3 * i] = F.x; out[3 * i + 1] = F.y; out[3 * i + 2] = F.z;
+}
+
+// winner record {cost, idx, n_points, type, path[cap][3]} per population
+__global__ void k_winner(DevView D, double *dst) {
+  int pop = blockIdx.x;
+  int best = D.best_idx[pop];
+  size_t pa = (size_t)pop * D.N + best;
+  size_t rec = 4 + (size_t)D.cap * 3;
+  double *o = dst + pop * rec;
+  if (threadIdx.x == 0) {
+    o[0] = D.costs[pa];
+    o[1] = (double)best;
+    o[2] = (double)D.n_points[pa];
+    o[3] = (double)D.types[best];
+  }
+  const double *path = D.paths + pa * (size_t)D.cap * 3;
+  int n3 = D.n_points[pa] * 3;
+  for (int i = threadIdx.x; i < D.cap * 3; i += blockDim.x) o[4 + i] = (i < n3) ? path[i] : 0.0;
+}
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+static thread_local std::string g_err;
+
+struct HipError {
+  hipError_t e;
+  const char *what;
+  int line;
+};
+#define HIP_CHECK(x)                                   \
+  do {                                                 \
+    hipError_t _e = (x);                               \
+    if (_e != hipSuccess) throw HipError{_e, #x, __LINE__}; \
+  } while (0)
+
+struct StatusError {
+  int code;
+  std::string msg;
+};
+static void fail(int code, const std::string &msg) { throw StatusError{code, msg}; }
+
+struct pmaf_planner {
+  DevView D{};
+  int device = 0;
+  int lpa = 64;
+  int n_blocks = 0;
+  size_t lds_rollout = 0, lds_manager = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev_mgr = nullptr;
+  std::vector<void *> allocs;
+  double *h_out = nullptr;      // pinned [P][8]
+  double *d_out = nullptr;      // device alias of h_out
+  static constexpr int kStage = 4;
+  double *h_stage[kStage] = {nullptr, nullptr, nullptr, nullptr};  // pinned staging ring for obstacle SoA uploads
+  hipEvent_t ev_stage[kStage] = {nullptr, nullptr, nullptr, nullptr};
+  int stage_next = 0;
+  double *d_reset_in = nullptr; // [P][6]
+  int32_t *d_agent_id = nullptr;// [P]
+  CostParams cp{};
+  bool cp_valid = false;        // cp holds the workspace terms the stored cost_ws was computed with
+  bool scores_valid = false;
+  bool rollout_pending = false; // agents were (re)set since the last rollout
+  std::vector<std::vector<double>> real_path;  // per population, xyz triples
+  std::vector<double> goal_h;
+  // profiling
+  bool profiling = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_free, ev_inflight;
+  double rollout_ms = 0.0, last_rollout_ms = 0.0;
+  int64_t launches = 0, timed_launches = 0;
+
+  template <typename T>
+  T *dalloc(size_t n) {
+    void *p = nullptr;
+    HIP_CHECK(hipMalloc(&p, sizeof(T) * (n ? n : 1)));
+    allocs.push_back(p);
+    HIP_CHECK(hipMemsetAsync(p, 0, sizeof(T) * (n ? n : 1), stream));
+    return static_cast<T *>(p);
+  }
+  template <typename T>
+  void upload(T *dst, const T *src, size_t n) {
+    HIP_CHECK(hipMemcpyAsync(dst, src, sizeof(T) * n, hipMemcpyHostToDevice, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+  }
+  template <typename T>
+  void download(T *dst, const T *src, size_t n) {
+    HIP_CHECK(hipMemcpyAsync(dst, src, sizeof(T) * n, hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+  }
+  void use_device() { HIP_CHECK(hipSetDevice(device)); }
+};
+
+static void aos_to_soa(const double *aos, double *soa, int P, int n_obs) {
+  for (int p = 0; p < P; p++)
+    for (int i = 0; i < n_obs; i++)
+      for (int c = 0; c < 7; c++) soa[((size_t)p * 7 + c) * n_obs + i] = aos[((size_t)p * n_obs + i) * 7 + c];
+}
+
+static int pick_lpa(int N, int P, int M) {
+  // Heuristic: fill the 1024 SIMDs of the chip with waves, but never use more
+  // lanes per agent than there are field obstacles to share.
+  int lpa = 64;
+  while (lpa > 1) {
+    long waves = ((long)N * lpa + 63) / 64 * P;
+    bool too_wide = lpa / 2 >= (M > 0 ? M : 1);
+    if (waves > 2048 || too_wide) lpa /= 2; else break;
+  }
+  // known-flag bitmask holds 64 tiles per lane
+  while ((M + lpa - 1) / lpa > 64 && lpa < 64) lpa *= 2;
+  return lpa;
+}
+
+// fold finished rollout event pairs (oldest first) into the stats; all=true
+// requires the stream to be idle
+static void drain_events(pmaf_planner *h, bool all) {
+  size_t done = 0;
+  for (; done < h->ev_inflight.size(); done++) {
+    auto &pr = h->ev_inflight[done];
+    if (!all && hipEventQuery(pr.second) != hipSuccess) break;
+    float ms = 0.f;
+    HIP_CHECK(hipEventElapsedTime(&ms, pr.first, pr.second));
+    h->rollout_ms += ms;
+    h->last_rollout_ms = ms;
+    h->timed_launches++;
+    h->ev_free.push_back(pr);
+  }
+  h->ev_inflight.erase(h->ev_inflight.begin(), h->ev_inflight.begin() + (long)done);
+}
+
+static void launch_rollout(pmaf_planner *h) {
+  dim3 grid((unsigned)h->n_blocks, (unsigned)h->D.P), block(64);
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (h->profiling) {
+    drain_events(h, false);
+    if (h->ev_free.empty()) {
+      hipEvent_t a, b;
+      HIP_CHECK(hipEventCreate(&a));
+      HIP_CHECK(hipEventCreate(&b));
+      h->ev_free.emplace_back(a, b);
+    }
+    e0 = h->ev_free.back().first;
+    e1 = h->ev_free.back().second;
+    h->ev_free.pop_back();
+    h->ev_inflight.emplace_back(e0, e1);
+    HIP_CHECK(hipEventRecord(e0, h->stream));
+  }
+  switch (h->lpa) {
+#define PMAF_CASE(L) case L: hipLaunchKernelGGL((k_rollout<L>), grid, block, h->lds_rollout, h->stream, h->D, h->cp); break;
+    PMAF_CASE(1) PMAF_CASE(2) PMAF_CASE(4) PMAF_CASE(8) PMAF_CASE(16) PMAF_CASE(32) PMAF_CASE(64)
+#undef PMAF_CASE
+    default: fail(PMAF_ERR_INVALID, "bad lanes_per_agent");
+  }
+  HIP_CHECK(hipGetLastError());
+  if (h->profiling) HIP_CHECK(hipEventRecord(e1, h->stream));
+  h->launches++;
+  h->scores_valid = true;
+  h->cp_valid = true;
+  h->rollout_pending = false;
+}
+
+static void sync(pmaf_planner *h) {
+  HIP_CHECK(hipStreamSynchronize(h->stream));
+  if (!h->ev_inflight.empty()) drain_events(h, true);
+}
+
+static void set_cost_params(pmaf_planner *h, const double *cost_gains, const double *ws) {
+  CostParams n{};
+  n.k_goal_dist = cost_gains[0];
+  n.k_path_len = cost_gains[1];
+  n.k_safe_dist = cost_gains[2];
+  n.k_workspace = cost_gains[3];
+  for (int i = 0; i < 6; i++) n.ws[i] = ws[i];
+  bool same_ws = h->cp_valid && n.k_workspace == h->cp.k_workspace && std::memcmp(n.ws, h->cp.ws, sizeof(n.ws)) == 0;
+  h->cp = n;
+  if (!same_ws) h->scores_valid = false;
+  h->cp_valid = true;
+}
+
+static void ensure_scores(pmaf_planner *h) {
+  if (h->scores_valid) return;
+  int total = h->D.P * h->D.N;
+  hipLaunchKernelGGL(k_score, dim3((total + 63) / 64), dim3(64), 0, h->stream, h->D, h->cp);
+  HIP_CHECK(hipGetLastError());
+  h->scores_valid = true;
+}
+
+static void upload_live_obstacles(pmaf_planner *h, const double *obstacles) {
+  if (!obstacles) return;
+  // ring of pinned staging buffers: wait only for the copy that last used this slot
+  int s = h->stage_next;
+  h->stage_next = (s + 1) % pmaf_planner::kStage;
+  HIP_CHECK(hipEventSynchronize(h->ev_stage[s]));
+  aos_to_soa(obstacles, h->h_stage[s], h->D.P, h->D.n_obs);
+  HIP_CHECK(hipMemcpyAsync(h->D.obs_live, h->h_stage[s], sizeof(double) * (size_t)h->D.P * 7 * h->D.n_obs,
+                           hipMemcpyHostToDevice, h->stream));
+  HIP_CHECK(hipEventRecord(h->ev_stage[s], h->stream));
+}
+
+static void launch_manager(pmaf_planner *h, const ManagerArgs &A) {
+  hipLaunchKernelGGL(k_manager, dim3((unsigned)h->D.P), dim3(64), h->lds_manager, h->stream, h->D, h->cp, A);
+  HIP_CHECK(hipGetLastError());
+}
+
+static void append_real_path(pmaf_planner *h) {
+  for (int p = 0; p < h->D.P; p++) {
+    const double *o = h->h_out + p * 8;
+    h->real_path[p].insert(h->real_path[p].end(), {o[1], o[2], o[3]});
+  }
+}
+
+template <typename F>
+static int guarded(F &&f) {
+  try {
+    f();
+    return PMAF_OK;
+  } catch (const StatusError &e) {
+    g_err = e.msg;
+    return e.code;
+  } catch (const HipError &e) {
+    char buf[512];
+    snprintf(buf, sizeof(buf), "HIP error %d (%s) at %s [pmaf_hip.hip:%d]", (int)e.e, hipGetErrorString(e.e), e.what, e.line);
+    g_err = buf;
+    return PMAF_ERR_DEVICE;
+  } catch (const std::bad_alloc &) {
+    g_err = "host allocation failed";
+    return PMAF_ERR_NOMEM;
+  } catch (...) {
+    g_err = "unknown error";
+    return PMAF_ERR_INVALID;
+  }
+}
+
+#define REQUIRE(c, msg) do { if (!(c)) fail(PMAF_ERR_INVALID, msg); } while (0)
+
+extern "C" {
+
+const char *pmaf_last_error(void) { return g_err.c_str(); }
+int pmaf_abi_version(void) { return PMAF_ABI_VERSION; }
+
+int pmaf_create(const pmaf_params *prm, pmaf_planner **out) {
+  pmaf_planner *h = nullptr;
+  int rc = guarded([&] {
+    REQUIRE(prm && out, "pmaf_create: NULL argument");
+    REQUIRE(prm->abi_version == PMAF_ABI_VERSION, "pmaf_create: ABI version mismatch");
+    REQUIRE(prm->n_populations >= 1 && prm->n_agents >= 1, "pmaf_create: need n_populations >= 1 and n_agents >= 1");
+    REQUIRE(prm->n_obstacles >= 1, "pmaf_create: obstacle list must hold at least the trailing repulsive obstacle");
+    REQUIRE(prm->max_prediction_steps >= 1, "pmaf_create: max_prediction_steps must be >= 1");
+    REQUIRE(prm->goal && prm->obstacles && prm->k_attr && prm->k_circ && prm->k_repel && prm->k_damp,
+            "pmaf_create: goal, obstacles and gain arrays are required");
+    int lp = prm->lanes_per_agent;
+    REQUIRE(lp == 0 || (lp >= 1 && lp <= 64 && (lp & (lp - 1)) == 0), "pmaf_create: lanes_per_agent must be 0 or a power of two <= 64");
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) fail(PMAF_ERR_DEVICE, "pmaf_create: no HIP device available (this library has no CPU fallback)");
+    h = new pmaf_planner();
+    if (prm->device >= 0) h->device = prm->device; else HIP_CHECK(hipGetDevice(&h->device));
+    REQUIRE(h->device < ndev, "pmaf_create: device ordinal out of range");
+    h->use_device();
+    HIP_CHECK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    HIP_CHECK(hipEventCreateWithFlags(&h->ev_mgr, hipEventDisableTiming));
+    const int P = prm->n_populations, N = prm->n_agents, n_obs = prm->n_obstacles, cap = prm->max_prediction_steps;
+    const int M = n_obs - 1;
+    DevView &D = h->D;
+    D.P = P; D.N = N; D.n_obs = n_obs; D.cap = cap;
+    D.C.dt = prm->dt; D.C.vel_max = prm->velocity_max; D.C.approach = prm->approach_dist;
+    D.C.shell = prm->detect_shell_rad; D.C.mass = prm->agent_mass; D.C.rad = prm->radius;
+    h->lpa = lp ? lp : pick_lpa(N, P, M);
+    REQUIRE((M + h->lpa - 1) / h->lpa <= 64, "pmaf_create: too many obstacles for this lanes_per_agent (need M <= 64*lanes_per_agent)");
+    h->n_blocks = (N * h->lpa + 63) / 64;
+    h->lds_rollout = sizeof(double) * 7 * n_obs + sizeof(int32_t) * n_obs;
+    h->lds_manager = sizeof(double) * 7 * n_obs;
+    REQUIRE(h->lds_rollout <= 160 * 1024, "pmaf_create: obstacle table does not fit in LDS");
+
+    size_t PN = (size_t)P * N;
+    double *goal = h->dalloc<double>(P * 3);
+    D.goal = goal;
+    D.agent_init_pos = h->dalloc<double>(P * 3);
+    D.start_pos = h->dalloc<double>(P * 3);
+    D.start_vel = h->dalloc<double>(P * 3);
+    D.obs_start = h->dalloc<double>((size_t)P * 7 * n_obs);
+    D.known_start = h->dalloc<int32_t>((size_t)P * n_obs);
+    D.obs_live = h->dalloc<double>((size_t)P * 7 * n_obs);
+    double *ka = h->dalloc<double>(PN), *kc = h->dalloc<double>(PN), *kr = h->dalloc<double>(PN), *kd = h->dalloc<double>(PN);
+    D.k_attr = ka; D.k_circ = kc; D.k_repel = kr; D.k_damp = kd;
+    int32_t *types = h->dalloc<int32_t>(N);
+    D.types = types;
+    D.rot = h->dalloc<double>(PN * 3 * n_obs);
+    double *rnd = h->dalloc<double>(PN * 3 * n_obs);
+    D.rnd = rnd;
+    D.paths = h->dalloc<double>(PN * (size_t)cap * 3);
+    D.n_points = h->dalloc<int32_t>(PN);
+    D.agent_vel = h->dalloc<double>(PN * 3);
+    D.min_obs = h->dalloc<double>(PN);
+    D.cost_ws = h->dalloc<double>(PN);
+    D.path_len = h->dalloc<double>(PN);
+    D.goal_dist = h->dalloc<double>(PN);
+    D.reached = h->dalloc<int32_t>(PN);
+    D.known_out = h->dalloc<int32_t>(PN * n_obs);
+    D.costs = h->dalloc<double>(PN);
+    D.real_pos = h->dalloc<double>(P * 3);
+    D.real_vel = h->dalloc<double>(P * 3);
+    D.real_force = h->dalloc<double>(P * 3);
+    D.real_init_pos = h->dalloc<double>(P * 3);
+    D.real_known = h->dalloc<int32_t>((size_t)P * n_obs);
+    D.real_rot = h->dalloc<double>((size_t)P * 3 * n_obs);
+    D.has_best = h->dalloc<int32_t>(P);
+    D.best_id = h->dalloc<int32_t>(P);
+    D.best_type = h->dalloc<int32_t>(P);
+    D.best_rnd = h->dalloc<double>((size_t)P * 3 * n_obs);
+    D.best_idx = h->dalloc<int32_t>(P);
+    D.step_counter = h->dalloc<unsigned long long>(1);
+    h->d_reset_in = h->dalloc<double>(P * 6);
+    h->d_agent_id = h->dalloc<int32_t>(P);
+    HIP_CHECK(hipHostMalloc((void **)&h->h_out, sizeof(double) * P * 8, hipHostMallocMapped));
+    HIP_CHECK(hipHostGetDevicePointer((void **)&h->d_out, h->h_out, 0));
+    for (int i = 0; i < pmaf_planner::kStage; i++) {
+      HIP_CHECK(hipHostMalloc((void **)&h->h_stage[i], sizeof(double) * (size_t)P * 7 * n_obs, hipHostMallocDefault));
+      HIP_CHECK(hipEventCreateWithFlags(&h->ev_stage[i], hipEventDisableTiming));
+    }
+    std::memset(h->h_out, 0, sizeof(double) * P * 8);
+
+    // ---- initial state = freshly constructed agents (cf_agent.h:69-97) ----
+    std::vector<double> init(P * 3, 0.0);
+    if (prm->init_pos) init.assign(prm->init_pos, prm->init_pos + P * 3);
+    h->goal_h.assign(prm->goal, prm->goal + P * 3);
+    h->upload(goal, prm->goal, P * 3);
+    // CfAgent::init_pos_ member starts at zero (cf_agent.h:78), positions at CfManager::init_pos_
+    h->upload(D.start_pos, init.data(), P * 3);
+    h->upload(D.real_pos, init.data(), P * 3);
+    std::vector<double> v0(P * 3, 0.0);
+    for (int p = 0; p < P; p++) v0[p * 3] = 0.01;  // vel_{0.01, 0, 0}, cf_agent.h:76
+    h->upload(D.start_vel, v0.data(), P * 3);
+    h->upload(D.real_vel, v0.data(), P * 3);
+    std::vector<double> soa((size_t)P * 7 * n_obs);
+    aos_to_soa(prm->obstacles, soa.data(), P, n_obs);
+    h->upload(D.obs_start, soa.data(), soa.size());
+    h->upload(D.obs_live, soa.data(), soa.size());
+    h->upload(ka, prm->k_attr, PN); h->upload(kc, prm->k_circ, PN);
+    h->upload(kr, prm->k_repel, PN); h->upload(kd, prm->k_damp, PN);
+    std::vector<int32_t> ty(N);
+    static const int layout[5] = {PMAF_HAD_HEURISTIC, PMAF_GOAL_HEURISTIC, PMAF_OBSTACLE_HEURISTIC,
+                                  PMAF_GOAL_OBSTACLE_HEURISTIC, PMAF_VEL_HEURISTIC};
+    for (int i = 0; i < N; i++) {
+      ty[i] = prm->agent_types ? prm->agent_types[i] : (i < 5 ? layout[i] : PMAF_RANDOM_AGENT);
+      REQUIRE(ty[i] >= PMAF_GOAL_HEURISTIC && ty[i] <= PMAF_HAD_HEURISTIC, "pmaf_create: agent type must be one of the six heuristics");
+    }
+    h->upload(types, ty.data(), N);
+    // rotation vectors start at (0,0,1), cf_agent.h:92-96; component-major [3][n_obs]
+    {
+      std::vector<double> rot(PN * 3 * n_obs, 0.0);
+      for (size_t pa = 0; pa < PN; pa++)
+        for (int i = 0; i < n_obs; i++) rot[(pa * 3 + 2) * n_obs + i] = 1.0;
+      h->upload(D.rot, rot.data(), rot.size());
+      std::vector<double> rr((size_t)P * 3 * n_obs, 0.0);
+      for (int p = 0; p < P; p++)
+        for (int i = 0; i < n_obs; i++) rr[((size_t)p * 3 + 2) * n_obs + i] = 1.0;
+      h->upload(D.real_rot, rr.data(), rr.size());
+    }
+    if (prm->random_vecs) {
+      std::vector<double> r(PN * 3 * n_obs);
+      for (size_t pa = 0; pa < PN; pa++)
+        for (int i = 0; i < n_obs; i++)
+          for (int c = 0; c < 3; c++) r[(pa * 3 + c) * n_obs + i] = prm->random_vecs[(pa * n_obs + i) * 3 + c];
+      h->upload(rnd, r.data(), r.size());
+    }
+    // 1-point paths at init_pos, min_obs = shell
+    {
+      std::vector<double> paths(PN * (size_t)cap * 3, 0.0);
+      std::vector<int32_t> np(PN, 1);
+      std::vector<double> mo(PN, prm->detect_shell_rad), av(PN * 3, 0.0);
+      for (size_t pa = 0; pa < PN; pa++) {
+        int p = (int)(pa / N);
+        for (int c = 0; c < 3; c++) paths[pa * cap * 3 + c] = init[p * 3 + c];
+        av[pa * 3] = 0.01;
+      }
+      h->upload(D.paths, paths.data(), paths.size());
+      h->upload(D.n_points, np.data(), np.size());
+      h->upload(D.min_obs, mo.data(), mo.size());
+      h->upload(D.agent_vel, av.data(), av.size());
+    }
+    h->real_path.assign(P, {});
+    for (int p = 0; p < P; p++) h->real_path[p].insert(h->real_path[p].end(), {init[p * 3], init[p * 3 + 1], init[p * 3 + 2]});
+    h->rollout_pending = true;
+    sync(h);
+    *out = h;
+  });
+  if (rc != PMAF_OK && h) { pmaf_destroy(h); }
+  return rc;
+}
+
+int pmaf_destroy(pmaf_planner *h) {
+  if (!h) return PMAF_OK;
+  (void)hipSetDevice(h->device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  for (void *p : h->allocs) (void)hipFree(p);
+  if (h->h_out) (void)hipHostFree(h->h_out);
+  for (int i = 0; i < pmaf_planner::kStage; i++) {
+    if (h->h_stage[i]) (void)hipHostFree(h->h_stage[i]);
+    if (h->ev_stage[i]) (void)hipEventDestroy(h->ev_stage[i]);
+  }
+  for (auto &e : h->ev_free) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+  for (auto &e : h->ev_inflight) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+  if (h->ev_mgr) (void)hipEventDestroy(h->ev_mgr);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+  return PMAF_OK;
+}
+
+int pmaf_set_initial_position(pmaf_planner *h, const double *pos) {
+  return guarded([&] {
+    REQUIRE(h && pos, "pmaf_set_initial_position: NULL argument");
+    h->use_device();
+    sync(h);
+    DevView &D = h->D;
+    const int P = D.P, N = D.N, cap = D.cap;
+    h->upload(D.agent_init_pos, pos, P * 3);
+    h->upload(D.real_init_pos, pos, P * 3);
+    h->upload(D.real_pos, pos, P * 3);
+    h->upload(D.start_pos, pos, P * 3);
+    // CfAgent::setPosition = clear + push_back for every predicted agent
+    std::vector<int32_t> np((size_t)P * N, 1);
+    h->upload(D.n_points, np.data(), np.size());
+    for (int p = 0; p < P; p++) {
+      for (int a = 0; a < N; a++)
+        HIP_CHECK(hipMemcpyAsync(D.paths + ((size_t)p * N + a) * cap * 3, pos + p * 3, sizeof(double) * 3,
+                                 hipMemcpyHostToDevice, h->stream));
+      // RealCfAgent::setPosition = push_back
+      h->real_path[p].insert(h->real_path[p].end(), {pos[p * 3], pos[p * 3 + 1], pos[p * 3 + 2]});
+    }
+    sync(h);
+    h->scores_valid = false;
+    h->rollout_pending = true;
+  });
+}
+
+int pmaf_set_real_position(pmaf_planner *h, const double *pos) {
+  return guarded([&] {
+    REQUIRE(h && pos, "pmaf_set_real_position: NULL argument");
+    h->use_device();
+    sync(h);
+    h->upload(h->D.real_pos, pos, h->D.P * 3);
+    for (int p = 0; p < h->D.P; p++)
+      h->real_path[p].insert(h->real_path[p].end(), {pos[p * 3], pos[p * 3 + 1], pos[p * 3 + 2]});
+  });
+}
+
+int pmaf_start(pmaf_planner *h) {
+  return guarded([&] {
+    REQUIRE(h, "pmaf_start: NULL handle");
+    h->use_device();
+    // a finished rollout that was not reset has nothing left to predict
+    // (guard B/src/cf_agent.cpp:310-311 is already false)
+    if (!h->rollout_pending) return;
+    if (!h->cp_valid) {  // no evaluate yet: score with neutral workspace terms, rescored on evaluate
+      h->cp = CostParams{};
+      h->cp.ws[0] = h->cp.ws[2] = h->cp.ws[4] = INFINITY;
+      h->cp.ws[1] = h->cp.ws[3] = h->cp.ws[5] = -INFINITY;
+    }
+    bool had_cp = h->cp_valid;
+    launch_rollout(h);
+    h->cp_valid = had_cp;
+    if (!had_cp) h->scores_valid = false;
+  });
+}
+
+int pmaf_stop(pmaf_planner *h) {
+  return guarded([&] {
+    REQUIRE(h, "pmaf_stop: NULL handle");
+    h->use_device();
+    sync(h);
+  });
+}
+
+int pmaf_evaluate(pmaf_planner *h, const double *cost_gains, const double *ws, int32_t *best_idx) {
+  return guarded([&] {
+    REQUIRE(h && cost_gains && ws, "pmaf_evaluate: NULL argument");
+    h->use_device();
+    set_cost_params(h, cost_gains, ws);
+    ensure_scores(h);
+    ManagerArgs A{};
+    A.do_select = 1;
+    A.out = h->d_out;
+    launch_manager(h, A);
+    sync(h);
+    if (best_idx)
+      for (int p = 0; p < h->D.P; p++) best_idx[p] = (int32_t)h->h_out[p * 8];
+  });
+}
+
+int pmaf_move_real(pmaf_planner *h, const double *obstacles, double dt, int32_t steps, const int32_t *agent_id) {
+  return guarded([&] {
+    REQUIRE(h && agent_id, "pmaf_move_real: NULL argument");
+    REQUIRE(steps >= 0, "pmaf_move_real: steps must be >= 0");
+    h->use_device();
+    sync(h);
+    int32_t hb = 0;
+    h->download(&hb, h->D.has_best, 1);
+    if (!hb) fail(PMAF_ERR_STATE, "pmaf_move_real: no best agent yet (call pmaf_evaluate first; the reference dereferences a null best_agent_ here)");
+    for (int p = 0; p < h->D.P; p++) REQUIRE(agent_id[p] >= 0 && agent_id[p] < h->D.N, "pmaf_move_real: agent_id out of range");
+    upload_live_obstacles(h, obstacles);
+    h->upload(h->d_agent_id, agent_id, h->D.P);
+    for (int s = 0; s < steps; s++) {
+      ManagerArgs A{};
+      A.do_move = 1;
+      A.dt_real = dt;
+      A.agent_id = h->d_agent_id;
+      A.out = h->d_out;
+      launch_manager(h, A);
+      sync(h);
+      append_real_path(h);
+    }
+  });
+}
+
+int pmaf_reset_agents(pmaf_planner *h, const double *pos, const double *vel, const double *obstacles) {
+  return guarded([&] {
+    REQUIRE(h && pos && vel, "pmaf_reset_agents: NULL argument");
+    h->use_device();
+    sync(h);
+    upload_live_obstacles(h, obstacles);
+    std::vector<double> in(h->D.P * 6);
+    for (int p = 0; p < h->D.P; p++)
+      for (int c = 0; c < 3; c++) { in[p * 6 + c] = pos[p * 3 + c]; in[p * 6 + 3 + c] = vel[p * 3 + c]; }
+    h->upload(h->d_reset_in, in.data(), in.size());
+    ManagerArgs A{};
+    A.do_reset = 1;
+    A.reset_in = h->d_reset_in;
+    launch_manager(h, A);
+    sync(h);
+    h->scores_valid = false;
+    h->rollout_pending = true;
+  });
+}
+
+int pmaf_tick(pmaf_planner *h, const double *obstacles, double dt, const double *cost_gains, const double *ws,
+              int32_t *best_idx, double *next_pos, double *next_vel) {
+  return guarded([&] {
+    REQUIRE(h && cost_gains && ws, "pmaf_tick: NULL argument");
+    h->use_device();
+    set_cost_params(h, cost_gains, ws);
+    upload_live_obstacles(h, obstacles);
+    ensure_scores(h);
+    ManagerArgs A{};
+    A.do_select = 1; A.do_move = 1; A.do_reset = 1; A.reset_from_real = 1;
+    A.dt_real = dt;
+    A.out = h->d_out;
+    launch_manager(h, A);
+    HIP_CHECK(hipEventRecord(h->ev_mgr, h->stream));
+    h->rollout_pending = true;
+    launch_rollout(h);
+    // outputs of k_manager land in mapped pinned memory; wait for it only
+    HIP_CHECK(hipEventSynchronize(h->ev_mgr));
+    append_real_path(h);
+    for (int p = 0; p < h->D.P; p++) {
+      const double *o = h->h_out + p * 8;
+      if (best_idx) best_idx[p] = (int32_t)o[0];
+      if (next_pos) { next_pos[p * 3] = o[1]; next_pos[p * 3 + 1] = o[2]; next_pos[p * 3 + 2] = o[3]; }
+      if (next_vel) { next_vel[p * 3] = o[4]; next_vel[p * 3 + 1] = o[5]; next_vel[p * 3 + 2] = o[6]; }
+    }
+  });
+}
+
+int pmaf_link_force(pmaf_planner *h, int32_t pop, int32_t n, const double *link_pos, const double *k_r_force,
+                    const double *obstacles, double *out) {
+  return guarded([&] {
+    REQUIRE(h && link_pos && k_r_force && obstacles && out, "pmaf_link_force: NULL argument");
+    REQUIRE(pop >= 0 && pop < h->D.P && n >= 0, "pmaf_link_force: bad population or count");
+    if (n == 0) return;
+    h->use_device();
+    double *d_lp = nullptr, *d_k = nullptr, *d_s = nullptr, *d_o = nullptr;
+    HIP_CHECK(hipMalloc((void **)&d_lp, sizeof(double) * 3 * n));
+    HIP_CHECK(hipMalloc((void **)&d_k, sizeof(double) * n));
+    HIP_CHECK(hipMalloc((void **)&d_s, sizeof(double) * 7));
+    HIP_CHECK(hipMalloc((void **)&d_o, sizeof(double) * 3 * n));
+    const double *sent = obstacles + ((size_t)pop * h->D.n_obs + (h->D.n_obs - 1)) * 7;
+    HIP_CHECK(hipMemcpyAsync(d_lp, link_pos, sizeof(double) * 3 * n, hipMemcpyHostToDevice, h->stream));
+    HIP_CHECK(hipMemcpyAsync(d_k, k_r_force, sizeof(double) * n, hipMemcpyHostToDevice, h->stream));
+    HIP_CHECK(hipMemcpyAsync(d_s, sent, sizeof(double) * 7, hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(k_link_force, dim3((n + 63) / 64), dim3(64), 0, h->stream, n, d_lp, d_k, d_s, h->D.C.rad,
+                       h->D.C.shell, d_o);
+    HIP_CHECK(hipMemcpyAsync(out, d_o, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, h->stream));
+    sync(h);
+    (void)hipFree(d_lp); (void)hipFree(d_k); (void)hipFree(d_s); (void)hipFree(d_o);
+  });
+}
+
+#define GETTER_PROLOGUE(name)                    \
+  REQUIRE(h, name ": NULL handle");              \
+  h->use_device();                               \
+  sync(h);                                       \
+  const DevView &D = h->D;                       \
+  const size_t PN = (size_t)D.P * D.N;           \
+  (void)PN;
+
+int pmaf_get_paths(pmaf_planner *h, double *paths, int32_t *n_points) {
+  return guarded([&] {
+    GETTER_PROLOGUE("pmaf_get_paths")
+    if (paths) h->download(paths, D.paths, PN * (size_t)D.cap * 3);
+    if (n_points) h->download(n_points, D.n_points, PN);
+  });
+}
+int pmaf_get_costs(pmaf_planner *h, double *costs) {
+  return guarded([&] { GETTER_PROLOGUE("pmaf_get_costs") REQUIRE(costs, "NULL out"); h->download(costs, D.costs, PN); });
+}
+int pmaf_get_path_lengths(pmaf_planner *h, double *out) {
+  return guarded([&] {
+    GETTER_PROLOGUE("pmaf_get_path_lengths")
+    REQUIRE(out, "NULL out");
+    if (!h->cp_valid) {
+      h->cp = CostParams{};
+      h->cp.ws[0] = h->cp.ws[2] = h->cp.ws[4] = INFINITY;
+      h->cp.ws[1] = h->cp.ws[3] = h->cp.ws[5] = -INFINITY;
+    }
+    bool had = h->cp_valid;
+    ensure_scores(h);
+    if (!had) h->scores_valid = false;
+    sync(h);
+    h->download(out, D.path_len, PN);
+  });
+}
+int pmaf_get_min_obs_dist(pmaf_planner *h, double *out) {
+  return guarded([&] { GETTER_PROLOGUE("pmaf_get_min_obs_dist") REQUIRE(out, "NULL out"); h->download(out, D.min_obs, PN); });
+}
+int pmaf_get_success(pmaf_planner *h, int32_t *out) {
+  return guarded([&] { GETTER_PROLOGUE("pmaf_get_success") REQUIRE(out, "NULL out"); h->download(out, D.reached, PN); });
+}
+int pmaf_get_agent_velocities(pmaf_planner *h, double *out) {
+  return guarded([&] { GETTER_PROLOGUE("pmaf_get_agent_velocities") REQUIRE(out, "NULL out"); h->download(out, D.agent_vel, PN * 3); });
+}
+int pmaf_get_rotation_vectors(pmaf_planner *h, double *rot, int32_t *known) {
+  return guarded([&] {
+    GETTER_PROLOGUE("pmaf_get_rotation_vectors")
+    const int n_obs = D.n_obs;
+    if (rot) {
+      std::vector<double> r(PN * 3 * n_obs);
+      h->download(r.data(), D.rot, r.size());
+      for (size_t pa = 0; pa < PN; pa++)
+        for (int i = 0; i < n_obs; i++)
+          for (int c = 0; c < 3; c++) rot[(pa * n_obs + i) * 3 + c] = r[(pa * 3 + c) * n_obs + i];
+    }
+    if (known) h->download(known, D.known_out, PN * n_obs);
+  });
+}
+int pmaf_get_real_state(pmaf_planner *h, double *pos, double *vel, double *force) {
+  return guarded([&] {
+    GETTER_PROLOGUE("pmaf_get_real_state")
+    if (pos) h->download(pos, D.real_pos, D.P * 3);
+    if (vel) h->download(vel, D.real_vel, D.P * 3);
+    if (force) h->download(force, D.real_force, D.P * 3);
+  });
+}
+int pmaf_get_real_known(pmaf_planner *h, int32_t *known, double *rot) {
+  return guarded([&] {
+    GETTER_PROLOGUE("pmaf_get_real_known")
+    const int n_obs = D.n_obs;
+    if (known) h->download(known, D.real_known, (size_t)D.P * n_obs);
+    if (rot) {
+      std::vector<double> r((size_t)D.P * 3 * n_obs);
+      h->download(r.data(), D.real_rot, r.size());
+      for (int p = 0; p < D.P; p++)
+        for (int i = 0; i < n_obs; i++)
+          for (int c = 0; c < 3; c++) rot[((size_t)p * n_obs + i) * 3 + c] = r[((size_t)p * 3 + c) * n_obs + i];
+    }
+  });
+}
+int pmaf_get_real_path(pmaf_planner *h, int32_t pop, double *out, int32_t max_points, int32_t *n_total) {
+  return guarded([&] {
+    REQUIRE(h && pop >= 0 && pop < h->D.P, "pmaf_get_real_path: bad argument");
+    const std::vector<double> &rp = h->real_path[pop];
+    int n = (int)(rp.size() / 3);
+    if (n_total) *n_total = n;
+    if (out && max_points > 0) std::memcpy(out, rp.data(), sizeof(double) * 3 * (size_t)(n < max_points ? n : max_points));
+  });
+}
+int pmaf_get_dist_from_goal(pmaf_planner *h, double *out) {
+  return guarded([&] {
+    GETTER_PROLOGUE("pmaf_get_dist_from_goal")
+    REQUIRE(out, "NULL out");
+    // (goal_pos_ - real.getLatestPosition()).norm(), cf_manager.h:87-89; same
+    // operation order as the device code, evaluated on the 3 downloaded doubles
+    std::vector<double> rp(D.P * 3);
+    h->download(rp.data(), D.real_pos, rp.size());
+    for (int p = 0; p < D.P; p++) {
+      double dx = h->goal_h[p * 3] - rp[p * 3], dy = h->goal_h[p * 3 + 1] - rp[p * 3 + 1], dz = h->goal_h[p * 3 + 2] - rp[p * 3 + 2];
+#ifdef PMAF_DOT_RIGHT_ASSOC
+      out[p] = std::sqrt(dx * dx + (dy * dy + dz * dz));
+#else
+      out[p] = std::sqrt((dx * dx + dy * dy) + dz * dz);
+#endif
+    }
+  });
+}
+int pmaf_get_best(pmaf_planner *h, int32_t *type, int32_t *id) {
+  return guarded([&] {
+    GETTER_PROLOGUE("pmaf_get_best")
+    std::vector<int32_t> hb(D.P), bt(D.P), bi(D.P);
+    h->download(hb.data(), D.has_best, D.P);
+    h->download(bt.data(), D.best_type, D.P);
+    h->download(bi.data(), D.best_id, D.P);
+    for (int p = 0; p < D.P; p++) {
+      if (type) type[p] = hb[p] ? bt[p] : -1;
+      if (id) id[p] = hb[p] ? bi[p] : 0;
+    }
+  });
+}
+int pmaf_get_prediction_times_ns(pmaf_planner *h, double *out) {
+  return guarded([&] {
+    GETTER_PROLOGUE("pmaf_get_prediction_times_ns")
+    REQUIRE(out, "NULL out");
+    if (!h->profiling) fail(PMAF_ERR_STATE, "pmaf_get_prediction_times_ns: enable pmaf_set_profiling first");
+    for (size_t i = 0; i < PN; i++) out[i] = h->last_rollout_ms * 1e6;
+  });
+}
+
+int pmaf_set_best(pmaf_planner *h, const int32_t *id, const int32_t *type, const double *rand_vecs) {
+  return guarded([&] {
+    REQUIRE(h && id && type, "pmaf_set_best: NULL argument");
+    h->use_device();
+    sync(h);
+    const DevView &D = h->D;
+    std::vector<int32_t> hb(D.P);
+    for (int p = 0; p < D.P; p++) {
+      REQUIRE(id[p] >= 0 && id[p] <= D.N, "pmaf_set_best: id out of range");
+      hb[p] = id[p] > 0;
+    }
+    h->upload(D.has_best, hb.data(), D.P);
+    h->upload(D.best_id, id, D.P);
+    h->upload(D.best_type, type, D.P);
+    if (rand_vecs) {
+      const int n_obs = D.n_obs;
+      std::vector<double> r((size_t)D.P * 3 * n_obs);
+      for (int p = 0; p < D.P; p++)
+        for (int i = 0; i < n_obs; i++)
+          for (int c = 0; c < 3; c++) r[((size_t)p * 3 + c) * n_obs + i] = rand_vecs[((size_t)p * n_obs + i) * 3 + c];
+      h->upload(D.best_rnd, r.data(), r.size());
+    }
+  });
+}
+
+size_t pmaf_winner_record_doubles(const pmaf_planner *h) { return h ? 4 + (size_t)h->D.cap * 3 : 0; }
+
+int pmaf_write_winner_records(pmaf_planner *h, void *dst_device, size_t bytes) {
+  return guarded([&] {
+    REQUIRE(h && dst_device, "pmaf_write_winner_records: NULL argument");
+    REQUIRE(bytes >= sizeof(double) * pmaf_winner_record_doubles(h) * h->D.P, "pmaf_write_winner_records: buffer too small");
+    h->use_device();
+    hipLaunchKernelGGL(k_winner, dim3((unsigned)h->D.P), dim3(256), 0, h->stream, h->D, (double *)dst_device);
+    HIP_CHECK(hipGetLastError());
+  });
+}
+
+void *pmaf_stream(pmaf_planner *h) { return h ? (void *)h->stream : nullptr; }
+
+int pmaf_set_profiling(pmaf_planner *h, int32_t enable) {
+  return guarded([&] {
+    REQUIRE(h, "pmaf_set_profiling: NULL handle");
+    h->use_device();
+    sync(h);
+    h->profiling = enable != 0;
+  });
+}
+int pmaf_get_kernel_stats(pmaf_planner *h, double *rollout_ms, int64_t *launches, int64_t *agent_steps) {
+  return guarded([&] {
+    GETTER_PROLOGUE("pmaf_get_kernel_stats")
+    if (rollout_ms) *rollout_ms = h->rollout_ms;
+    if (launches) *launches = h->profiling ? h->timed_launches : h->launches;
+    if (agent_steps) {
+      unsigned long long s = 0;
+      h->download(&s, D.step_counter, 1);
+      *agent_steps = (int64_t)s;
+    }
+  });
+}
+int pmaf_reset_kernel_stats(pmaf_planner *h) {
+  return guarded([&] {
+    REQUIRE(h, "pmaf_reset_kernel_stats: NULL handle");
+    h->use_device();
+    sync(h);
+    h->rollout_ms = 0.0;
+    h->launches = 0;
+    h->timed_launches = 0;
+    HIP_CHECK(hipMemsetAsync(h->D.step_counter, 0, sizeof(unsigned long long), h->stream));
+    sync(h);
+  });
+}
+int pmaf_get_launch_config(pmaf_planner *h, int32_t *lanes_per_agent, int32_t *n_blocks, int32_t *lds_bytes) {
+  return guarded([&] {
+    REQUIRE(h, "pmaf_get_launch_config: NULL handle");
+    if (lanes_per_agent) *lanes_per_agent = h->lpa;
+    if (n_blocks) *n_blocks = h->n_blocks * h->D.P;
+    if (lds_bytes) *lds_bytes = (int32_t)h->lds_rollout;
+  });
+}
+
+}  // extern "C"

@@ -1,0 +1,356 @@
+"""ctypes host binding of libpmaf_hip.so (include/pmaf.h).
+
+Python is only the test/bench orchestration layer of this build; the product
+host layer is the C++ facade in include/bimanual_planning_ros/. The binding is
+deliberately thin: one method per C-ABI entry point, numpy in / numpy out,
+every non-zero status raised as PmafError. There is no fallback: if the
+shared library is missing or no HIP device is present this module raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libpmaf_hip.so")
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int32)
+
+
+class PmafError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("pmaf status %d: %s" % (code, msg))
+        self.code = code
+
+
+class PmafParams(C.Structure):
+    _fields_ = [
+        ("abi_version", C.c_int32), ("n_populations", C.c_int32), ("n_agents", C.c_int32),
+        ("n_obstacles", C.c_int32), ("max_prediction_steps", C.c_int32), ("device", C.c_int32),
+        ("lanes_per_agent", C.c_int32), ("reserved", C.c_int32),
+        ("dt", C.c_double), ("velocity_max", C.c_double), ("approach_dist", C.c_double),
+        ("detect_shell_rad", C.c_double), ("agent_mass", C.c_double), ("radius", C.c_double),
+        ("goal", _dp), ("init_pos", _dp), ("obstacles", _dp),
+        ("k_attr", _dp), ("k_circ", _dp), ("k_repel", _dp), ("k_damp", _dp),
+        ("agent_types", _ip), ("random_vecs", _dp),
+    ]
+
+
+# every symbol include/pmaf.h declares: name -> (restype, argtypes)
+_V = C.c_void_p
+SYMBOLS = {
+    "pmaf_create": (C.c_int, [C.POINTER(PmafParams), C.POINTER(_V)]),
+    "pmaf_destroy": (C.c_int, [_V]),
+    "pmaf_last_error": (C.c_char_p, []),
+    "pmaf_abi_version": (C.c_int, []),
+    "pmaf_set_initial_position": (C.c_int, [_V, _dp]),
+    "pmaf_set_real_position": (C.c_int, [_V, _dp]),
+    "pmaf_start": (C.c_int, [_V]),
+    "pmaf_stop": (C.c_int, [_V]),
+    "pmaf_evaluate": (C.c_int, [_V, _dp, _dp, _ip]),
+    "pmaf_move_real": (C.c_int, [_V, _dp, C.c_double, C.c_int32, _ip]),
+    "pmaf_reset_agents": (C.c_int, [_V, _dp, _dp, _dp]),
+    "pmaf_tick": (C.c_int, [_V, _dp, C.c_double, _dp, _dp, _ip, _dp, _dp]),
+    "pmaf_link_force": (C.c_int, [_V, C.c_int32, C.c_int32, _dp, _dp, _dp, _dp]),
+    "pmaf_get_paths": (C.c_int, [_V, _dp, _ip]),
+    "pmaf_get_costs": (C.c_int, [_V, _dp]),
+    "pmaf_get_path_lengths": (C.c_int, [_V, _dp]),
+    "pmaf_get_min_obs_dist": (C.c_int, [_V, _dp]),
+    "pmaf_get_success": (C.c_int, [_V, _ip]),
+    "pmaf_get_agent_velocities": (C.c_int, [_V, _dp]),
+    "pmaf_get_rotation_vectors": (C.c_int, [_V, _dp, _ip]),
+    "pmaf_get_real_state": (C.c_int, [_V, _dp, _dp, _dp]),
+    "pmaf_get_real_known": (C.c_int, [_V, _ip, _dp]),
+    "pmaf_get_real_path": (C.c_int, [_V, C.c_int32, _dp, C.c_int32, _ip]),
+    "pmaf_get_dist_from_goal": (C.c_int, [_V, _dp]),
+    "pmaf_get_best": (C.c_int, [_V, _ip, _ip]),
+    "pmaf_get_prediction_times_ns": (C.c_int, [_V, _dp]),
+    "pmaf_set_best": (C.c_int, [_V, _ip, _ip, _dp]),
+    "pmaf_write_winner_records": (C.c_int, [_V, _V, C.c_size_t]),
+    "pmaf_winner_record_doubles": (C.c_size_t, [_V]),
+    "pmaf_stream": (_V, [_V]),
+    "pmaf_set_profiling": (C.c_int, [_V, C.c_int32]),
+    "pmaf_get_kernel_stats": (C.c_int, [_V, _dp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "pmaf_reset_kernel_stats": (C.c_int, [_V]),
+    "pmaf_get_launch_config": (C.c_int, [_V, _ip, _ip, _ip]),
+}
+
+_LIB = None
+
+
+def load_library(path=None):
+    """dlopen libpmaf_hip.so and type every exported symbol. Raises OSError if
+    the library has not been built (python __graft_entry__.py build)."""
+    global _LIB
+    if _LIB is None:
+        path = path or LIB_PATH
+        if not os.path.exists(path):
+            raise OSError("libpmaf_hip.so not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(expected at %s); there is no CPU fallback" % path)
+        lib = C.CDLL(path)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(lib, name)  # AttributeError if a declared symbol is missing
+            fn.restype = res
+            fn.argtypes = args
+        _LIB = lib
+    return _LIB
+
+
+def _d(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if shape is not None:
+        a = np.ascontiguousarray(np.broadcast_to(a, shape))
+    return a
+
+
+def _p(a):
+    return a.ctypes.data_as(_dp) if a is not None else None
+
+
+def _pi(a):
+    return a.ctypes.data_as(_ip) if a is not None else None
+
+
+class PmafPlanner:
+    """P populations of N agents on one MI355X. `scenes` is one scene dict or
+    a list of P scene dicts (see scenes.py) sharing N, n_obs, capacity and the
+    scalar parameters. Method names follow the C-ABI / CfManager."""
+
+    def __init__(self, scenes, device=-1, lanes_per_agent=0, mgr_init_pos=None):
+        if isinstance(scenes, dict):
+            scenes = [scenes]
+        self.L = load_library()
+        s0 = scenes[0]
+        self.P = len(scenes)
+        self.N = int(s0["n_agents"])
+        self.n_obs = int(s0["obstacles"].shape[0])
+        self.cap = int(s0["max_prediction_steps"])
+        P, N, n_obs = self.P, self.N, self.n_obs
+        for s in scenes:
+            assert int(s["n_agents"]) == N and s["obstacles"].shape[0] == n_obs and int(s["max_prediction_steps"]) == self.cap
+        prm = PmafParams()
+        prm.abi_version = self.L.pmaf_abi_version()
+        prm.n_populations, prm.n_agents, prm.n_obstacles = P, N, n_obs
+        prm.max_prediction_steps = self.cap
+        prm.device = device
+        prm.lanes_per_agent = lanes_per_agent
+        prm.dt = s0["dt"]
+        prm.velocity_max = s0["velocity_max"]
+        prm.approach_dist = s0["approach_dist"]
+        prm.detect_shell_rad = s0["detect_shell_rad"]
+        prm.agent_mass = s0.get("agent_mass", 1.0)
+        prm.radius = s0.get("radius", 0.05)
+        keep = []
+        goal = _d(np.stack([s["goal"] for s in scenes])); keep.append(goal)
+        prm.goal = _p(goal)
+        if mgr_init_pos is not None:
+            ip = _d(mgr_init_pos, (P, 3)); keep.append(ip)
+            prm.init_pos = _p(ip)
+        obs = _d(np.stack([s["obstacles"] for s in scenes])); keep.append(obs)
+        prm.obstacles = _p(obs)
+        for k in ("k_attr", "k_circ", "k_repel", "k_damp"):
+            g = _d(np.stack([np.broadcast_to(np.asarray(s[k], dtype=np.float64), (N,)) for s in scenes]))
+            keep.append(g)
+            setattr(prm, k, _p(g))
+        types = s0.get("agent_types")
+        if types is not None:
+            types = np.ascontiguousarray(types, dtype=np.int32); keep.append(types)
+            prm.agent_types = _pi(types)
+        rv = _d(np.stack([s["random_vecs"] for s in scenes])); keep.append(rv)
+        assert rv.shape == (P, N, n_obs, 3)
+        prm.random_vecs = _p(rv)
+        h = _V()
+        self._h = None
+        self._chk(self.L.pmaf_create(C.byref(prm), C.byref(h)))
+        self._h = h
+
+    # -- plumbing --
+    def _chk(self, rc):
+        if rc != 0:
+            raise PmafError(rc, self.L.pmaf_last_error().decode())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.L.pmaf_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _sq(self, a):
+        """drop the population axis for single-population handles"""
+        return a[0] if self.P == 1 else a
+
+    # -- CfManager surface --
+    def set_initial_position(self, pos):
+        a = _d(pos, (self.P, 3))
+        self._chk(self.L.pmaf_set_initial_position(self._h, _p(a)))
+
+    def set_real_position(self, pos):
+        a = _d(pos, (self.P, 3))
+        self._chk(self.L.pmaf_set_real_position(self._h, _p(a)))
+
+    def start(self):
+        self._chk(self.L.pmaf_start(self._h))
+
+    def stop(self):
+        self._chk(self.L.pmaf_stop(self._h))
+
+    def rollout(self):
+        """start + stop: run every agent's prediction to its guard."""
+        self.start()
+        self.stop()
+
+    def evaluate(self, cost_gains, ws):
+        g, w = _d(cost_gains), _d(ws)
+        best = np.zeros(self.P, dtype=np.int32)
+        self._chk(self.L.pmaf_evaluate(self._h, _p(g), _p(w), _pi(best)))
+        return int(best[0]) if self.P == 1 else best
+
+    def _obs(self, obstacles):
+        if obstacles is None:
+            return None
+        return _d(obstacles).reshape(self.P, self.n_obs, 7)
+
+    def move_real(self, obstacles, dt, steps, agent_id):
+        o = self._obs(obstacles)
+        ids = np.ascontiguousarray(np.broadcast_to(np.asarray(agent_id, dtype=np.int32), (self.P,)))
+        self._chk(self.L.pmaf_move_real(self._h, _p(o), float(dt), int(steps), _pi(ids)))
+
+    def reset_agents(self, pos, vel, obstacles):
+        p, v, o = _d(pos, (self.P, 3)), _d(vel, (self.P, 3)), self._obs(obstacles)
+        self._chk(self.L.pmaf_reset_agents(self._h, _p(p), _p(v), _p(o)))
+
+    def tick(self, obstacles, dt, cost_gains, ws, want_outputs=True):
+        o = self._obs(obstacles)
+        g, w = _d(cost_gains), _d(ws)
+        best = np.zeros(self.P, dtype=np.int32)
+        npos = np.zeros((self.P, 3))
+        nvel = np.zeros((self.P, 3))
+        self._chk(self.L.pmaf_tick(self._h, _p(o), float(dt), _p(g), _p(w), _pi(best), _p(npos), _p(nvel)))
+        self.last_next_pos, self.last_next_vel = npos, nvel
+        return int(best[0]) if self.P == 1 else best
+
+    def link_force(self, link_pos, k_r_force, obstacles, pop=0):
+        lp, k, o = _d(link_pos), _d(k_r_force), self._obs(obstacles)
+        out = np.zeros_like(lp)
+        self._chk(self.L.pmaf_link_force(self._h, pop, lp.shape[0], _p(lp), _p(k), _p(o), _p(out)))
+        return out
+
+    # -- getters --
+    def paths(self):
+        paths = np.zeros((self.P, self.N, self.cap, 3))
+        n = np.zeros((self.P, self.N), dtype=np.int32)
+        self._chk(self.L.pmaf_get_paths(self._h, _p(paths), _pi(n)))
+        return self._sq(paths), self._sq(n)
+
+    def n_points(self):
+        n = np.zeros((self.P, self.N), dtype=np.int32)
+        self._chk(self.L.pmaf_get_paths(self._h, None, _pi(n)))
+        return self._sq(n)
+
+    def _get(self, fn, shape, dtype=np.float64):
+        out = np.zeros(shape, dtype=dtype)
+        ptr = _p(out) if dtype == np.float64 else _pi(out)
+        self._chk(getattr(self.L, fn)(self._h, ptr))
+        return self._sq(out)
+
+    def costs(self):
+        return self._get("pmaf_get_costs", (self.P, self.N))
+
+    def path_lengths(self):
+        return self._get("pmaf_get_path_lengths", (self.P, self.N))
+
+    def min_obs_dist(self):
+        return self._get("pmaf_get_min_obs_dist", (self.P, self.N))
+
+    def success(self):
+        return self._get("pmaf_get_success", (self.P, self.N), np.int32)
+
+    def agent_vel(self):
+        return self._get("pmaf_get_agent_velocities", (self.P, self.N, 3))
+
+    def rot_vecs(self):
+        rot = np.zeros((self.P, self.N, self.n_obs, 3))
+        self._chk(self.L.pmaf_get_rotation_vectors(self._h, _p(rot), None))
+        return self._sq(rot)
+
+    def known(self):
+        known = np.zeros((self.P, self.N, self.n_obs), dtype=np.int32)
+        self._chk(self.L.pmaf_get_rotation_vectors(self._h, None, _pi(known)))
+        return self._sq(known)
+
+    def real_state(self):
+        pos, vel, force = np.zeros((self.P, 3)), np.zeros((self.P, 3)), np.zeros((self.P, 3))
+        self._chk(self.L.pmaf_get_real_state(self._h, _p(pos), _p(vel), _p(force)))
+        return self._sq(pos), self._sq(vel), self._sq(force)
+
+    def real_known(self):
+        known = np.zeros((self.P, self.n_obs), dtype=np.int32)
+        rot = np.zeros((self.P, self.n_obs, 3))
+        self._chk(self.L.pmaf_get_real_known(self._h, _pi(known), _p(rot)))
+        return self._sq(known), self._sq(rot)
+
+    def real_path(self, pop=0):
+        n = C.c_int32(0)
+        self._chk(self.L.pmaf_get_real_path(self._h, pop, None, 0, C.byref(n)))
+        out = np.zeros((n.value, 3))
+        self._chk(self.L.pmaf_get_real_path(self._h, pop, _p(out), n.value, None))
+        return out
+
+    def dist_from_goal(self):
+        out = self._get("pmaf_get_dist_from_goal", (self.P,))
+        return float(out) if self.P == 1 else out
+
+    def best(self):
+        t = np.zeros(self.P, dtype=np.int32)
+        i = np.zeros(self.P, dtype=np.int32)
+        self._chk(self.L.pmaf_get_best(self._h, _pi(t), _pi(i)))
+        return t, i
+
+    def best_type(self):
+        return int(self.best()[0][0])
+
+    def best_id(self):
+        return int(self.best()[1][0])
+
+    def set_best(self, ids, types, rand_vecs=None):
+        ids = np.ascontiguousarray(np.broadcast_to(np.asarray(ids, dtype=np.int32), (self.P,)))
+        types = np.ascontiguousarray(np.broadcast_to(np.asarray(types, dtype=np.int32), (self.P,)))
+        rv = _d(rand_vecs).reshape(self.P, self.n_obs, 3) if rand_vecs is not None else None
+        self._chk(self.L.pmaf_set_best(self._h, _pi(ids), _pi(types), _p(rv)))
+
+    def prediction_times_ns(self):
+        return self._get("pmaf_get_prediction_times_ns", (self.P, self.N))
+
+    # -- sharding / measurement --
+    def winner_record_doubles(self):
+        return int(self.L.pmaf_winner_record_doubles(self._h))
+
+    def write_winner_records(self, device_ptr, nbytes):
+        self._chk(self.L.pmaf_write_winner_records(self._h, C.c_void_p(device_ptr), nbytes))
+
+    def stream(self):
+        return self.L.pmaf_stream(self._h)
+
+    def set_profiling(self, on=True):
+        self._chk(self.L.pmaf_set_profiling(self._h, 1 if on else 0))
+
+    def kernel_stats(self):
+        ms = C.c_double(0)
+        n = C.c_int64(0)
+        steps = C.c_int64(0)
+        self._chk(self.L.pmaf_get_kernel_stats(self._h, C.byref(ms), C.byref(n), C.byref(steps)))
+        return ms.value, n.value, steps.value
+
+    def reset_kernel_stats(self):
+        self._chk(self.L.pmaf_reset_kernel_stats(self._h))
+
+    def launch_config(self):
+        a, b, c = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+        self._chk(self.L.pmaf_get_launch_config(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return dict(lanes_per_agent=a.value, n_blocks=b.value, lds_bytes=c.value)

@@ -1,0 +1,17 @@
+import sys, time, numpy as np
+sys.path.insert(0,'/root/repo')
+import __graft_entry__ as g
+pm=g.load_package()
+for name,lpas in (("C2",[64,32,16,8]),("C3",[64,16,4]),("C1",[64])):
+    sc=pm.scenes.config_scene(name)
+    for lpa in lpas:
+        h=pm.PmafPlanner(sc,device=0,mgr_init_pos=sc["start"],lanes_per_agent=lpa); h.set_initial_position(sc["start"])
+        h.set_profiling(True)
+        for _ in range(20): h.tick(None,sc["dt"],sc["cost_gains"],sc["ws_limits"])
+        h.stop(); h.reset_kernel_stats()
+        t0=time.perf_counter(); K=200
+        for _ in range(K): h.tick(None,sc["dt"],sc["cost_gains"],sc["ws_limits"])
+        h.stop(); t1=time.perf_counter()
+        ms,n,steps=h.kernel_stats()
+        print(name,"lpa",lpa,"tick %.1f us"%((t1-t0)/K*1e6),"kernel %.1f us"%(ms/n*1e3),"launches",n,"steps/launch",steps/n, "rollouts/s %.0f"%(sc["n_agents"]*K/(t1-t0)), flush=True)
+        h.close()

@@ -1,0 +1,74 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import __graft_entry__ as graft  # noqa: E402
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def pmaf():
+    """the package predictive-multi-agent-framework_amd/ as module pmaf_amd"""
+    return graft.load_package()
+
+
+@pytest.fixture(scope="session")
+def scenes(pmaf):
+    return pmaf.scenes
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle import orc
+    orc.build()
+    return orc
+
+
+def has_gpu():
+    return os.path.exists("/dev/kfd")
+
+
+@pytest.fixture(scope="session")
+def hip_lib(pmaf):
+    """built libpmaf_hip.so (built on demand; hipcc cross-compiles on CPU)"""
+    graft.build()
+    return pmaf.load_library()
+
+
+def std_mt19937_unit_vectors(seed, n):
+    """n normalised vectors from std::mt19937(seed) +
+    std::uniform_real_distribution<>(-1,1) as libstdc++ evaluates them (two
+    32-bit draws per double, low word first) -- the generator the SURVEY.md
+    8(c) probe used for makeRandomVector()."""
+    rs = np.random.RandomState(seed)
+    raw = rs._bit_generator.random_raw(2 * 3 * n).astype(np.float64)
+    lo, hi = raw[0::2], raw[1::2]
+    can = (lo + hi * 4294967296.0) / 18446744073709551616.0
+    v = (can * 2.0 + (-1.0)).reshape(n, 3)
+    nrm = np.sqrt((v[:, 0] * v[:, 0] + v[:, 1] * v[:, 1]) + v[:, 2] * v[:, 2])
+    return v / nrm[:, None]
+
+
+def drive(planner, scene, n_ticks, dynamic=False, advance=None, until_reached=False):
+    """Run the planCallback sequence n_ticks times. Returns per-tick best
+    indices and real-agent positions."""
+    obs = scene["obstacles"].copy()
+    best, pos = [], []
+    for t in range(n_ticks):
+        b = planner.tick(obs, scene["dt"], scene["cost_gains"], scene["ws_limits"])
+        if dynamic:
+            obs = advance(obs)
+        best.append(np.asarray(b).copy())
+        pos.append(np.asarray(planner.real_state()[0]).copy())
+        if until_reached and np.all(np.asarray(planner.dist_from_goal()) < 0.01):
+            break
+    return np.asarray(best), np.asarray(pos)

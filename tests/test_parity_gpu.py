@@ -1,0 +1,259 @@
+"""Parity of the HIP path (through the C-ABI, libpmaf_hip.so) against the CPU
+oracle on identical seeded inputs. Bar (BASELINE.json north_star): selected
+trajectory within 1e-5 m. The kernels keep the oracle's operation order in
+IEEE double, so everything except exp() (attractorForceScaling) is expected
+bit-identical; the tests assert TOL = 1e-9 m on trajectories and exact
+equality on indices / step counts / flags."""
+import numpy as np
+import pytest
+
+from conftest import drive
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-9  # metres; contract is 1e-5 (BASELINE.json), expected ~1e-15
+
+
+def make_pair(pmaf, oracle, scene, **kw):
+    hip = pmaf.PmafPlanner(scene, device=0, mgr_init_pos=scene["start"], **kw)
+    ora = oracle.OraclePlanner(scene, mgr_init_pos=scene["start"])
+    hip.set_initial_position(scene["start"])
+    ora.set_initial_position(scene["start"])
+    return hip, ora
+
+
+def assert_state_equal(hip, ora, tol=TOL):
+    ph, nh = hip.paths()
+    po, no = ora.paths()
+    np.testing.assert_array_equal(nh, no)
+    assert np.nanmax(np.abs(ph - po)) <= tol if np.isfinite(po).any() else True
+    assert np.array_equal(np.isnan(ph), np.isnan(po))
+    np.testing.assert_allclose(hip.min_obs_dist(), ora.min_obs_dist(), rtol=0, atol=tol)
+    np.testing.assert_allclose(hip.agent_vel(), ora.agent_vel(), rtol=0, atol=1e-7)
+    np.testing.assert_array_equal(hip.success(), ora.success())
+    np.testing.assert_allclose(hip.path_lengths(), ora.path_lengths(), rtol=0, atol=tol * 10)
+    np.testing.assert_array_equal(hip.known(), ora.known())
+    np.testing.assert_allclose(hip.rot_vecs(), ora.rot_vecs(), rtol=0, atol=1e-7, equal_nan=True)
+    rh, ro = hip.real_state(), ora.real_state()
+    for a, b in zip(rh, ro):
+        np.testing.assert_allclose(a, b, rtol=0, atol=tol * 100, equal_nan=True)
+    kh, rrh = hip.real_known()
+    ko, rro = ora.real_known()
+    np.testing.assert_array_equal(kh, ko)
+    np.testing.assert_allclose(rrh, rro, rtol=0, atol=1e-7, equal_nan=True)
+
+
+def run_both(pmaf, oracle, scenes, scene, n_ticks, dynamic=False, **kw):
+    hip, ora = make_pair(pmaf, oracle, scene, **kw)
+    bh, ph = drive(hip, scene, n_ticks, dynamic, scenes.advance_live_obstacles)
+    bo, po = drive(ora, scene, n_ticks, dynamic, scenes.advance_live_obstacles)
+    hip.stop()
+    np.testing.assert_array_equal(bh, bo)
+    assert np.abs(ph - po).max() <= TOL
+    np.testing.assert_allclose(hip.costs(), ora.costs(), rtol=1e-12, atol=1e-12)
+    assert_state_equal(hip, ora)
+    assert hip.best_type() == ora.best_type() and hip.best_id() == ora.best_id()
+    return hip, ora
+
+
+def test_c1_static1_16_agents(pmaf, oracle, scenes):
+    """BASELINE config C1: static1 scene, 16 agents, 100-step horizon."""
+    sc = scenes.config_scene("C1")
+    hip, ora = run_both(pmaf, oracle, scenes, sc, 25)
+    np.testing.assert_allclose(hip.real_path(), ora.real_path(), rtol=0, atol=TOL)
+    hip.close()
+
+
+def test_static1_as_shipped_10_agents_long_horizon(pmaf, oracle, scenes):
+    """the task file as shipped: 10 agents, max_prediction_steps 1500 ->
+    agents stop early at distGoal <= 0.1 (cf_agent.cpp:310)"""
+    sc = scenes.static1_scene(10, 1499)
+    hip, ora = run_both(pmaf, oracle, scenes, sc, 6)
+    assert (hip.n_points() < 1500).any()
+    hip.close()
+
+
+@pytest.mark.parametrize("lpa", [1, 2, 4, 8, 16, 32, 64])
+def test_every_lane_mapping(pmaf, oracle, scenes, lpa):
+    """all lanes-per-agent instantiations give the same answer; N=13 leaves a
+    ragged last wave, M=9 is not a multiple of any LPA > 1"""
+    sc = scenes.static1_scene(13, 120)
+    hip, _ = run_both(pmaf, oracle, scenes, sc, 8, lanes_per_agent=lpa)
+    assert hip.launch_config()["lanes_per_agent"] == lpa
+    hip.close()
+
+
+def test_c2_synthetic_64_agents_32_obstacles(pmaf, oracle, scenes):
+    sc = scenes.config_scene("C2")
+    hip, _ = run_both(pmaf, oracle, scenes, sc, 12)
+    hip.close()
+
+
+def test_c2_dynamic_obstacles(pmaf, oracle, scenes):
+    """moving obstacles exercise predictObstacles (cf_agent.cpp:270-276) and
+    the live-obstacle stream (dynamic_obstacle_node.cpp:355-357)"""
+    sc = scenes.config_scene("C2", scene_id=3, dynamic=True)
+    hip, _ = run_both(pmaf, oracle, scenes, sc, 12, dynamic=True)
+    hip.close()
+
+
+@pytest.mark.parametrize("lpa", [0, 8, 64])
+def test_c3_256_agents_128_obstacles(pmaf, oracle, scenes, lpa):
+    """BASELINE config C3 (LDS-tiled obstacle sweep: several tiles per lane)"""
+    sc = scenes.config_scene("C3")
+    hip, _ = run_both(pmaf, oracle, scenes, sc, 2, lanes_per_agent=lpa)
+    hip.close()
+
+
+def test_dyn1_closed_loop_until_reached(pmaf, oracle, scenes):
+    """dual_arms_dyn1 scene driven until getDistFromGoal() < 0.01 (taskCallback
+    'reached', panda_bimanual_control.cpp:565-569): ~745 ticks with moving
+    obstacles, early termination and hysteresis."""
+    sc = scenes.dyn1_scene(10, 1500)
+    hip, ora = make_pair(pmaf, oracle, sc)
+    bh, ph = drive(hip, sc, 2000, True, scenes.advance_live_obstacles, until_reached=True)
+    bo, po = drive(ora, sc, 2000, True, scenes.advance_live_obstacles, until_reached=True)
+    assert len(bh) == len(bo)
+    np.testing.assert_array_equal(bh, bo)
+    assert np.abs(ph - po).max() <= TOL
+    hip.close()
+
+
+def test_batched_populations_match_individual_oracles(pmaf, oracle, scenes):
+    """P independent populations in one handle (BASELINE C5 shape, reduced N)"""
+    scs = [scenes.synthetic_scene(40, 150, 32, 5, sid, dynamic=(sid % 2 == 1)) for sid in range(5)]
+    hip = pmaf.PmafPlanner(scs, device=0, mgr_init_pos=np.stack([s["start"] for s in scs]))
+    hip.set_initial_position(np.stack([s["start"] for s in scs]))
+    oras = []
+    for s in scs:
+        o = oracle.OraclePlanner(s, mgr_init_pos=s["start"])
+        o.set_initial_position(s["start"])
+        oras.append(o)
+    obs = np.stack([s["obstacles"] for s in scs])
+    for t in range(6):
+        bh = hip.tick(obs, scs[0]["dt"], scs[0]["cost_gains"], scs[0]["ws_limits"])
+        bo = [o.tick(obs[i], scs[0]["dt"], scs[0]["cost_gains"], scs[0]["ws_limits"]) for i, o in enumerate(oras)]
+        np.testing.assert_array_equal(bh, bo)
+        obs = np.stack([scenes.advance_live_obstacles(o) if i % 2 == 1 else o for i, o in enumerate(obs)])
+    ph, nh = hip.paths()
+    for i, o in enumerate(oras):
+        po, no = o.paths()
+        np.testing.assert_array_equal(nh[i], no)
+        assert np.abs(ph[i] - po).max() <= TOL
+        np.testing.assert_allclose(hip.real_state()[0][i], o.real_state()[0], rtol=0, atol=TOL)
+    hip.close()
+
+
+def test_step_api_equals_fused_tick(pmaf, oracle, scenes):
+    """stopPrediction / evaluateAgents / moveRealEEAgent / resetEEAgents /
+    startPrediction called one by one == pmaf_tick == oracle"""
+    sc = scenes.config_scene("C1")
+    hip, ora = make_pair(pmaf, oracle, sc)
+    for t in range(6):
+        hip.stop()
+        bh = hip.evaluate(sc["cost_gains"], sc["ws_limits"])
+        hip.move_real(sc["obstacles"], sc["dt"], 1, bh)
+        p, v, _ = hip.real_state()
+        hip.reset_agents(p, v, sc["obstacles"])
+        hip.start()
+        bo = ora.tick(sc["obstacles"], sc["dt"], sc["cost_gains"], sc["ws_limits"])
+        assert bh == bo
+    hip.stop()
+    assert_state_equal(hip, ora)
+    hip.close()
+
+
+def test_rollout_before_any_evaluate_and_rescoring(pmaf, oracle, scenes):
+    """start without a prior evaluate, then evaluate with two different
+    workspace boxes (forces the k_score re-scoring path)"""
+    sc = scenes.config_scene("C1")
+    hip, ora = make_pair(pmaf, oracle, sc)
+    hip.rollout()
+    ora.rollout()
+    assert_state_equal(hip, ora)
+    tight = np.array([0.2, -0.2, 0.05, -0.05, 0.8, 0.6])
+    for ws in (sc["ws_limits"], tight, sc["ws_limits"]):
+        # evaluate mutates the hysteresis state identically on both sides
+        assert hip.evaluate(sc["cost_gains"], ws) == ora.evaluate(sc["cost_gains"], ws)
+        np.testing.assert_allclose(hip.costs(), ora.costs(), rtol=1e-13, atol=0)
+    hip.close()
+
+
+def test_all_heuristic_types_population(pmaf, oracle, scenes):
+    """explicit agent_types: 6 agents of each heuristic in a cluttered scene"""
+    types = np.repeat([1, 2, 3, 4, 5, 6], 6).astype(np.int32)
+    sc = scenes.synthetic_scene(36, 200, 20, 7, 1, agent_types=types)
+    hip, _ = run_both(pmaf, oracle, scenes, sc, 5)
+    hip.close()
+
+
+def test_edge_only_sentinel_obstacle(pmaf, oracle, scenes):
+    """M = 0: obstacle list holds only the trailing repulsive obstacle; every
+    heuristic degenerates to the damped straight line"""
+    sc = scenes.synthetic_scene(8, 80, 0, 9, 0)
+    hip, ora = run_both(pmaf, oracle, scenes, sc, 3)
+    ph, _ = hip.paths()
+    assert np.abs(ph - ph[0]).max() == 0.0
+    hip.close()
+
+
+def test_edge_single_field_obstacle(pmaf, oracle, scenes):
+    """one field obstacle: Obstacle/GoalObstacle 'closest other' is itself
+    (cf_agent.cpp:434-446) -> zero vectors / NaNs must match the oracle"""
+    sc = scenes.synthetic_scene(8, 120, 1, 9, 1)
+    sc["obstacles"][0, :3] = [0.0, 0.02, 0.72]
+    hip, _ = run_both(pmaf, oracle, scenes, sc, 3)
+    hip.close()
+
+
+def test_edge_had_degenerate_obstacle_on_goal_line(pmaf, oracle, scenes):
+    """Had heuristic divides by |d x g| unguarded (cf_agent.cpp:609): obstacle
+    centre exactly on the agent-goal line gives NaN; NaN pattern must match"""
+    sc = scenes.synthetic_scene(6, 60, 1, 9, 2)
+    sc["obstacles"][0] = [0.0, 0.0, 0.7, 0, 0, 0, 0.05]
+    hip, ora = make_pair(pmaf, oracle, sc)
+    for _ in range(2):
+        hip.tick(sc["obstacles"], sc["dt"], sc["cost_gains"], sc["ws_limits"])
+        ora.tick(sc["obstacles"], sc["dt"], sc["cost_gains"], sc["ws_limits"])
+    ph, nh = hip.paths()
+    po, no = ora.paths()
+    np.testing.assert_array_equal(nh, no)
+    assert np.array_equal(np.isnan(ph), np.isnan(po))
+    m = ~np.isnan(po)
+    assert np.abs(ph[m] - po[m]).max() <= TOL
+    hip.close()
+
+
+def test_edge_start_inside_goal_region_and_capacity_one(pmaf, oracle, scenes):
+    """guard false at once (distGoal <= 0.1) -> 1-point paths; capacity 1"""
+    sc = scenes.synthetic_scene(6, 50, 4, 9, 3)
+    sc["start"] = sc["goal"] + np.array([0.05, 0.0, 0.0])
+    hip, _ = run_both(pmaf, oracle, scenes, sc, 3)
+    assert (hip.n_points() == 1).all()
+    hip.close()
+    sc = scenes.synthetic_scene(6, 0, 4, 9, 4)  # max_prediction_steps = 1
+    hip, _ = run_both(pmaf, oracle, scenes, sc, 3)
+    hip.close()
+
+
+def test_link_force_matches_oracle(pmaf, oracle, scenes):
+    sc = scenes.config_scene("C1")
+    sc["obstacles"][-1, :3] = [0.1, 0.0, 0.7]  # bring the repulsive obstacle into range
+    hip, ora = make_pair(pmaf, oracle, sc)
+    rng = np.random.default_rng(5)
+    lp = rng.uniform(-0.3, 0.5, (37, 3)) + np.array([0.0, 0.0, 0.6])
+    k = rng.uniform(0.01, 0.05, 37)
+    np.testing.assert_allclose(hip.link_force(lp, k, sc["obstacles"]), ora.link_force(lp, k, sc["obstacles"]),
+                               rtol=0, atol=0)
+    hip.close()
+
+
+def test_error_reporting(pmaf, scenes):
+    sc = scenes.config_scene("C1")
+    hip = pmaf.PmafPlanner(sc, device=0)
+    with pytest.raises(pmaf.PmafError) as e:
+        hip.move_real(sc["obstacles"], 0.01, 1, 0)  # no best agent yet
+    assert e.value.code == -3
+    with pytest.raises(pmaf.PmafError):
+        pmaf.PmafPlanner(sc, device=0, lanes_per_agent=3)
+    hip.close()

@@ -202,6 +202,11 @@ int pmaf_reset_kernel_stats(pmaf_planner *h);
 int pmaf_get_launch_config(pmaf_planner *h, int32_t *lanes_per_agent,
                            int32_t *n_blocks, int32_t *lds_bytes);
 
+/* Self-test of the device arithmetic the parity argument rests on: evaluates
+ * op over n elements ON THE GPU (0: a/b, 1: sqrt(a), 2: the kernels' portable exp(a), 3: a*b,
+ * 4: a+b). Tests compare the result bitwise with the host's IEEE results. */
+int pmaf_debug_math(int32_t op, int32_t n, const double *a, const double *b, double *out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -61,8 +61,25 @@ def lib():
         L.orc_best_id.argtypes = [C.c_void_p]
         L.orc_agent_steps.restype = C.c_int64
         L.orc_agent_steps.argtypes = [C.c_void_p]
+        L.orc_set_exp_mode.argtypes = [C.c_int]
+        L.pmaf_portable_exp.restype = C.c_double
+        L.pmaf_portable_exp.argtypes = [C.c_double]
         _LIB = L
     return _LIB
+
+
+def set_exp_mode(mode):
+    """0 = libm exp (reference-faithful), 1 = portable exp shared with the HIP kernels"""
+    lib().orc_set_exp_mode(int(mode))
+
+
+def get_exp_mode():
+    return lib().orc_get_exp_mode()
+
+
+def portable_exp(x):
+    L = lib()
+    return np.array([L.pmaf_portable_exp(float(v)) for v in np.ravel(x)]).reshape(np.shape(x))
 
 
 def _d(a):

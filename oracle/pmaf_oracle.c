@@ -49,6 +49,57 @@ static inline v3 vnormalized(v3 a) {
 static inline v3 vcross(v3 a, v3 b) {
   return V(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
 }
+/*
+ * exp(): the reference calls std::exp (B/src/cf_agent.cpp:220), i.e. the
+ * platform libm, whose last bit differs between libms (glibc vs numpy vs ROCm
+ * OCML disagree on 4-6 % of arguments). Mode 0 (default) keeps libm exp: the
+ * reference-faithful restatement. Mode 1 uses pmaf_portable_exp below, the
+ * table-free argument-reduction + rational-polynomial algorithm of Sun's
+ * fdlibm e_exp.c (error < 1 ulp), written with plain IEEE + - * / only, so it
+ * gives the same bits on every IEEE platform; the HIP kernels use the same
+ * function (csrc/pmaf_device.hpp), which makes kernel-vs-oracle comparisons
+ * bit-exact in mode 1.
+ */
+static int g_exp_mode = 0;
+void orc_set_exp_mode(int mode) { g_exp_mode = mode; }
+int orc_get_exp_mode(void) { return g_exp_mode; }
+
+double pmaf_portable_exp(double x) {
+  const double ln2HI = 6.93147180369123816490e-01, ln2LO = 1.90821492927058770002e-10,
+               invln2 = 1.44269504088896338700e+00,
+               P1 = 1.66666666666666019037e-01, P2 = -2.77777777770155933842e-03,
+               P3 = 6.61375632143793436117e-05, P4 = -1.65339022054652515390e-06,
+               P5 = 4.13813679705723846039e-08;
+  double hi = 0.0, lo = 0.0, t, c, y;
+  int k = 0;
+  double ax = fabs(x);
+  if (ax > 708.0) return (x > 0) ? HUGE_VAL : 0.0;       /* outside the path's range */
+  if (ax > 0.34657359027997264) {                        /* |x| > 0.5 ln2 */
+    if (ax < 1.0397207708399179) {                       /* |x| < 1.5 ln2 */
+      if (x > 0) { hi = x - ln2HI; lo = ln2LO; k = 1; }
+      else { hi = x + ln2HI; lo = -ln2LO; k = -1; }
+    } else {
+      k = (int)(invln2 * x + ((x < 0) ? -0.5 : 0.5));
+      t = (double)k;
+      hi = x - t * ln2HI;
+      lo = t * ln2LO;
+    }
+    x = hi - lo;
+  } else if (ax < 3.725290298461914e-09) {               /* |x| < 2^-28 */
+    return 1.0 + x;
+  }
+  t = x * x;
+  c = x - t * (P1 + t * (P2 + t * (P3 + t * (P4 + t * P5))));
+  if (k == 0) return 1.0 - ((x * c) / (c - 2.0) - x);
+  y = 1.0 - ((lo - (x * c) / (2.0 - c)) - hi);
+  {
+    union { uint64_t u; double d; } two_k;
+    two_k.u = (uint64_t)(1023 + k) << 52;                /* 2^k, exact scaling */
+    return y * two_k.d;
+  }
+}
+static inline double orc_exp(double x) { return g_exp_mode ? pmaf_portable_exp(x) : exp(x); }
+
 static inline double dmax(double a, double b) { return (a < b) ? b : a; }
 static inline double dmin(double a, double b) { return (b < a) ? b : a; }
 
@@ -281,7 +332,7 @@ static double attractor_force_scaling(const agent_t *a, const obs_t *obstacles, 
       vnorm(goal_vec) > 0.15) {
     return 0.0;
   }
-  double w1 = 1 - exp(-sqrt(closest) / a->shell);
+  double w1 = 1 - orc_exp(-sqrt(closest) / a->shell);
   v3 ro = vsub(obstacles[id_closest].pos, p);
   double w2 = 1 - (vdot(goal_vec, ro) / (vnorm(goal_vec) * vnorm(ro)));
   w2 = w2 * w2;

@@ -41,6 +41,13 @@ enum {
 
 typedef struct orc_planner orc_planner;
 
+/* exp() used by attractorForceScaling (B/src/cf_agent.cpp:220): 0 = libm exp
+ * (reference-faithful, default), 1 = pmaf_portable_exp (same function as the
+ * HIP kernels; bit-reproducible on any IEEE platform). Process-global. */
+void orc_set_exp_mode(int mode);
+int orc_get_exp_mode(void);
+double pmaf_portable_exp(double x);
+
 /*
  * CfManager::init on a default-constructed manager
  * (B/src/cf_manager.cpp:41-124). scal = {dt (= prediction_freq_multiple *

@@ -13,7 +13,7 @@
 // Floating point: IEEE double, no FMA contraction (-ffp-contract=off), true
 // divisions and square roots, and the reference's operation order (see
 // oracle/pmaf_oracle.c header), so results are bit-identical to the CPU
-// restatement except through exp() (attractorForceScaling :220).
+// restatement; exp() (attractorForceScaling :220) is the portable_exp below.
 //
 // The sequential `force_ += curr_force` of circForce (:106) is reproduced by
 // adding the non-zero per-obstacle terms in ascending obstacle index
@@ -54,6 +54,42 @@ __device__ __forceinline__ V3 cross(V3 a, V3 b) {
 // std::max(a,b) / std::min(a,b) semantics incl. NaN behaviour
 __device__ __forceinline__ double smax(double a, double b) { return (a < b) ? b : a; }
 __device__ __forceinline__ double smin(double a, double b) { return (b < a) ? b : a; }
+
+// exp() of attractorForceScaling (B/src/cf_agent.cpp:220). The reference
+// calls the platform libm, whose last bit is not portable; this is the
+// table-free fdlibm e_exp.c algorithm (< 1 ulp) in plain IEEE + - * /, the
+// same function as oracle/pmaf_oracle.c:pmaf_portable_exp, so it produces
+// identical bits on the host and on gfx950.
+__device__ __forceinline__ double portable_exp(double x) {
+  const double ln2HI = 6.93147180369123816490e-01, ln2LO = 1.90821492927058770002e-10,
+               invln2 = 1.44269504088896338700e+00,
+               P1 = 1.66666666666666019037e-01, P2 = -2.77777777770155933842e-03,
+               P3 = 6.61375632143793436117e-05, P4 = -1.65339022054652515390e-06,
+               P5 = 4.13813679705723846039e-08;
+  double hi = 0.0, lo = 0.0, t, c, y;
+  int k = 0;
+  double ax = fabs(x);
+  if (ax > 708.0) return (x > 0) ? __builtin_huge_val() : 0.0;
+  if (ax > 0.34657359027997264) {
+    if (ax < 1.0397207708399179) {
+      if (x > 0) { hi = x - ln2HI; lo = ln2LO; k = 1; }
+      else { hi = x + ln2HI; lo = -ln2LO; k = -1; }
+    } else {
+      k = (int)(invln2 * x + ((x < 0) ? -0.5 : 0.5));
+      t = (double)k;
+      hi = x - t * ln2HI;
+      lo = t * ln2LO;
+    }
+    x = hi - lo;
+  } else if (ax < 3.725290298461914e-09) {
+    return 1.0 + x;
+  }
+  t = x * x;
+  c = x - t * (P1 + t * (P2 + t * (P3 + t * (P4 + t * P5))));
+  if (k == 0) return 1.0 - ((x * c) / (c - 2.0) - x);
+  y = 1.0 - ((lo - (x * c) / (2.0 - c)) - hi);
+  return y * __longlong_as_double((long long)(1023 + k) << 52);
+}
 
 enum : int { T_REAL = 0, T_GOAL = 1, T_OBST = 2, T_GOALOBST = 3, T_VEL = 4, T_RANDOM = 5, T_HAD = 6 };
 
@@ -289,7 +325,7 @@ __device__ __forceinline__ void circ_and_scale(bool act, int sub, int grp, int t
     } else if (dot(g, v) <= 0.0 && norm(v) < C.vel_max - 0.1 * C.vel_max && norm(g) > 0.15) {
       scale = 0.0;
     } else {
-      double w1 = 1 - exp(-__builtin_sqrt(best_d) / C.shell);
+      double w1 = 1 - portable_exp(-__builtin_sqrt(best_d) / C.shell);
       V3 ro = T.pos(best_i) - p;
       double w2 = 1 - (dot(g, ro) / (norm(g) * norm(ro)));
       w2 = w2 * w2;

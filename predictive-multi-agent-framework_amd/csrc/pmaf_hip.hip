@@ -388,6 +388,22 @@ __global__ void k_link_force(int n, const double *link_pos, const double *k_r, c
   out[3 * i] = F.x; out[3 * i + 1] = F.y; out[3 * i + 2] = F.z;
 }
 
+// elementary operations the parity argument rests on, exposed for the GPU
+// self-test: 0 a/b, 1 sqrt(a), 2 exp(a), 3 a*b, 4 a+b
+__global__ void k_debug_math(int op, int n, const double *a, const double *b, double *out) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double r = 0.0;
+  switch (op) {
+    case 0: r = a[i] / b[i]; break;
+    case 1: r = __builtin_sqrt(a[i]); break;
+    case 2: r = portable_exp(a[i]); break;
+    case 3: r = a[i] * b[i]; break;
+    case 4: r = a[i] + b[i]; break;
+  }
+  out[i] = r;
+}
+
 // winner record {cost, idx, n_points, type, path[cap][3]} per population
 __global__ void k_winner(DevView D, double *dst) {
   int pop = blockIdx.x;
@@ -983,8 +999,15 @@ int pmaf_link_force(pmaf_planner *h, int32_t pop, int32_t n, const double *link_
 int pmaf_get_paths(pmaf_planner *h, double *paths, int32_t *n_points) {
   return guarded([&] {
     GETTER_PROLOGUE("pmaf_get_paths")
-    if (paths) h->download(paths, D.paths, PN * (size_t)D.cap * 3);
-    if (n_points) h->download(n_points, D.n_points, PN);
+    std::vector<int32_t> np(PN);
+    h->download(np.data(), D.n_points, PN);
+    if (paths) {
+      h->download(paths, D.paths, PN * (size_t)D.cap * 3);
+      // entries past an agent's path end are stale device memory: report zeros
+      for (size_t pa = 0; pa < PN; pa++)
+        std::memset(paths + (pa * D.cap + np[pa]) * 3, 0, sizeof(double) * 3 * (size_t)(D.cap - np[pa]));
+    }
+    if (n_points) std::memcpy(n_points, np.data(), sizeof(int32_t) * PN);
   });
 }
 int pmaf_get_costs(pmaf_planner *h, double *costs) {
@@ -1171,6 +1194,22 @@ int pmaf_reset_kernel_stats(pmaf_planner *h) {
     sync(h);
   });
 }
+int pmaf_debug_math(int32_t op, int32_t n, const double *a, const double *b, double *out) {
+  return guarded([&] {
+    REQUIRE(a && b && out && n > 0 && op >= 0 && op <= 4, "pmaf_debug_math: bad argument");
+    double *da = nullptr, *db = nullptr, *dout = nullptr;
+    HIP_CHECK(hipMalloc((void **)&da, sizeof(double) * n));
+    HIP_CHECK(hipMalloc((void **)&db, sizeof(double) * n));
+    HIP_CHECK(hipMalloc((void **)&dout, sizeof(double) * n));
+    HIP_CHECK(hipMemcpy(da, a, sizeof(double) * n, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(db, b, sizeof(double) * n, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_debug_math, dim3((n + 255) / 256), dim3(256), 0, 0, op, n, da, db, dout);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipMemcpy(out, dout, sizeof(double) * n, hipMemcpyDeviceToHost));
+    (void)hipFree(da); (void)hipFree(db); (void)hipFree(dout);
+  });
+}
+
 int pmaf_get_launch_config(pmaf_planner *h, int32_t *lanes_per_agent, int32_t *n_blocks, int32_t *lds_bytes) {
   return guarded([&] {
     REQUIRE(h, "pmaf_get_launch_config: NULL handle");

@@ -74,7 +74,20 @@ SYMBOLS = {
     "pmaf_get_kernel_stats": (C.c_int, [_V, _dp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "pmaf_reset_kernel_stats": (C.c_int, [_V]),
     "pmaf_get_launch_config": (C.c_int, [_V, _ip, _ip, _ip]),
+    "pmaf_debug_math": (C.c_int, [C.c_int32, C.c_int32, _dp, _dp, _dp]),
 }
+
+
+def debug_math(op, a, b=None):
+    """evaluate an elementary op on the GPU (see pmaf_debug_math)"""
+    L = load_library()
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    b = np.ascontiguousarray(a if b is None else b, dtype=np.float64)
+    out = np.zeros_like(a)
+    rc = L.pmaf_debug_math(op, a.size, a.ctypes.data_as(_dp), b.ctypes.data_as(_dp), out.ctypes.data_as(_dp))
+    if rc != 0:
+        raise PmafError(rc, L.pmaf_last_error().decode())
+    return out
 
 _LIB = None
 

@@ -2,7 +2,9 @@ import sys, time, numpy as np
 sys.path.insert(0,'/root/repo')
 import __graft_entry__ as g
 pm=g.load_package()
-for name,lpas in (("C2",[64,32,16,8]),("C3",[64,16,4]),("C1",[64])):
+cfgs = sys.argv[1:] or ["C2:64,32", "C3:64,16", "C1:64"]
+for c in cfgs:
+    name,l=c.split(":"); lpas=[int(x) for x in l.split(",")]
     sc=pm.scenes.config_scene(name)
     for lpa in lpas:
         h=pm.PmafPlanner(sc,device=0,mgr_init_pos=sc["start"],lanes_per_agent=lpa); h.set_initial_position(sc["start"])
@@ -13,5 +15,5 @@ for name,lpas in (("C2",[64,32,16,8]),("C3",[64,16,4]),("C1",[64])):
         for _ in range(K): h.tick(None,sc["dt"],sc["cost_gains"],sc["ws_limits"])
         h.stop(); t1=time.perf_counter()
         ms,n,steps=h.kernel_stats()
-        print(name,"lpa",lpa,"tick %.1f us"%((t1-t0)/K*1e6),"kernel %.1f us"%(ms/n*1e3),"launches",n,"steps/launch",steps/n, "rollouts/s %.0f"%(sc["n_agents"]*K/(t1-t0)), flush=True)
+        print(name,"lpa",lpa,"tick %.1f us"%((t1-t0)/K*1e6),"kernel %.1f us"%(ms/n*1e3),"us/step %.3f"%(ms/n*1e3/(sc["max_prediction_steps"]-1)),"rollouts/s %.0f"%(sc["n_agents"]*K/(t1-t0)), flush=True)
         h.close()

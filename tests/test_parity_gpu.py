@@ -1,9 +1,19 @@
 """Parity of the HIP path (through the C-ABI, libpmaf_hip.so) against the CPU
 oracle on identical seeded inputs. Bar (BASELINE.json north_star): selected
-trajectory within 1e-5 m. The kernels keep the oracle's operation order in
-IEEE double, so everything except exp() (attractorForceScaling) is expected
-bit-identical; the tests assert TOL = 1e-9 m on trajectories and exact
-equality on indices / step counts / flags."""
+trajectory within 1e-5 m of the reference CPU planner.
+
+Two oracle modes (oracle/pmaf_oracle.c):
+  * portable exp (mode 1): the oracle evaluates exp() with the same
+    table-free algorithm as the kernels. Every other operation is a correctly
+    rounded IEEE + - * / sqrt in the same order on both sides, so the HIP
+    results must be BIT-IDENTICAL: TOL = 0 on every trajectory point, cost,
+    rotation vector and flag, at every horizon. All tests below run in this
+    mode unless they say otherwise.
+  * libm exp (mode 0, the reference-faithful restatement): glibc's exp differs
+    from any other exp in the last bit on ~5-10 % of arguments, and the
+    rollout amplifies a 1-ulp perturbation (mildly over the BASELINE horizons,
+    chaotically over 1000+ steps). test_libm_exp_oracle_* assert the north-star
+    tolerance 1e-5 m on the BASELINE configs in that mode."""
 import numpy as np
 import pytest
 
@@ -11,7 +21,15 @@ from conftest import drive
 
 pytestmark = pytest.mark.gpu
 
-TOL = 1e-9  # metres; contract is 1e-5 (BASELINE.json), expected ~1e-15
+TOL = 0.0        # metres, portable-exp oracle: bit-identical
+LIBM_TOL = 1e-5  # metres, libm-exp oracle: the north-star tolerance
+
+
+@pytest.fixture(autouse=True)
+def _portable_exp_oracle(oracle):
+    oracle.set_exp_mode(1)
+    yield
+    oracle.set_exp_mode(0)
 
 
 def make_pair(pmaf, oracle, scene, **kw):
@@ -26,21 +44,22 @@ def assert_state_equal(hip, ora, tol=TOL):
     ph, nh = hip.paths()
     po, no = ora.paths()
     np.testing.assert_array_equal(nh, no)
-    assert np.nanmax(np.abs(ph - po)) <= tol if np.isfinite(po).any() else True
     assert np.array_equal(np.isnan(ph), np.isnan(po))
+    m = ~np.isnan(po)
+    assert np.abs(ph[m] - po[m]).max() <= tol
     np.testing.assert_allclose(hip.min_obs_dist(), ora.min_obs_dist(), rtol=0, atol=tol)
-    np.testing.assert_allclose(hip.agent_vel(), ora.agent_vel(), rtol=0, atol=1e-7)
+    np.testing.assert_allclose(hip.agent_vel(), ora.agent_vel(), rtol=0, atol=tol)
     np.testing.assert_array_equal(hip.success(), ora.success())
-    np.testing.assert_allclose(hip.path_lengths(), ora.path_lengths(), rtol=0, atol=tol * 10)
+    np.testing.assert_allclose(hip.path_lengths(), ora.path_lengths(), rtol=0, atol=tol)
     np.testing.assert_array_equal(hip.known(), ora.known())
-    np.testing.assert_allclose(hip.rot_vecs(), ora.rot_vecs(), rtol=0, atol=1e-7, equal_nan=True)
+    np.testing.assert_allclose(hip.rot_vecs(), ora.rot_vecs(), rtol=0, atol=tol, equal_nan=True)
     rh, ro = hip.real_state(), ora.real_state()
     for a, b in zip(rh, ro):
-        np.testing.assert_allclose(a, b, rtol=0, atol=tol * 100, equal_nan=True)
+        np.testing.assert_allclose(a, b, rtol=0, atol=tol, equal_nan=True)
     kh, rrh = hip.real_known()
     ko, rro = ora.real_known()
     np.testing.assert_array_equal(kh, ko)
-    np.testing.assert_allclose(rrh, rro, rtol=0, atol=1e-7, equal_nan=True)
+    np.testing.assert_allclose(rrh, rro, rtol=0, atol=tol, equal_nan=True)
 
 
 def run_both(pmaf, oracle, scenes, scene, n_ticks, dynamic=False, **kw):
@@ -50,7 +69,7 @@ def run_both(pmaf, oracle, scenes, scene, n_ticks, dynamic=False, **kw):
     hip.stop()
     np.testing.assert_array_equal(bh, bo)
     assert np.abs(ph - po).max() <= TOL
-    np.testing.assert_allclose(hip.costs(), ora.costs(), rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(hip.costs(), ora.costs(), rtol=0, atol=0)
     assert_state_equal(hip, ora)
     assert hip.best_type() == ora.best_type() and hip.best_id() == ora.best_id()
     return hip, ora
@@ -175,7 +194,7 @@ def test_rollout_before_any_evaluate_and_rescoring(pmaf, oracle, scenes):
     for ws in (sc["ws_limits"], tight, sc["ws_limits"]):
         # evaluate mutates the hysteresis state identically on both sides
         assert hip.evaluate(sc["cost_gains"], ws) == ora.evaluate(sc["cost_gains"], ws)
-        np.testing.assert_allclose(hip.costs(), ora.costs(), rtol=1e-13, atol=0)
+        np.testing.assert_allclose(hip.costs(), ora.costs(), rtol=0, atol=0)
     hip.close()
 
 
@@ -257,3 +276,44 @@ def test_error_reporting(pmaf, scenes):
     with pytest.raises(pmaf.PmafError):
         pmaf.PmafPlanner(sc, device=0, lanes_per_agent=3)
     hip.close()
+
+
+# ---------------------------------------------------------------------------
+# reference-faithful oracle (libm exp): north-star tolerance on BASELINE configs
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("cfg,ticks", [("C1", 30), ("C2", 30), ("C3", 2)])
+def test_libm_exp_oracle_within_north_star_tolerance(pmaf, oracle, scenes, cfg, ticks):
+    oracle.set_exp_mode(0)
+    sc = scenes.config_scene(cfg)
+    hip, ora = make_pair(pmaf, oracle, sc)
+    bh, ph = drive(hip, sc, ticks)
+    bo, po = drive(ora, sc, ticks)
+    hip.stop()
+    np.testing.assert_array_equal(bh, bo)
+    # the selected trajectory = the real agent's path ...
+    assert np.abs(ph - po).max() <= LIBM_TOL
+    # ... and the winning agent's predicted path; report all agents too
+    pth, nh = hip.paths()
+    pto, no = ora.paths()
+    np.testing.assert_array_equal(nh, no)
+    best = int(bh[-1])
+    assert np.abs(pth[best] - pto[best]).max() <= LIBM_TOL
+    print("%s: max |path - libm oracle| best agent %.3g m, all agents %.3g m" %
+          (cfg, np.abs(pth[best] - pto[best]).max(), np.abs(pth - pto).max()))
+    assert np.abs(pth - pto).max() <= LIBM_TOL
+    hip.close()
+
+
+def test_device_arithmetic_is_ieee_exact(pmaf, oracle):
+    """the parity argument: device / sqrt * + are correctly rounded (== host),
+    device exp == the oracle's portable exp bit for bit"""
+    rng = np.random.default_rng(1)
+    n = 1_000_000
+    a = rng.uniform(1e-6, 4.0, n)
+    b = rng.uniform(1e-6, 4.0, n)
+    assert (pmaf.debug_math(0, a, b) == a / b).all()
+    assert (pmaf.debug_math(1, a) == np.sqrt(a)).all()
+    assert (pmaf.debug_math(3, a, b) == a * b).all()
+    assert (pmaf.debug_math(4, a, b) == a + b).all()
+    x = -rng.uniform(0.0, 3.0, 200_000)
+    assert (pmaf.debug_math(2, x) == oracle.portable_exp(x)).all()

@@ -1,0 +1,223 @@
+#!/usr/bin/env python3
+"""bench.py -- planner-tick throughput of the MI355X-native circular-field
+planner (BASELINE.json metric: agent-rollouts/s + planner tick latency).
+
+One "step" = one planner tick (pmaf_tick: stop -> evaluateAgents ->
+moveRealEEAgent -> resetEEAgents -> startPrediction) of one population in the
+BASELINE configuration the metric is quoted on:
+    C2 = 64 agents, 200-step horizon, 32 synthetic sphere obstacles (+ the
+    trailing repulsive obstacle), SURVEY.md 8(d) scene generator.
+Obstacles / agent state are resident in HBM before the timed region; ticks are
+issued back to back, each returning best index + next set-point to the host
+(the real per-tick API, not a batched open-loop shortcut).
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): every rank plans
+its own independent population (scene id = rank) -- the path shards by
+population with no data-path collective (weak scaling). torch.distributed is
+used only for the barrier and the max-over-ranks timing.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as graft  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+FP64_VALU_PEAK_TF = 78.6   # 256 CU x 2.4 GHz x 128 flop/clk (vector FP64)
+
+
+def algorithmic_bytes_per_tick(N, H, n_obs):
+    """path write N*(H+1)*24 B + per-agent results N*32 B;
+    reads (M+1)*56 B obstacles + N*48 B agent state."""
+    return N * (H + 1) * 24 + N * 32 + n_obs * 56 + N * 48
+
+
+def algorithmic_flops_per_agent_step(M):
+    """SURVEY.md 8(d) estimate: 110 + 47 M (+12 M scaling sweep) + 65 S, with
+    S (in-shell obstacles per step) taken as M/4."""
+    return 110 + 47 * M + 12 * M + 65 * (M / 4.0)
+
+
+def cpu_baseline(pkg, scene, budget_s, threads):
+    """Times the CPU oracle (oracle/, a scalar C restatement of the
+    reference's algorithm = kind 'port') on this host: the same tick sequence
+    on the same scene, for about budget_s seconds."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import orc
+    orc.set_exp_mode(0)
+    N = scene["n_agents"]
+
+    def run(nthreads, budget):
+        o = orc.OraclePlanner(scene, mgr_init_pos=scene["start"])
+        o.set_initial_position(scene["start"])
+        cuts = np.linspace(0, N, nthreads + 1).astype(int)
+        pool = ThreadPoolExecutor(nthreads) if nthreads > 1 else None
+        obs, dt, cg, ws = scene["obstacles"], scene["dt"], scene["cost_gains"], scene["ws_limits"]
+        ticks = 0
+        t0 = time.perf_counter()
+        while True:
+            best = o.evaluate(cg, ws)
+            o.move_real(obs, dt, 1, best)
+            p, v, _ = o.real_state()
+            o.reset_agents(p, v, obs)
+            if pool:
+                list(pool.map(lambda i: o.rollout_range(int(cuts[i]), int(cuts[i + 1])), range(nthreads)))
+            else:
+                o.rollout()
+            ticks += 1
+            el = time.perf_counter() - t0
+            if el >= budget:
+                break
+        if pool:
+            pool.shutdown()
+        steps = o.agent_steps()
+        o.close()
+        return ticks, el, steps
+
+    t1, e1, s1 = run(1, budget_s * 0.4)
+    tn, en, sn = run(threads, budget_s * 0.6)
+    return {
+        "value": N * tn / en, "unit": "rollouts/s", "cores": threads, "kind": "port",
+        "sample": "%d ticks (%.1f s) of the bench workload through oracle/libpmaf_oracle.so "
+                  "(gcc -O2, scalar C restatement, agents split over %d threads)" % (tn, en, threads),
+        "value_1core": N * t1 / e1, "agent_steps_per_s": sn / en, "agent_steps_per_s_1core": s1 / e1,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--config", default="C2", help="C1|C2|C3|C5 (BASELINE.json configs); C2 is the metric's config")
+    ap.add_argument("--populations", type=int, default=1, help="independent populations per GPU in one handle")
+    ap.add_argument("--lanes-per-agent", type=int, default=0)
+    ap.add_argument("--dynamic", action="store_true", help="moving obstacles, re-uploaded every tick")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline time budget (0 = skip)")
+    ap.add_argument("--episode", type=int, default=256,
+                    help="ticks per episode: the real agent is put back at the start every EPISODE ticks so every "
+                         "timed rollout runs its full horizon (stationary workload; 0 = never)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    pkg = graft.load_package()
+    pkg.load_library()
+    scenes = [pkg.scenes.config_scene(args.config, scene_id=rank * args.populations + i, dynamic=args.dynamic)
+              for i in range(args.populations)]
+    sc = scenes[0]
+    N, H, n_obs = sc["n_agents"], sc["max_prediction_steps"] - 1, sc["obstacles"].shape[0]
+    P = args.populations
+    starts = np.stack([s["start"] for s in scenes])
+    planner = pkg.PmafPlanner(scenes, device=local_rank, lanes_per_agent=args.lanes_per_agent, mgr_init_pos=starts)
+    planner.set_initial_position(starts)
+    obs = np.stack([s["obstacles"] for s in scenes])
+    dt, cg, ws = sc["dt"], sc["cost_gains"], sc["ws_limits"]
+
+    tick_no = [0]
+
+    def one_tick(o):
+        # stationary workload: restart the episode before the real agent gets
+        # so close to the goal that rollouts stop early (cf_agent.cpp:310)
+        if args.episode and tick_no[0] % args.episode == 0:
+            planner.set_initial_position(starts)
+        tick_no[0] += 1
+        return planner.tick(o if args.dynamic else None, dt, cg, ws)
+
+    def sync_all():
+        planner.stop()
+        if dist is not None:
+            import torch
+            torch.cuda.synchronize()
+            dist.barrier()
+
+    planner.tick(obs, dt, cg, ws)  # obstacles resident in HBM from here on
+    for _ in range(args.warmup):
+        one_tick(obs)
+    planner.set_profiling(True)
+    sync_all()
+    planner.reset_kernel_stats()
+    lat = np.zeros(args.steps)
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        ta = time.perf_counter()
+        one_tick(obs)
+        lat[k] = time.perf_counter() - ta
+        if args.dynamic:
+            obs = np.stack([pkg.scenes.advance_live_obstacles(o) for o in obs])
+    planner.stop()
+    if dist is not None:
+        import torch
+        torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.barrier()
+        elapsed = float(t.item())
+    kernel_ms, launches, agent_steps = planner.kernel_stats()
+    cfg = planner.launch_config()
+    planner.close()
+
+    if rank == 0:
+        rollouts = N * P * world * args.steps
+        value = rollouts / elapsed
+        avg_kernel_s = kernel_ms / max(launches, 1) * 1e-3
+        bytes_per_launch = P * algorithmic_bytes_per_tick(N, H, n_obs)
+        achieved = bytes_per_launch / avg_kernel_s / 1e9
+        steps_per_launch = agent_steps / max(launches, 1)
+        flops = algorithmic_flops_per_agent_step(n_obs - 1) * steps_per_launch
+        out = {
+            "metric": "agent_rollouts_per_s", "value": value, "unit": "rollouts/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "%s: %d agents x %d-step horizon, %d sphere obstacles + repulsive sentinel, "
+                                   "%d population(s) per GPU, %s obstacles, one pmaf_tick per step"
+                                   % (args.config, N, H, n_obs - 1, P, "moving" if args.dynamic else "static"),
+                       "agents": N, "horizon": H, "obstacles": n_obs - 1, "populations_per_gpu": P,
+                       "parallelism": "population-per-gpu x%d" % world,
+                       "lanes_per_agent": cfg["lanes_per_agent"], "rollout_blocks": cfg["n_blocks"]},
+            "agent_steps_per_s": agent_steps / max(launches, 1) * world * args.steps / elapsed,
+            "h_eff": steps_per_launch / (N * P),
+            "tick_latency_us": {"median": float(np.median(lat) * 1e6), "p99": float(np.percentile(lat, 99) * 1e6)},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "k_rollout<%d>" % cfg["lanes_per_agent"],
+                         "avg_kernel_us": avg_kernel_s * 1e6,
+                         "algorithmic_bytes_per_launch": bytes_per_launch,
+                         "note": "FP64-VALU/latency-bound ODE integration; HBM fraction is structurally tiny "
+                                 "(SURVEY.md 8d): see fp64_valu"},
+            "fp64_valu": {"achieved_tflops": flops / avg_kernel_s / 1e12, "peak_tflops": FP64_VALU_PEAK_TF,
+                          "frac": flops / avg_kernel_s / 1e12 / FP64_VALU_PEAK_TF,
+                          "flops_per_agent_step_est": algorithmic_flops_per_agent_step(n_obs - 1)},
+        }
+        if args.cpu_seconds > 0:
+            threads = max(1, min(N, os.cpu_count() or 1))
+            out["cpu_baseline"] = cpu_baseline(pkg, sc, args.cpu_seconds, threads)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

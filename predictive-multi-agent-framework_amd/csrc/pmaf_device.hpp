@@ -173,6 +173,43 @@ __device__ __forceinline__ void ordered_accumulate(V3 &F, V3 c, bool has_c, int 
   }
 }
 
+// ---- DPP wave reductions (wave64, no LDS crossbar round trips) -------------
+// dpp_ctrl encodings: quad_perm 0x00-0xFF, row_half_mirror 0x141, row_mirror
+// 0x140, row_bcast15 0x142, row_bcast31 0x143 (GFX9 / CDNA).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_d(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_i(int v) {
+  return __builtin_amdgcn_update_dpp(v, v, CTRL, ROW_MASK, 0xf, false);
+}
+__device__ __forceinline__ double sel_min(double a, double b) { return (b < a) ? b : a; }
+
+// minimum over the 64 lanes, returned wave-uniform. Inputs must not be NaN.
+__device__ __forceinline__ double wave_min64(double v) {
+  v = sel_min(v, dpp_d<0xB1, 0xf>(v));   // lane ^ 1 within quads
+  v = sel_min(v, dpp_d<0x4E, 0xf>(v));   // lane ^ 2 within quads
+  v = sel_min(v, dpp_d<0x141, 0xf>(v));  // row_half_mirror: other quad of the 8-lane half
+  v = sel_min(v, dpp_d<0x140, 0xf>(v));  // row_mirror: other half of the 16-lane row
+  v = sel_min(v, dpp_d<0x142, 0xa>(v));  // row_bcast15 -> rows 1,3
+  v = sel_min(v, dpp_d<0x143, 0xc>(v));  // row_bcast31 -> rows 2,3; lane 63 holds the total
+  return readlane_d(v, 63);
+}
+__device__ __forceinline__ int wave_min64_i(int v) {
+  int o;
+  o = dpp_i<0xB1, 0xf>(v); v = o < v ? o : v;
+  o = dpp_i<0x4E, 0xf>(v); v = o < v ? o : v;
+  o = dpp_i<0x141, 0xf>(v); v = o < v ? o : v;
+  o = dpp_i<0x140, 0xf>(v); v = o < v ? o : v;
+  o = dpp_i<0x142, 0xa>(v); v = o < v ? o : v;
+  o = dpp_i<0x143, 0xc>(v); v = o < v ? o : v;
+  return __builtin_amdgcn_readlane(v, 63);
+}
+
 // ---- heuristics ----------------------------------------------------------
 // currentVector, B/src/cf_agent.cpp:389-406 (Goal), 414-426 (Obstacle),
 // 463-475 (GoalObstacle), 520-537 (Vel), 545-557 (Random), 585-597 (Had).
@@ -327,6 +364,100 @@ __device__ __forceinline__ void circ_and_scale(bool act, int sub, int grp, int t
     } else {
       double w1 = 1 - portable_exp(-__builtin_sqrt(best_d) / C.shell);
       V3 ro = T.pos(best_i) - p;
+      double w2 = 1 - (dot(g, ro) / (norm(g) * norm(ro)));
+      w2 = w2 * w2;
+      scale = w1 * w2;
+    }
+  }
+}
+
+// ---- wave-per-agent specialisation (LPA = 64), latency-tuned ---------------
+// Same arithmetic as circ_and_scale<64,false>; differences are mechanical:
+// the lane's rotation vectors live in registers (rx/ry/rz[TILES], written
+// through to global memory on a latch so they persist across ticks), the
+// min / argmin reductions use DPP instead of ds_bpermute, and with TILES == 1
+// the closest obstacle's position is fetched with v_readlane instead of LDS.
+template <int TILES>
+__device__ __forceinline__ void circ_and_scale_w64(bool act, int lane, int type, V3 p, V3 v, V3 goal, V3 g,
+                                                   const PopConst &C, double k_circ, const ObsTab &T,
+                                                   int n_obs, double *rot_g, const double *rand_g,
+                                                   unsigned &known_bits, double (&rx)[TILES],
+                                                   double (&ry)[TILES], double (&rz)[TILES], double &min_obs,
+                                                   V3 &F, double &scale) {
+  if (!act) return;  // wave-uniform: one agent per wave
+  const int M = n_obs - 1;
+  V3 gn = normalized(g);
+  double lane_min = min_obs;
+  double best_d = C.shell;
+  int best_i = 0x7fffffff;
+  V3 op0 = mk(0.0, 0.0, 0.0);
+#pragma unroll
+  for (int t = 0; t < TILES; t++) {
+    int i = t * 64 + lane;
+    bool valid = i < M;
+    int ii = valid ? i : 0;
+    V3 op = T.pos(ii);
+    V3 ov = T.vel(ii);
+    double orad = T.r[ii];
+    if (t == 0) op0 = op;
+    V3 ro = op - p;
+    V3 rv = v - ov;
+    double z = sqn(ro);
+    double s = __builtin_sqrt(z);
+    V3 ron = (z > 0.0) ? (ro / s) : ro;
+    bool skip = (dot(ron, gn) < -0.01) && (dot(ro, rv) < -0.01);
+    double d = s - (C.rad + orad);
+    d = smax(d, 1e-5);
+    if (valid && d < best_d) { best_d = d; best_i = i; }
+    V3 c = mk(0.0, 0.0, 0.0);
+    bool has_c = false;
+    if (valid && !skip) {
+      if (d < lane_min) lane_min = d;
+      if (d < C.shell) {
+        V3 rot;
+        if (!((known_bits >> t) & 1u)) {
+          V3 rnd = mk(0.0, 0.0, 0.0);
+          if (type == T_RANDOM) rnd = mk(rand_g[i], rand_g[n_obs + i], rand_g[2 * n_obs + i]);
+          rot = calc_rot_vec(type, p, goal, T, n_obs, i, rnd);
+          rot_g[i] = rot.x; rot_g[n_obs + i] = rot.y; rot_g[2 * n_obs + i] = rot.z;
+          rx[t] = rot.x; ry[t] = rot.y; rz[t] = rot.z;
+          known_bits |= (1u << t);
+        } else {
+          rot = mk(rx[t], ry[t], rz[t]);
+        }
+        double vn = norm(rv);
+        if (vn != 0) {
+          V3 nv = rv / vn;
+          V3 cur = current_vector(type, rv, g, ron, rot);
+          c = (k_circ / (d * d)) * cross(nv, cross(cur, nv));
+          has_c = true;
+        }
+      }
+    }
+    ordered_accumulate<64>(F, c, has_c, 0);
+  }
+  min_obs = wave_min64(lane_min);
+  // attractorForceScaling, B/src/cf_agent.cpp:195-227 (only if |F| > 1e-5, :319)
+  if (norm(F) > 1e-5) {
+    double m = wave_min64(best_d);
+    bool cand = (best_i != 0x7fffffff) && (best_d == m);
+    int bi;
+    if (TILES == 1) {
+      unsigned long long bm = __ballot(cand);
+      bi = bm ? (__ffsll((long long)bm) - 1) : 0x7fffffff;
+    } else {
+      bi = wave_min64_i(cand ? best_i : 0x7fffffff);
+    }
+    if (bi == 0x7fffffff) {
+      scale = 1;
+    } else if (dot(g, v) <= 0.0 && norm(v) < C.vel_max - 0.1 * C.vel_max && norm(g) > 0.15) {
+      scale = 0.0;
+    } else {
+      double w1 = 1 - portable_exp(-__builtin_sqrt(m) / C.shell);
+      V3 bp;
+      if (TILES == 1) bp = mk(readlane_d(op0.x, bi), readlane_d(op0.y, bi), readlane_d(op0.z, bi));
+      else bp = T.pos(bi);
+      V3 ro = bp - p;
       double w2 = 1 - (dot(g, ro) / (norm(g) * norm(ro)));
       w2 = w2 * w2;
       scale = w1 * w2;

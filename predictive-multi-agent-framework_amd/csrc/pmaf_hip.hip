@@ -21,6 +21,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -181,6 +182,107 @@ __global__ __launch_bounds__(64) void k_rollout(DevView D, CostParams CP) {
       if (ran) D.reached[pa] = dgf < 0.100001;  // B/src/cf_agent.cpp:330-337
       atomicAdd(D.step_counter, (unsigned long long)(n - 1));
     }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// k_rollout_w64<TILES>: one wave64 per agent, lanes over obstacles, TILES =
+// ceil(M/64) compile-time obstacle slots per lane with their rotation vectors
+// in registers. The latency-bound shape (few agents, e.g. BASELINE C2/C3).
+// ---------------------------------------------------------------------------
+template <int TILES>
+__global__ __launch_bounds__(64) void k_rollout_w64(DevView D, CostParams CP) {
+  extern __shared__ double smem[];
+  const int lane = threadIdx.x;
+  const int pop = blockIdx.y;
+  const int a = blockIdx.x;  // grid.x == N
+  const int n_obs = D.n_obs;
+  const PopConst C = D.C;
+
+  ObsTab T = carve_obstab(smem, n_obs);
+  const int32_t *ks = D.known_start + (size_t)pop * n_obs;
+  {
+    const double *src = D.obs_start + (size_t)pop * 7 * n_obs;
+    for (int i = lane; i < 7 * n_obs; i += 64) smem[i] = src[i];
+  }
+  __syncthreads();
+
+  const size_t pa = (size_t)pop * D.N + a;
+  const V3 goal = mk(D.goal[pop * 3], D.goal[pop * 3 + 1], D.goal[pop * 3 + 2]);
+  const V3 init_pos = mk(D.agent_init_pos[pop * 3], D.agent_init_pos[pop * 3 + 1], D.agent_init_pos[pop * 3 + 2]);
+  V3 p = mk(D.start_pos[pop * 3], D.start_pos[pop * 3 + 1], D.start_pos[pop * 3 + 2]);
+  V3 v = mk(D.start_vel[pop * 3], D.start_vel[pop * 3 + 1], D.start_vel[pop * 3 + 2]);
+  const double k_attr = D.k_attr[pa], k_circ = D.k_circ[pa], k_repel = D.k_repel[pa], k_damp = D.k_damp[pa];
+  const int type = D.types[a];
+  double *rot_g = D.rot + pa * 3 * n_obs;
+  const double *rnd_g = D.rnd + pa * 3 * n_obs;
+  double *path = D.paths + pa * (size_t)D.cap * 3;
+  const int M = n_obs - 1;
+
+  unsigned known_bits = 0u;
+  double rx[TILES], ry[TILES], rz[TILES];
+#pragma unroll
+  for (int t = 0; t < TILES; t++) {
+    int i = t * 64 + lane;
+    bool valid = i < M;
+    int ii = valid ? i : 0;
+    if (valid && ks[ii]) known_bits |= (1u << t);
+    rx[t] = rot_g[ii]; ry[t] = rot_g[n_obs + ii]; rz[t] = rot_g[2 * n_obs + ii];
+  }
+
+  double min_obs = C.shell;
+  double cost_ws = 0.0;
+  double path_len = 0.0;
+  int n = 1;
+  bool ran = false;
+  ws_cost_add(cost_ws, p, CP.ws, CP.k_workspace);
+  if (lane == 0) { path[0] = p.x; path[1] = p.y; path[2] = p.z; }
+
+  while (true) {
+    V3 g = goal - p;
+    double dg = norm(g);
+    bool run = (dg > 0.1) && (n < D.cap);  // wave-uniform
+    if (!run) break;
+    bool gate = !(dg < C.approach || (norm(v) < 0.5 * C.vel_max && norm(p - init_pos) < 0.2));
+    V3 F = mk(0.0, 0.0, 0.0);
+    double scale = 1.0;
+    circ_and_scale_w64<TILES>(gate, lane, type, p, v, goal, g, C, k_circ, T, n_obs, rot_g, rnd_g, known_bits,
+                              rx, ry, rz, min_obs, F, scale);
+    V3 new_pos;
+    finish_step(p, v, g, F, scale, C, k_attr, k_repel, k_damp, C.dt, T.pos(n_obs - 1), T.r[n_obs - 1], new_pos);
+    path_len += norm(new_pos - p);
+    p = new_pos;
+    ws_cost_add(cost_ws, p, CP.ws, CP.k_workspace);
+    if (lane == 0) { path[n * 3] = p.x; path[n * 3 + 1] = p.y; path[n * 3 + 2] = p.z; }
+    n++;
+    ran = true;
+    // predictObstacles, B/src/cf_agent.cpp:270-276 (shared copy, once per step)
+    __syncthreads();
+    for (int i = lane; i < n_obs; i += 64) {
+      T.px[i] = T.px[i] + T.vx[i] * C.dt;
+      T.py[i] = T.py[i] + T.vy[i] * C.dt;
+      T.pz[i] = T.pz[i] + T.vz[i] * C.dt;
+    }
+    __syncthreads();
+  }
+
+  int32_t *ko = D.known_out + pa * n_obs;
+#pragma unroll
+  for (int t = 0; t < TILES; t++) {
+    int i = t * 64 + lane;
+    if (i < M) ko[i] = (int32_t)((known_bits >> t) & 1u);
+  }
+  if (lane == 0) {
+    ko[M] = ks[M];
+    D.n_points[pa] = n;
+    D.agent_vel[pa * 3] = v.x; D.agent_vel[pa * 3 + 1] = v.y; D.agent_vel[pa * 3 + 2] = v.z;
+    D.min_obs[pa] = min_obs;
+    D.cost_ws[pa] = cost_ws;
+    D.path_len[pa] = path_len;
+    double dgf = norm(goal - p);
+    D.goal_dist[pa] = dgf;
+    if (ran) D.reached[pa] = dgf < 0.100001;  // B/src/cf_agent.cpp:330-337
+    atomicAdd(D.step_counter, (unsigned long long)(n - 1));
   }
 }
 
@@ -448,6 +550,7 @@ struct pmaf_planner {
   DevView D{};
   int device = 0;
   int lpa = 64;
+  bool force_generic = false;  // PMAF_FORCE_GENERIC=1: always use the generic k_rollout<LPA>
   int n_blocks = 0;
   size_t lds_rollout = 0, lds_manager = 0;
   hipStream_t stream = nullptr;
@@ -506,8 +609,7 @@ static int pick_lpa(int N, int P, int M) {
   int lpa = 64;
   while (lpa > 1) {
     long waves = ((long)N * lpa + 63) / 64 * P;
-    bool too_wide = lpa / 2 >= (M > 0 ? M : 1);
-    if (waves > 2048 || too_wide) lpa /= 2; else break;
+    if (waves > 2048) lpa /= 2; else break;
   }
   // known-flag bitmask holds 64 tiles per lane
   while ((M + lpa - 1) / lpa > 64 && lpa < 64) lpa *= 2;
@@ -548,6 +650,13 @@ static void launch_rollout(pmaf_planner *h) {
     h->ev_inflight.emplace_back(e0, e1);
     HIP_CHECK(hipEventRecord(e0, h->stream));
   }
+  const int tiles64 = (h->D.n_obs - 1 + 63) / 64;
+  if (h->lpa == 64 && tiles64 <= 4 && !h->force_generic) {
+    dim3 g64((unsigned)h->D.N, (unsigned)h->D.P);
+    if (tiles64 <= 1) hipLaunchKernelGGL((k_rollout_w64<1>), g64, block, h->lds_rollout, h->stream, h->D, h->cp);
+    else if (tiles64 == 2) hipLaunchKernelGGL((k_rollout_w64<2>), g64, block, h->lds_rollout, h->stream, h->D, h->cp);
+    else hipLaunchKernelGGL((k_rollout_w64<4>), g64, block, h->lds_rollout, h->stream, h->D, h->cp);
+  } else
   switch (h->lpa) {
 #define PMAF_CASE(L) case L: hipLaunchKernelGGL((k_rollout<L>), grid, block, h->lds_rollout, h->stream, h->D, h->cp); break;
     PMAF_CASE(1) PMAF_CASE(2) PMAF_CASE(4) PMAF_CASE(8) PMAF_CASE(16) PMAF_CASE(32) PMAF_CASE(64)
@@ -669,6 +778,7 @@ int pmaf_create(const pmaf_params *prm, pmaf_planner **out) {
     D.C.dt = prm->dt; D.C.vel_max = prm->velocity_max; D.C.approach = prm->approach_dist;
     D.C.shell = prm->detect_shell_rad; D.C.mass = prm->agent_mass; D.C.rad = prm->radius;
     h->lpa = lp ? lp : pick_lpa(N, P, M);
+    { const char *fg = getenv("PMAF_FORCE_GENERIC"); h->force_generic = fg && fg[0] == '1'; }
     REQUIRE((M + h->lpa - 1) / h->lpa <= 64, "pmaf_create: too many obstacles for this lanes_per_agent (need M <= 64*lanes_per_agent)");
     h->n_blocks = (N * h->lpa + 63) / 64;
     h->lds_rollout = sizeof(double) * 7 * n_obs + sizeof(int32_t) * n_obs;

@@ -70,33 +70,21 @@ double pmaf_portable_exp(double x) {
                P1 = 1.66666666666666019037e-01, P2 = -2.77777777770155933842e-03,
                P3 = 6.61375632143793436117e-05, P4 = -1.65339022054652515390e-06,
                P5 = 4.13813679705723846039e-08;
-  double hi = 0.0, lo = 0.0, t, c, y;
-  int k = 0;
-  double ax = fabs(x);
-  if (ax > 708.0) return (x > 0) ? HUGE_VAL : 0.0;       /* outside the path's range */
-  if (ax > 0.34657359027997264) {                        /* |x| > 0.5 ln2 */
-    if (ax < 1.0397207708399179) {                       /* |x| < 1.5 ln2 */
-      if (x > 0) { hi = x - ln2HI; lo = ln2LO; k = 1; }
-      else { hi = x + ln2HI; lo = -ln2LO; k = -1; }
-    } else {
-      k = (int)(invln2 * x + ((x < 0) ? -0.5 : 0.5));
-      t = (double)k;
-      hi = x - t * ln2HI;
-      lo = t * ln2LO;
-    }
-    x = hi - lo;
-  } else if (ax < 3.725290298461914e-09) {               /* |x| < 2^-28 */
-    return 1.0 + x;
-  }
-  t = x * x;
-  c = x - t * (P1 + t * (P2 + t * (P3 + t * (P4 + t * P5))));
-  if (k == 0) return 1.0 - ((x * c) / (c - 2.0) - x);
-  y = 1.0 - ((lo - (x * c) / (2.0 - c)) - hi);
-  {
-    union { uint64_t u; double d; } two_k;
-    two_k.u = (uint64_t)(1023 + k) << 52;                /* 2^k, exact scaling */
-    return y * two_k.d;
-  }
+  const double ax = fabs(x);
+  if (ax > 708.0) return (x > 0) ? HUGE_VAL : 0.0;        /* outside the path's range */
+  if (ax < 3.725290298461914e-09) return 1.0 + x;         /* |x| < 2^-28 */
+  /* k = 0 for |x| <= 0.5 ln2, else round(x / ln2); one formula for all k */
+  const int k = (ax > 0.34657359027997264) ? (int)(invln2 * x + ((x < 0) ? -0.5 : 0.5)) : 0;
+  const double t = (double)k;
+  const double hi = x - t * ln2HI;
+  const double lo = t * ln2LO;
+  const double r = hi - lo;
+  const double r2 = r * r;
+  const double c = r - r2 * (P1 + r2 * (P2 + r2 * (P3 + r2 * (P4 + r2 * P5))));
+  const double y = 1.0 - ((lo - (r * c) / (2.0 - c)) - hi);
+  union { uint64_t u; double d; } two_k;
+  two_k.u = (uint64_t)(1023 + k) << 52;                   /* 2^k, exact scaling */
+  return y * two_k.d;
 }
 static inline double orc_exp(double x) { return g_exp_mode ? pmaf_portable_exp(x) : exp(x); }
 

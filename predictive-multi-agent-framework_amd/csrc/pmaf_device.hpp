@@ -66,28 +66,20 @@ __device__ __forceinline__ double portable_exp(double x) {
                P1 = 1.66666666666666019037e-01, P2 = -2.77777777770155933842e-03,
                P3 = 6.61375632143793436117e-05, P4 = -1.65339022054652515390e-06,
                P5 = 4.13813679705723846039e-08;
-  double hi = 0.0, lo = 0.0, t, c, y;
-  int k = 0;
-  double ax = fabs(x);
-  if (ax > 708.0) return (x > 0) ? __builtin_huge_val() : 0.0;
-  if (ax > 0.34657359027997264) {
-    if (ax < 1.0397207708399179) {
-      if (x > 0) { hi = x - ln2HI; lo = ln2LO; k = 1; }
-      else { hi = x + ln2HI; lo = -ln2LO; k = -1; }
-    } else {
-      k = (int)(invln2 * x + ((x < 0) ? -0.5 : 0.5));
-      t = (double)k;
-      hi = x - t * ln2HI;
-      lo = t * ln2LO;
-    }
-    x = hi - lo;
-  } else if (ax < 3.725290298461914e-09) {
-    return 1.0 + x;
-  }
-  t = x * x;
-  c = x - t * (P1 + t * (P2 + t * (P3 + t * (P4 + t * P5))));
-  if (k == 0) return 1.0 - ((x * c) / (c - 2.0) - x);
-  y = 1.0 - ((lo - (x * c) / (2.0 - c)) - hi);
+  const double ax = fabs(x);
+  if (ax > 708.0) return (x > 0) ? __builtin_huge_val() : 0.0;  // outside the path's range
+  if (ax < 3.725290298461914e-09) return 1.0 + x;                // |x| < 2^-28
+  // k = 0 for |x| <= 0.5 ln2, else round(x / ln2); one formula for all k
+  // (for k = 0: hi = x, lo = 0, and 1 - ((0 - q) - x) == 1 - (-q - x), the
+  // k == 0 branch of the classic formulation, bit for bit)
+  const int k = (ax > 0.34657359027997264) ? (int)(invln2 * x + ((x < 0) ? -0.5 : 0.5)) : 0;
+  const double t = (double)k;
+  const double hi = x - t * ln2HI;
+  const double lo = t * ln2LO;
+  const double r = hi - lo;
+  const double r2 = r * r;
+  const double c = r - r2 * (P1 + r2 * (P2 + r2 * (P3 + r2 * (P4 + r2 * P5))));
+  const double y = 1.0 - ((lo - (r * c) / (2.0 - c)) - hi);
   return y * __longlong_as_double((long long)(1023 + k) << 52);
 }
 
@@ -232,10 +224,9 @@ __device__ __forceinline__ V3 current_vector(int type, V3 agent_vel, V3 goal_vec
 }
 
 // nearest other field obstacle by centre distance, cf_agent.cpp:434-446 / :480-492
-__device__ __forceinline__ int closest_other(const ObsTab &T, int n_obs, int id) {
+__device__ __forceinline__ int closest_other(const ObsTab &T, int n_obs, int id, V3 oid) {
   double min_dist = 100.0;
   int closest = 0;
-  V3 oid = T.pos(id);
   for (int i = 0; i < n_obs - 1; i++) {
     if (i != id) {
       double d = norm(oid - T.pos(i));
@@ -248,21 +239,23 @@ __device__ __forceinline__ int closest_other(const ObsTab &T, int n_obs, int id)
 // calculateRotationVector, B/src/cf_agent.cpp:408-412 (Goal), 428-461
 // (Obstacle), 477-518 (GoalObstacle), 539-543 (Vel), 559-566 (Random),
 // 599-611 (Had)
+// own_pos = position of obstacle `id` (the caller has it in registers; it is
+// the same value as T.pos(id)); T is only read for the closest-other search.
 __device__ __forceinline__ V3 calc_rot_vec(int type, V3 agent_pos, V3 goal_pos, const ObsTab &T,
-                                           int n_obs, int id, V3 rand_vec) {
+                                           int n_obs, int id, V3 own_pos, V3 rand_vec) {
   if (type == T_GOAL || type == T_VEL) return mk(0.0, 0.0, 1.0);
   if (type == T_OBST) {
     if (n_obs < 2) return mk(0.0, 0.0, 1.0);
-    int c = closest_other(T, n_obs, id);
-    V3 obstacle_vec = T.pos(c) - T.pos(id);
-    V3 to_obs = normalized(T.pos(id) - agent_pos);
+    int c = closest_other(T, n_obs, id, own_pos);
+    V3 obstacle_vec = T.pos(c) - own_pos;
+    V3 to_obs = normalized(own_pos - agent_pos);
     V3 cur = to_obs * dot(obstacle_vec, to_obs) - obstacle_vec;
     return normalized(cross(cur, to_obs));
   }
   if (type == T_GOALOBST) {
-    int c = closest_other(T, n_obs, id);
-    V3 obstacle_vec = T.pos(c) - T.pos(id);
-    V3 to_obs = normalized(T.pos(id) - agent_pos);
+    int c = closest_other(T, n_obs, id, own_pos);
+    V3 obstacle_vec = T.pos(c) - own_pos;
+    V3 to_obs = normalized(own_pos - agent_pos);
     V3 obst_cur = to_obs * dot(obstacle_vec, to_obs) - obstacle_vec;
     V3 goal_vec = goal_pos - agent_pos;
     V3 goal_cur = goal_vec - to_obs * dot(to_obs, goal_vec);
@@ -276,7 +269,7 @@ __device__ __forceinline__ V3 calc_rot_vec(int type, V3 agent_pos, V3 goal_pos, 
     return cross(goal_vec, rand_vec);
   }
   if (type == T_HAD) {
-    V3 obs_pos = T.pos(id);
+    V3 obs_pos = own_pos;
     V3 goal_vec = goal_pos - agent_pos;
     V3 rob_obs = obs_pos - agent_pos;
     double gn = norm(goal_vec);
@@ -333,7 +326,7 @@ __device__ __forceinline__ void circ_and_scale(bool act, int sub, int grp, int t
         if (!((known_bits >> t) & 1ull)) {
           V3 rnd = mk(0.0, 0.0, 0.0);
           if (type == T_RANDOM) rnd = mk(rand_g[i], rand_g[n_obs + i], rand_g[2 * n_obs + i]);
-          rot = calc_rot_vec(type, p, goal, T, n_obs, i, rnd);
+          rot = calc_rot_vec(type, p, goal, T, n_obs, i, op, rnd);
           rot_g[i] = rot.x; rot_g[n_obs + i] = rot.y; rot_g[2 * n_obs + i] = rot.z;
           known_bits |= (1ull << t);
         } else {
@@ -371,100 +364,6 @@ __device__ __forceinline__ void circ_and_scale(bool act, int sub, int grp, int t
   }
 }
 
-// ---- wave-per-agent specialisation (LPA = 64), latency-tuned ---------------
-// Same arithmetic as circ_and_scale<64,false>; differences are mechanical:
-// the lane's rotation vectors live in registers (rx/ry/rz[TILES], written
-// through to global memory on a latch so they persist across ticks), the
-// min / argmin reductions use DPP instead of ds_bpermute, and with TILES == 1
-// the closest obstacle's position is fetched with v_readlane instead of LDS.
-template <int TILES>
-__device__ __forceinline__ void circ_and_scale_w64(bool act, int lane, int type, V3 p, V3 v, V3 goal, V3 g,
-                                                   const PopConst &C, double k_circ, const ObsTab &T,
-                                                   int n_obs, double *rot_g, const double *rand_g,
-                                                   unsigned &known_bits, double (&rx)[TILES],
-                                                   double (&ry)[TILES], double (&rz)[TILES], double &min_obs,
-                                                   V3 &F, double &scale) {
-  if (!act) return;  // wave-uniform: one agent per wave
-  const int M = n_obs - 1;
-  V3 gn = normalized(g);
-  double lane_min = min_obs;
-  double best_d = C.shell;
-  int best_i = 0x7fffffff;
-  V3 op0 = mk(0.0, 0.0, 0.0);
-#pragma unroll
-  for (int t = 0; t < TILES; t++) {
-    int i = t * 64 + lane;
-    bool valid = i < M;
-    int ii = valid ? i : 0;
-    V3 op = T.pos(ii);
-    V3 ov = T.vel(ii);
-    double orad = T.r[ii];
-    if (t == 0) op0 = op;
-    V3 ro = op - p;
-    V3 rv = v - ov;
-    double z = sqn(ro);
-    double s = __builtin_sqrt(z);
-    V3 ron = (z > 0.0) ? (ro / s) : ro;
-    bool skip = (dot(ron, gn) < -0.01) && (dot(ro, rv) < -0.01);
-    double d = s - (C.rad + orad);
-    d = smax(d, 1e-5);
-    if (valid && d < best_d) { best_d = d; best_i = i; }
-    V3 c = mk(0.0, 0.0, 0.0);
-    bool has_c = false;
-    if (valid && !skip) {
-      if (d < lane_min) lane_min = d;
-      if (d < C.shell) {
-        V3 rot;
-        if (!((known_bits >> t) & 1u)) {
-          V3 rnd = mk(0.0, 0.0, 0.0);
-          if (type == T_RANDOM) rnd = mk(rand_g[i], rand_g[n_obs + i], rand_g[2 * n_obs + i]);
-          rot = calc_rot_vec(type, p, goal, T, n_obs, i, rnd);
-          rot_g[i] = rot.x; rot_g[n_obs + i] = rot.y; rot_g[2 * n_obs + i] = rot.z;
-          rx[t] = rot.x; ry[t] = rot.y; rz[t] = rot.z;
-          known_bits |= (1u << t);
-        } else {
-          rot = mk(rx[t], ry[t], rz[t]);
-        }
-        double vn = norm(rv);
-        if (vn != 0) {
-          V3 nv = rv / vn;
-          V3 cur = current_vector(type, rv, g, ron, rot);
-          c = (k_circ / (d * d)) * cross(nv, cross(cur, nv));
-          has_c = true;
-        }
-      }
-    }
-    ordered_accumulate<64>(F, c, has_c, 0);
-  }
-  min_obs = wave_min64(lane_min);
-  // attractorForceScaling, B/src/cf_agent.cpp:195-227 (only if |F| > 1e-5, :319)
-  if (norm(F) > 1e-5) {
-    double m = wave_min64(best_d);
-    bool cand = (best_i != 0x7fffffff) && (best_d == m);
-    int bi;
-    if (TILES == 1) {
-      unsigned long long bm = __ballot(cand);
-      bi = bm ? (__ffsll((long long)bm) - 1) : 0x7fffffff;
-    } else {
-      bi = wave_min64_i(cand ? best_i : 0x7fffffff);
-    }
-    if (bi == 0x7fffffff) {
-      scale = 1;
-    } else if (dot(g, v) <= 0.0 && norm(v) < C.vel_max - 0.1 * C.vel_max && norm(g) > 0.15) {
-      scale = 0.0;
-    } else {
-      double w1 = 1 - portable_exp(-__builtin_sqrt(m) / C.shell);
-      V3 bp;
-      if (TILES == 1) bp = mk(readlane_d(op0.x, bi), readlane_d(op0.y, bi), readlane_d(op0.z, bi));
-      else bp = T.pos(bi);
-      V3 ro = bp - p;
-      double w2 = 1 - (dot(g, ro) / (norm(g) * norm(ro)));
-      w2 = w2 * w2;
-      scale = w1 * w2;
-    }
-  }
-}
-
 // repelForce (:159-181) + attractorForce (:183-193) + updatePositionAndVelocity
 // (:253-268): O(1) per agent, evaluated by every lane of the group.
 __device__ __forceinline__ void finish_step(V3 p, V3 &v, V3 goal_vec, V3 &F, double scale,
@@ -492,7 +391,10 @@ __device__ __forceinline__ void finish_step(V3 p, V3 &v, V3 goal_vec, V3 &F, dou
     vel_des = vel_des * scale_lim;
     F = F + (scale * k_damp) * (vel_des - v);
   }
-  V3 acc = F / C.mass;
+  // force_ / mass_; x / 1.0 == x exactly for every x, so the reference's
+  // default mass (1.0) needs no division
+  V3 acc = F;
+  if (C.mass != 1.0) acc = F / C.mass;
   double an = norm(acc);
   if (an > 13.0) acc = acc * (13.0 / an);
   V3 half = ((0.5 * acc) * dt) * dt;
@@ -506,13 +408,17 @@ __device__ __forceinline__ void finish_step(V3 p, V3 &v, V3 goal_vec, V3 &F, dou
 // workspace-box penalty of one path point, B/src/cf_manager.cpp:302-324;
 // adds up to three terms to cost in x,y,z order.
 __device__ __forceinline__ void ws_cost_add(double &cost, V3 q, const double *ws, double k_ws) {
-  double t;
-  if (q.x > ws[0]) { t = fabs(q.x - ws[0]) * k_ws; cost += t * t; }
-  else if (q.x < ws[1]) { t = fabs(q.x - ws[1]) * k_ws; cost += t * t; }
-  if (q.y > ws[2]) { t = fabs(q.y - ws[2]) * k_ws; cost += t * t; }
-  else if (q.y < ws[3]) { t = fabs(q.y - ws[3]) * k_ws; cost += t * t; }
-  if (q.z > ws[4]) { t = fabs(q.z - ws[4]) * k_ws; cost += t * t; }
-  else if (q.z < ws[5]) { t = fabs(q.z - ws[5]) * k_ws; cost += t * t; }
+  // one (rarely taken) branch for the common in-box case
+  const bool out = (q.x > ws[0]) | (q.x < ws[1]) | (q.y > ws[2]) | (q.y < ws[3]) | (q.z > ws[4]) | (q.z < ws[5]);
+  if (out) {
+    double t;
+    if (q.x > ws[0]) { t = fabs(q.x - ws[0]) * k_ws; cost += t * t; }
+    else if (q.x < ws[1]) { t = fabs(q.x - ws[1]) * k_ws; cost += t * t; }
+    if (q.y > ws[2]) { t = fabs(q.y - ws[2]) * k_ws; cost += t * t; }
+    else if (q.y < ws[3]) { t = fabs(q.y - ws[3]) * k_ws; cost += t * t; }
+    if (q.z > ws[4]) { t = fabs(q.z - ws[4]) * k_ws; cost += t * t; }
+    else if (q.z < ws[5]) { t = fabs(q.z - ws[5]) * k_ws; cost += t * t; }
+  }
 }
 
 }  // namespace pmaf

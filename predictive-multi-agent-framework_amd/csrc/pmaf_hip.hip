@@ -28,6 +28,7 @@
 
 #include "../../include/pmaf.h"
 #include "pmaf_device.hpp"
+#include "pmaf_rollout_w64.hpp"
 
 using namespace pmaf;
 
@@ -186,49 +187,60 @@ __global__ __launch_bounds__(64) void k_rollout(DevView D, CostParams CP) {
 }
 
 // ---------------------------------------------------------------------------
-// k_rollout_w64<TILES>: one wave64 per agent, lanes over obstacles, TILES =
-// ceil(M/64) compile-time obstacle slots per lane with their rotation vectors
-// in registers. The latency-bound shape (few agents, e.g. BASELINE C2/C3).
+// k_rollout_w64<TILES>: one wave64 per agent (see pmaf_rollout_w64.hpp)
 // ---------------------------------------------------------------------------
-template <int TILES>
-__global__ __launch_bounds__(64) void k_rollout_w64(DevView D, CostParams CP) {
+// the step loop, specialised on the agent's heuristic so the per-step code
+// carries no type dispatch (the type is uniform per wave)
+template <int TILES, int TYPE>
+__device__ __forceinline__ void rollout_w64_body(const DevView &D, const CostParams &CP, const int lane,
+                                                 const int pop, const int a) {
   extern __shared__ double smem[];
-  const int lane = threadIdx.x;
-  const int pop = blockIdx.y;
-  const int a = blockIdx.x;  // grid.x == N
   const int n_obs = D.n_obs;
+  const int M = n_obs - 1;
   const PopConst C = D.C;
+  const size_t pa = (size_t)pop * D.N + a;
+  // only the "closest other obstacle" search of these two heuristics reads the table
+  constexpr bool need_table = (TYPE == T_OBST) || (TYPE == T_GOALOBST);
 
   ObsTab T = carve_obstab(smem, n_obs);
+  const double *src = D.obs_start + (size_t)pop * 7 * n_obs;
   const int32_t *ks = D.known_start + (size_t)pop * n_obs;
-  {
-    const double *src = D.obs_start + (size_t)pop * 7 * n_obs;
-    for (int i = lane; i < 7 * n_obs; i += 64) smem[i] = src[i];
-  }
-  __syncthreads();
-
-  const size_t pa = (size_t)pop * D.N + a;
-  const V3 goal = mk(D.goal[pop * 3], D.goal[pop * 3 + 1], D.goal[pop * 3 + 2]);
-  const V3 init_pos = mk(D.agent_init_pos[pop * 3], D.agent_init_pos[pop * 3 + 1], D.agent_init_pos[pop * 3 + 2]);
-  V3 p = mk(D.start_pos[pop * 3], D.start_pos[pop * 3 + 1], D.start_pos[pop * 3 + 2]);
-  V3 v = mk(D.start_vel[pop * 3], D.start_vel[pop * 3 + 1], D.start_vel[pop * 3 + 2]);
-  const double k_attr = D.k_attr[pa], k_circ = D.k_circ[pa], k_repel = D.k_repel[pa], k_damp = D.k_damp[pa];
-  const int type = D.types[a];
   double *rot_g = D.rot + pa * 3 * n_obs;
   const double *rnd_g = D.rnd + pa * 3 * n_obs;
-  double *path = D.paths + pa * (size_t)D.cap * 3;
-  const int M = n_obs - 1;
 
+  LaneObstacles<TILES> O;
   unsigned known_bits = 0u;
-  double rx[TILES], ry[TILES], rz[TILES];
 #pragma unroll
   for (int t = 0; t < TILES; t++) {
     int i = t * 64 + lane;
     bool valid = i < M;
     int ii = valid ? i : 0;
+    O.p[t] = mk(src[ii], src[n_obs + ii], src[2 * n_obs + ii]);
+    O.v[t] = mk(src[3 * n_obs + ii], src[4 * n_obs + ii], src[5 * n_obs + ii]);
+    O.r[t] = src[6 * n_obs + ii];
+    O.rx[t] = rot_g[ii]; O.ry[t] = rot_g[n_obs + ii]; O.rz[t] = rot_g[2 * n_obs + ii];
+    if (TYPE == T_RANDOM) { O.qx[t] = rnd_g[ii]; O.qy[t] = rnd_g[n_obs + ii]; O.qz[t] = rnd_g[2 * n_obs + ii]; }
+    else { O.qx[t] = 0.0; O.qy[t] = 0.0; O.qz[t] = 0.0; }
     if (valid && ks[ii]) known_bits |= (1u << t);
-    rx[t] = rot_g[ii]; ry[t] = rot_g[n_obs + ii]; rz[t] = rot_g[2 * n_obs + ii];
+    if (need_table && valid) { T.px[i] = O.p[t].x; T.py[i] = O.p[t].y; T.pz[i] = O.p[t].z; }
   }
+  // trailing repulsive obstacle, wave-uniform
+  V3 sent_p = mk(src[M], src[n_obs + M], src[2 * n_obs + M]);
+  const V3 sent_v = mk(src[3 * n_obs + M], src[4 * n_obs + M], src[5 * n_obs + M]);
+  const double sent_r = src[6 * n_obs + M];
+  if (need_table) wave_lds_fence();
+
+  const V3 goal = mk(D.goal[pop * 3], D.goal[pop * 3 + 1], D.goal[pop * 3 + 2]);
+  const V3 init_pos = mk(D.agent_init_pos[pop * 3], D.agent_init_pos[pop * 3 + 1], D.agent_init_pos[pop * 3 + 2]);
+  V3 p = mk(D.start_pos[pop * 3], D.start_pos[pop * 3 + 1], D.start_pos[pop * 3 + 2]);
+  V3 v = mk(D.start_vel[pop * 3], D.start_vel[pop * 3 + 1], D.start_vel[pop * 3 + 2]);
+  const double k_attr = D.k_attr[pa], k_circ = D.k_circ[pa], k_repel = D.k_repel[pa], k_damp = D.k_damp[pa];
+  double *path = D.paths + pa * (size_t)D.cap * 3;
+
+  // LDS list of the step's non-zero circular-field terms (after the obstacle table)
+  int clist_off = 7 * n_obs + (n_obs + 1) / 2;
+  clist_off += clist_off & 1;
+  double *clist = smem + clist_off;
 
   double min_obs = C.shell;
   double cost_ws = 0.0;
@@ -238,32 +250,44 @@ __global__ __launch_bounds__(64) void k_rollout_w64(DevView D, CostParams CP) {
   ws_cost_add(cost_ws, p, CP.ws, CP.k_workspace);
   if (lane == 0) { path[0] = p.x; path[1] = p.y; path[2] = p.z; }
 
-  while (true) {
-    V3 g = goal - p;
-    double dg = norm(g);
-    bool run = (dg > 0.1) && (n < D.cap);  // wave-uniform
-    if (!run) break;
-    bool gate = !(dg < C.approach || (norm(v) < 0.5 * C.vel_max && norm(p - init_pos) < 0.2));
+  // norms of the loop guard / gate are carried from the end of the previous
+  // step, where they share a basic block (and the FP64 pipeline) with the
+  // path-length norm
+  V3 g = goal - p;
+  double dg = norm(g);
+  double nrm_v = norm(v);
+  double d_init = norm(p - init_pos);
+  while ((dg > 0.1) && (n < D.cap)) {  // wave-uniform guard, B/src/cf_agent.cpp:310-311
+    // gate, :315-317
+    const bool gate = !(dg < C.approach || (nrm_v < 0.5 * C.vel_max && d_init < 0.2));
     V3 F = mk(0.0, 0.0, 0.0);
     double scale = 1.0;
-    circ_and_scale_w64<TILES>(gate, lane, type, p, v, goal, g, C, k_circ, T, n_obs, rot_g, rnd_g, known_bits,
-                              rx, ry, rz, min_obs, F, scale);
+    if (gate)
+      circ_and_scale_w64<TILES, TYPE>(lane, p, v, nrm_v, goal, g, dg, C, k_circ, T, n_obs, rot_g, known_bits, O,
+                                      clist, min_obs, F, scale);
     V3 new_pos;
-    finish_step(p, v, g, F, scale, C, k_attr, k_repel, k_damp, C.dt, T.pos(n_obs - 1), T.r[n_obs - 1], new_pos);
-    path_len += norm(new_pos - p);
+    finish_step(p, v, g, F, scale, C, k_attr, k_repel, k_damp, C.dt, sent_p, sent_r, new_pos);
+    const V3 dp = new_pos - p;
     p = new_pos;
+    g = goal - p;
+    const double seg = norm(dp);
+    dg = norm(g);
+    nrm_v = norm(v);
+    d_init = norm(p - init_pos);
+    path_len += seg;
     ws_cost_add(cost_ws, p, CP.ws, CP.k_workspace);
     if (lane == 0) { path[n * 3] = p.x; path[n * 3 + 1] = p.y; path[n * 3 + 2] = p.z; }
     n++;
     ran = true;
-    // predictObstacles, B/src/cf_agent.cpp:270-276 (shared copy, once per step)
-    __syncthreads();
-    for (int i = lane; i < n_obs; i += 64) {
-      T.px[i] = T.px[i] + T.vx[i] * C.dt;
-      T.py[i] = T.py[i] + T.vy[i] * C.dt;
-      T.pz[i] = T.pz[i] + T.vz[i] * C.dt;
+    // predictObstacles, B/src/cf_agent.cpp:270-276, in registers
+#pragma unroll
+    for (int t = 0; t < TILES; t++) {
+      O.p[t] = O.p[t] + O.v[t] * C.dt;
+      int i = t * 64 + lane;
+      if (need_table && i < M) { T.px[i] = O.p[t].x; T.py[i] = O.p[t].y; T.pz[i] = O.p[t].z; }
     }
-    __syncthreads();
+    sent_p = sent_p + sent_v * C.dt;
+    if (need_table) wave_lds_fence();
   }
 
   int32_t *ko = D.known_out + pa * n_obs;
@@ -279,10 +303,25 @@ __global__ __launch_bounds__(64) void k_rollout_w64(DevView D, CostParams CP) {
     D.min_obs[pa] = min_obs;
     D.cost_ws[pa] = cost_ws;
     D.path_len[pa] = path_len;
-    double dgf = norm(goal - p);
-    D.goal_dist[pa] = dgf;
-    if (ran) D.reached[pa] = dgf < 0.100001;  // B/src/cf_agent.cpp:330-337
+    D.goal_dist[pa] = dg;
+    if (ran) D.reached[pa] = dg < 0.100001;  // B/src/cf_agent.cpp:330-337
     atomicAdd(D.step_counter, (unsigned long long)(n - 1));
+  }
+}
+
+template <int TILES>
+__global__ __launch_bounds__(64) void k_rollout_w64(DevView D, CostParams CP) {
+  const int lane = threadIdx.x;
+  const int pop = blockIdx.y;
+  const int a = blockIdx.x;  // grid.x == N
+  switch (D.types[a]) {
+    case T_GOAL: rollout_w64_body<TILES, T_GOAL>(D, CP, lane, pop, a); break;
+    case T_OBST: rollout_w64_body<TILES, T_OBST>(D, CP, lane, pop, a); break;
+    case T_GOALOBST: rollout_w64_body<TILES, T_GOALOBST>(D, CP, lane, pop, a); break;
+    case T_VEL: rollout_w64_body<TILES, T_VEL>(D, CP, lane, pop, a); break;
+    case T_RANDOM: rollout_w64_body<TILES, T_RANDOM>(D, CP, lane, pop, a); break;
+    case T_HAD: rollout_w64_body<TILES, T_HAD>(D, CP, lane, pop, a); break;
+    default: break;
   }
 }
 
@@ -781,7 +820,13 @@ int pmaf_create(const pmaf_params *prm, pmaf_planner **out) {
     { const char *fg = getenv("PMAF_FORCE_GENERIC"); h->force_generic = fg && fg[0] == '1'; }
     REQUIRE((M + h->lpa - 1) / h->lpa <= 64, "pmaf_create: too many obstacles for this lanes_per_agent (need M <= 64*lanes_per_agent)");
     h->n_blocks = (N * h->lpa + 63) / 64;
-    h->lds_rollout = sizeof(double) * 7 * n_obs + sizeof(int32_t) * n_obs;
+    {
+      // obstacle table + known flags, then (w64 kernels) the per-step list of
+      // circular-field terms: 64 * TILES entries of 4 doubles
+      size_t off = 7 * (size_t)n_obs + ((size_t)n_obs + 1) / 2;
+      off += off & 1;
+      h->lds_rollout = sizeof(double) * (off + 64 * 4 * 4);
+    }
     h->lds_manager = sizeof(double) * 7 * n_obs;
     REQUIRE(h->lds_rollout <= 160 * 1024, "pmaf_create: obstacle table does not fit in LDS");
 

@@ -1,0 +1,374 @@
+// cf_manager.h -- host-side mirror of the reference's planner surface:
+// ghostplanner::cfplanner::CfManager (B/include/bimanual_planning_ros/cf_manager.h:18-137,
+// B/ = reference src/bimanual_planning_ros/) re-created on top of the C-ABI of
+// libpmaf_hip.so (include/pmaf.h). Same class name, namespace, method names,
+// argument order, defaults and return types as the reference, so a caller
+// written against the reference (B/src/panda_bimanual_control.cpp:329-369,
+// 463-471, 501-518) compiles against this header unchanged.
+//
+// What differs, deliberately (see DESIGN.md "Deviations"):
+//  * startPrediction() launches the agent x horizon rollout kernel
+//    asynchronously on the GPU, stopPrediction() waits for it; rollouts always
+//    run to their guard instead of being cut by wall clock
+//    (B/src/cf_agent.cpp:310-311).
+//  * Random agents draw their vectors from a seeded generator
+//    (setRandomSeed) instead of std::random_device
+//    (B/src/helper_functions.cpp:7-13).
+//  * moveAgent / moveAgents / moveAgentsPar (no callers in the reference,
+//    B/src/cf_manager.cpp:265-291) throw std::logic_error.
+//  * errors of the device layer surface as std::runtime_error.
+//
+// Vector type: Eigen::Vector3d when PMAF_USE_EIGEN is defined (a ROS box),
+// otherwise the small ghostplanner::cfplanner::Vec3 below (same accessors).
+#pragma once
+
+#include <array>
+#include <cmath>
+#include <cstdint>
+#include <random>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "bimanual_planning_ros/obstacle.h"
+#include "pmaf.h"
+
+namespace ghostplanner {
+namespace cfplanner {
+
+// Eigen::Matrix<double, 6, 1> stand-in for des_ws_limits when Eigen is absent
+#ifdef PMAF_USE_EIGEN
+using Vector6d = Eigen::Matrix<double, 6, 1>;
+#else
+struct Vector6d {
+  std::array<double, 6> d{};
+  double &operator()(int i) { return d[i]; }
+  double operator()(int i) const { return d[i]; }
+};
+#endif
+
+class CfManager {
+  pmaf_planner *h_ = nullptr;
+  int n_agents_ = 0;
+  int n_obs_ = 0;
+  int cap_ = 0;
+  Vector3d init_pos_{0.0, 0.0, 0.0};
+  Vector3d goal_pos_{0.0, 0.0, 0.0};
+  std::vector<double> k_r_force_;
+  std::vector<double> random_vecs_;       // [N][n_obs][3] of the current population
+  // best_agent_ survives init() in the reference (cf_manager.h:20, cf_manager.cpp:41-124)
+  int best_id_ = 0, best_type_ = -1;
+  std::vector<double> best_rand_;         // [n_obs][3]
+  uint64_t seed_ = 0x9E3779B97F4A7C15ull;
+  int device_ = -1;
+
+  static void check(int rc, const char *what) {
+    if (rc != PMAF_OK) throw std::runtime_error(std::string(what) + ": " + pmaf_last_error());
+  }
+  static std::vector<double> flat(const std::vector<Obstacle> &obstacles) {
+    std::vector<double> o(obstacles.size() * 7);
+    for (size_t i = 0; i < obstacles.size(); ++i) {
+      const Vector3d p = obstacles[i].getPosition(), v = obstacles[i].getVelocity();
+      double *r = &o[i * 7];
+      r[0] = p.x(); r[1] = p.y(); r[2] = p.z(); r[3] = v.x(); r[4] = v.y(); r[5] = v.z();
+      r[6] = obstacles[i].getRadius();
+    }
+    return o;
+  }
+  void require() const {
+    if (!h_) throw std::logic_error("CfManager: init() has not been called");
+  }
+  void remember_best() {
+    if (!h_) return;
+    int32_t type = -1, id = 0;
+    if (pmaf_get_best(h_, &type, &id) == PMAF_OK && id > 0) {
+      best_id_ = id;
+      best_type_ = type;
+      best_rand_.assign(random_vecs_.begin() + (size_t)(id - 1) * n_obs_ * 3,
+                        random_vecs_.begin() + (size_t)id * n_obs_ * 3);
+    }
+  }
+
+ public:
+  CfManager() = default;
+  CfManager(const Vector3d agent_pos, const Vector3d goal_pos, const double delta_t,
+            const std::vector<Obstacle> &obstacles, const std::vector<double> &k_a_ee,
+            const std::vector<double> &k_c_ee, const std::vector<double> &k_r_ee,
+            const std::vector<double> &k_d_ee, const std::vector<double> &k_manip,
+            const std::vector<double> &k_r_force, const double velocity_max = 0.5,
+            const double approach_dist = 0.25, const double detect_shell_rad = 0.8,
+            const size_t max_prediction_steps = 1500, const size_t prediction_freq_multiple = 1,
+            const double agent_mass = 1.0, const double radius = 0.01) {
+    init_pos_ = agent_pos;
+    // the reference's constructor forwards only the first twelve arguments to
+    // init (cf_manager.cpp:38-39): the remaining ones take init's defaults
+    (void)max_prediction_steps; (void)prediction_freq_multiple; (void)agent_mass; (void)radius;
+    init(goal_pos, delta_t, obstacles, k_a_ee, k_c_ee, k_r_ee, k_d_ee, k_manip, k_r_force, velocity_max,
+         approach_dist, detect_shell_rad);
+  }
+  ~CfManager() { if (h_) pmaf_destroy(h_); }
+  CfManager(const CfManager &) = delete;
+  CfManager &operator=(const CfManager &) = delete;
+
+  // ---- build-specific knobs (no reference equivalent) ----
+  void setRandomSeed(uint64_t seed) { seed_ = seed; }
+  void setDevice(int device) { device_ = device; }
+  // explicit Random-agent vectors [N][n_obs][3] for the next init()
+  void setRandomVectors(const std::vector<double> &v) { random_vecs_override_ = v; }
+  pmaf_planner *handle() { return h_; }
+
+  // CfManager::init, B/src/cf_manager.cpp:41-124
+  void init(const Vector3d goal_pos, const double delta_t, const std::vector<Obstacle> &obstacles,
+            const std::vector<double> &k_a_ee, const std::vector<double> &k_c_ee,
+            const std::vector<double> &k_r_ee, const std::vector<double> &k_d_ee,
+            const std::vector<double> &k_manip, const std::vector<double> &k_r_force,
+            const double velocity_max = 0.5, const double approach_dist = 0.25,
+            const double detect_shell_rad = 0.8, const size_t max_prediction_steps = 1500,
+            const size_t prediction_freq_multiple = 1, const double agent_mass = 1.0,
+            const double radius = 0.05) {
+    if (!((k_a_ee.size() == k_c_ee.size()) && (k_c_ee.size() == k_r_ee.size()) &&
+          (k_c_ee.size() == k_manip.size()) && (k_d_ee.size() == k_a_ee.size())))
+      throw std::invalid_argument("CfManager::init: gain vectors must have equal sizes");  // assert, :50
+    remember_best();
+    if (h_) { pmaf_destroy(h_); h_ = nullptr; }
+    goal_pos_ = goal_pos;
+    k_r_force_ = k_r_force;
+    n_agents_ = (int)k_a_ee.size();
+    n_obs_ = (int)obstacles.size();
+    cap_ = (int)max_prediction_steps;
+    // RandomCfAgent ctor (cf_agent.h:338-342): n_obs normalised U(-1,1)^3 vectors per agent
+    if (random_vecs_override_.size() == (size_t)n_agents_ * n_obs_ * 3) {
+      random_vecs_ = random_vecs_override_;
+    } else {
+      random_vecs_.assign((size_t)n_agents_ * n_obs_ * 3, 0.0);
+      std::mt19937_64 gen(seed_);
+      std::uniform_real_distribution<double> dis(-1.0, 1.0);
+      for (size_t k = 0; k < (size_t)n_agents_ * n_obs_; ++k) {
+        double x = dis(gen), y = dis(gen), z = dis(gen);
+        double zz = (x * x + y * y) + z * z;
+        if (zz > 0) { double s = std::sqrt(zz); x = x / s; y = y / s; z = z / s; }
+        random_vecs_[k * 3] = x; random_vecs_[k * 3 + 1] = y; random_vecs_[k * 3 + 2] = z;
+      }
+      seed_ = gen();  // a later init() draws fresh vectors, like the reference
+    }
+    const std::vector<double> obs = flat(obstacles);
+    const double goal[3] = {goal_pos.x(), goal_pos.y(), goal_pos.z()};
+    const double ip[3] = {init_pos_.x(), init_pos_.y(), init_pos_.z()};
+    pmaf_params prm{};
+    prm.abi_version = PMAF_ABI_VERSION;
+    prm.n_populations = 1;
+    prm.n_agents = n_agents_;
+    prm.n_obstacles = n_obs_;
+    prm.max_prediction_steps = cap_;
+    prm.device = device_;
+    prm.lanes_per_agent = 0;
+    prm.dt = (double)prediction_freq_multiple * delta_t;
+    prm.velocity_max = velocity_max;
+    prm.approach_dist = approach_dist;
+    prm.detect_shell_rad = detect_shell_rad;
+    prm.agent_mass = agent_mass;
+    prm.radius = radius;
+    prm.goal = goal;
+    prm.init_pos = ip;
+    prm.obstacles = obs.data();
+    prm.k_attr = k_a_ee.data();
+    prm.k_circ = k_c_ee.data();
+    prm.k_repel = k_r_ee.data();
+    prm.k_damp = k_d_ee.data();
+    prm.agent_types = nullptr;  // Had, Goal, Obstacle, GoalObstacle, Vel, Random..., :70-104
+    prm.random_vecs = random_vecs_.data();
+    check(pmaf_create(&prm, &h_), "CfManager::init");
+    if (best_id_ > 0 && best_id_ <= n_agents_ && best_rand_.size() == (size_t)n_obs_ * 3) {
+      const int32_t id = best_id_, type = best_type_;
+      check(pmaf_set_best(h_, &id, &type, best_rand_.data()), "CfManager::init(best)");
+    }
+  }
+
+  void startPrediction() { require(); check(pmaf_start(h_), "startPrediction"); }   // cf_manager.h:57-61
+  void stopPrediction() { require(); check(pmaf_stop(h_), "stopPrediction"); }      // cf_manager.cpp:126-140
+  void shutdownAllAgents() {}                                                       // no threads to stop
+  void joinPredictionThreads() { if (h_) check(pmaf_stop(h_), "joinPredictionThreads"); }
+
+  std::vector<std::vector<Vector3d>> getPredictedPaths() {                          // cf_manager.cpp:184-190
+    require();
+    std::vector<double> p((size_t)n_agents_ * cap_ * 3);
+    std::vector<int32_t> n(n_agents_);
+    check(pmaf_get_paths(h_, p.data(), n.data()), "getPredictedPaths");
+    std::vector<std::vector<Vector3d>> out(n_agents_);
+    for (int a = 0; a < n_agents_; ++a) {
+      out[a].reserve(n[a]);
+      for (int k = 0; k < n[a]; ++k) {
+        const double *q = &p[((size_t)a * cap_ + k) * 3];
+        out[a].push_back(Vector3d(q[0], q[1], q[2]));
+      }
+    }
+    return out;
+  }
+  std::vector<double> getPredictedPathLengths() {                                   // :192-198
+    require();
+    std::vector<double> out(n_agents_);
+    check(pmaf_get_path_lengths(h_, out.data()), "getPredictedPathLengths");
+    return out;
+  }
+  std::vector<double> getPredictionTimes() {                                        // :200-206
+    require();
+    std::vector<double> out(n_agents_, 0.0);
+    pmaf_set_profiling(h_, 1);
+    if (pmaf_get_prediction_times_ns(h_, out.data()) != PMAF_OK) out.assign(n_agents_, 0.0);
+    return out;
+  }
+  std::vector<bool> getAgentSuccess() {                                             // :208-214
+    require();
+    std::vector<int32_t> s(n_agents_);
+    check(pmaf_get_success(h_, s.data()), "getAgentSuccess");
+    return std::vector<bool>(s.begin(), s.end());
+  }
+  int getBestAgentType() {                                                          // cf_manager.h:73
+    require();
+    int32_t type = -1, id = 0;
+    check(pmaf_get_best(h_, &type, &id), "getBestAgentType");
+    if (id == 0) throw std::logic_error("getBestAgentType: no best agent yet");
+    return type;
+  }
+  Vector3d getNextPosition() {                                                      // :74-76
+    require();
+    double p[3];
+    check(pmaf_get_real_state(h_, p, nullptr, nullptr), "getNextPosition");
+    return Vector3d(p[0], p[1], p[2]);
+  }
+  Vector3d getInitialPosition() { return init_pos_; }                               // :77
+  Vector3d getNextVelocity() {                                                      // :78
+    require();
+    double v[3];
+    check(pmaf_get_real_state(h_, nullptr, v, nullptr), "getNextVelocity");
+    return Vector3d(v[0], v[1], v[2]);
+  }
+  Vector3d getEEForce() {                                                           // :79
+    require();
+    double f[3];
+    check(pmaf_get_real_state(h_, nullptr, nullptr, f), "getEEForce");
+    return Vector3d(f[0], f[1], f[2]);
+  }
+  Vector3d getGoalPosition() const { return goal_pos_; }                            // :80
+  int getNumPredictionSteps(int agent_id) {                                         // :81-83
+    require();
+    std::vector<int32_t> n(n_agents_);
+    check(pmaf_get_paths(h_, nullptr, n.data()), "getNumPredictionSteps");
+    return n.at(agent_id);
+  }
+  int getRealNumPredictionSteps() {                                                 // :84-86
+    require();
+    int32_t n = 0;
+    check(pmaf_get_real_path(h_, 0, nullptr, 0, &n), "getRealNumPredictionSteps");
+    return n;
+  }
+  double getDistFromGoal() const {                                                  // :87-89
+    if (!h_) throw std::logic_error("CfManager: init() has not been called");
+    double d = 0.0;
+    check(pmaf_get_dist_from_goal(h_, &d), "getDistFromGoal");
+    return d;
+  }
+  std::vector<Vector3d> getPlannedTrajectory() const {                              // :90-92
+    if (!h_) throw std::logic_error("CfManager: init() has not been called");
+    int32_t n = 0;
+    check(pmaf_get_real_path(h_, 0, nullptr, 0, &n), "getPlannedTrajectory");
+    std::vector<double> p((size_t)n * 3);
+    check(pmaf_get_real_path(h_, 0, p.data(), n, nullptr), "getPlannedTrajectory");
+    std::vector<Vector3d> out;
+    out.reserve(n);
+    for (int k = 0; k < n; ++k) out.push_back(Vector3d(p[k * 3], p[k * 3 + 1], p[k * 3 + 2]));
+    return out;
+  }
+  // CfManager::getLinkForce, B/src/cf_manager.cpp:169-182
+  std::vector<Vector3d> getLinkForce(const std::vector<Vector3d> &link_positions,
+                                     const std::vector<Obstacle> &obstacles) {
+    require();
+    if (k_r_force_.size() != link_positions.size())
+      throw std::invalid_argument("getLinkForce: one link position per k_r_force entry");  // assert, :172
+    std::vector<double> lp(link_positions.size() * 3), out(link_positions.size() * 3);
+    for (size_t i = 0; i < link_positions.size(); ++i) {
+      lp[i * 3] = link_positions[i].x(); lp[i * 3 + 1] = link_positions[i].y(); lp[i * 3 + 2] = link_positions[i].z();
+    }
+    const std::vector<double> obs = flat(obstacles);
+    check(pmaf_link_force(h_, 0, (int32_t)link_positions.size(), lp.data(), k_r_force_.data(), obs.data(), out.data()),
+          "getLinkForce");
+    std::vector<Vector3d> forces;
+    for (size_t i = 0; i < link_positions.size(); ++i)
+      forces.push_back(Vector3d(out[i * 3], out[i * 3 + 1], out[i * 3 + 2]));
+    return forces;
+  }
+
+  void setRealEEAgentPosition(const Vector3d &position) {                           // :216-218
+    require();
+    const double p[3] = {position.x(), position.y(), position.z()};
+    check(pmaf_set_real_position(h_, p), "setRealEEAgentPosition");
+  }
+  void setInitialPosition(const Vector3d &position) {                               // :226-229
+    init_pos_ = position;
+    setInitialEEPositions(position);
+  }
+  void setInitialEEPositions(const Vector3d &position) {                            // :231-236
+    if (!h_) return;  // default-constructed manager: no agents yet (empty loops in the reference)
+    const double p[3] = {position.x(), position.y(), position.z()};
+    check(pmaf_set_initial_position(h_, p), "setInitialPosition");
+  }
+  // CfManager::resetEEAgents, :246-255
+  void resetEEAgents(const Vector3d &position, const Vector3d &velocity, const std::vector<Obstacle> &obstacles) {
+    require();
+    const double p[3] = {position.x(), position.y(), position.z()};
+    const double v[3] = {velocity.x(), velocity.y(), velocity.z()};
+    const std::vector<double> obs = flat(obstacles);
+    if ((int)obstacles.size() != n_obs_) throw std::out_of_range("resetEEAgents: obstacle count changed");  // .at(), cf_agent.cpp:66
+    check(pmaf_reset_agents(h_, p, v, obs.data()), "resetEEAgents");
+  }
+  // CfManager::moveRealEEAgent, :257-263
+  void moveRealEEAgent(const std::vector<Obstacle> &obstacles, const double delta_t, const int steps,
+                       const int agent_id) {
+    require();
+    const std::vector<double> obs = flat(obstacles);
+    if ((int)obstacles.size() != n_obs_) throw std::out_of_range("moveRealEEAgent: obstacle count changed");
+    const int32_t id = agent_id;
+    check(pmaf_move_real(h_, obs.data(), delta_t, steps, &id), "moveRealEEAgent");
+  }
+  // CfManager::evaluateAgents, :293-356 (its obstacles argument is unused there too)
+  int evaluateAgents(const std::vector<Obstacle> &obstacles, const double k_goal_dist, const double k_path_len,
+                     const double k_safe_dist, const double k_workspace, const Vector6d des_ws_limits) {
+    (void)obstacles;
+    require();
+    const double gains[4] = {k_goal_dist, k_path_len, k_safe_dist, k_workspace};
+    double ws[6];
+    for (int i = 0; i < 6; ++i) ws[i] = des_ws_limits(i);
+    int32_t best = 0;
+    check(pmaf_evaluate(h_, gains, ws, &best), "evaluateAgents");
+    return best;
+  }
+  // the whole planCallback sequence (B/src/panda_bimanual_control.cpp:336-352)
+  // as one call: stop, evaluate, move the real agent one step, reset, start
+  int planTick(const std::vector<Obstacle> &obstacles, const double delta_t, const double k_goal_dist,
+               const double k_path_len, const double k_safe_dist, const double k_workspace,
+               const Vector6d des_ws_limits, Vector3d *next_position = nullptr) {
+    require();
+    const std::vector<double> obs = flat(obstacles);
+    const double gains[4] = {k_goal_dist, k_path_len, k_safe_dist, k_workspace};
+    double ws[6];
+    for (int i = 0; i < 6; ++i) ws[i] = des_ws_limits(i);
+    int32_t best = 0;
+    double np[3];
+    check(pmaf_tick(h_, obs.data(), delta_t, gains, ws, &best, np, nullptr), "planTick");
+    if (next_position) *next_position = Vector3d(np[0], np[1], np[2]);
+    return best;
+  }
+
+  // no callers in the reference (B/src/cf_manager.cpp:220-224, 238-244, 265-291); not on the accelerated path
+  void setEEAgentPositions(const Vector3d &) { throw std::logic_error("setEEAgentPositions: not supported"); }
+  void setEEAgentPosAndVels(const Vector3d &, const Vector3d &) { throw std::logic_error("setEEAgentPosAndVels: not supported"); }
+  void moveAgent(const std::vector<Obstacle> &, const double, const int, const int) { throw std::logic_error("moveAgent: not supported"); }
+  void moveAgents(const std::vector<Obstacle> &, const double, const int = 1) { throw std::logic_error("moveAgents: not supported"); }
+  void moveAgentsPar(const std::vector<Obstacle> &, const double, const int = 1) { throw std::logic_error("moveAgentsPar: not supported"); }
+
+ private:
+  std::vector<double> random_vecs_override_;
+};
+
+}  // namespace cfplanner
+}  // namespace ghostplanner

@@ -12,5 +12,5 @@ Contents: csrc/ (HIP kernels + C-ABI, built into lib/libpmaf_hip.so),
 planner.py (ctypes binding of include/pmaf.h), scenes.py (task scenes and the
 seeded synthetic scenes), shard.py (population sharding across ranks).
 """
-from . import scenes  # noqa: F401
+from . import scenes, shard  # noqa: F401
 from .planner import LIB_PATH, SYMBOLS, PmafError, PmafPlanner, debug_math, load_library  # noqa: F401

@@ -88,6 +88,14 @@ enum : int { T_REAL = 0, T_GOAL = 1, T_OBST = 2, T_GOALOBST = 3, T_VEL = 4, T_RA
 // population-wide scalars (CfManager::init arguments)
 struct PopConst {
   double dt, vel_max, approach, shell, mass, rad;
+  // exact squared thresholds (computed on the host, pmaf_hip.hip:sq_gt/sq_ge):
+  // for every z >= 0   sqrt(z) > 1e-5  <=>  z >= zf_gt
+  //                    sqrt(z) > 13.0  <=>  z >= zacc_gt
+  //                    sqrt(z) < 0.2   <=>  z <  zinit_lt
+  // (sqrt is monotonic and correctly rounded, so each predicate has one
+  // boundary double); they let the w64 kernel skip square roots whose value
+  // is only compared, never used.
+  double zf_gt, zacc_gt, zinit_lt;
 };
 
 // LDS-resident obstacle table, structure of arrays, n_obs entries each
@@ -179,7 +187,8 @@ template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ int dpp_i(int v) {
   return __builtin_amdgcn_update_dpp(v, v, CTRL, ROW_MASK, 0xf, false);
 }
-__device__ __forceinline__ double sel_min(double a, double b) { return (b < a) ? b : a; }
+// inputs are never NaN here (distances >= 1e-5), so v_min_f64 == select-min
+__device__ __forceinline__ double sel_min(double a, double b) { return __builtin_fmin(a, b); }
 
 // minimum over the 64 lanes, returned wave-uniform. Inputs must not be NaN.
 __device__ __forceinline__ double wave_min64(double v) {

@@ -242,7 +242,7 @@ __device__ __forceinline__ void rollout_w64_body(const DevView &D, const CostPar
   clist_off += clist_off & 1;
   double *clist = smem + clist_off;
 
-  double min_obs = C.shell;
+  double lane_min = C.shell;  // per-lane running min_obs_dist_, reduced once after the loop
   double cost_ws = 0.0;
   double path_len = 0.0;
   int n = 1;
@@ -256,24 +256,24 @@ __device__ __forceinline__ void rollout_w64_body(const DevView &D, const CostPar
   V3 g = goal - p;
   double dg = norm(g);
   double nrm_v = norm(v);
-  double d_init = norm(p - init_pos);
+  double z_init = sqn(p - init_pos);
   while ((dg > 0.1) && (n < D.cap)) {  // wave-uniform guard, B/src/cf_agent.cpp:310-311
     // gate, :315-317
-    const bool gate = !(dg < C.approach || (nrm_v < 0.5 * C.vel_max && d_init < 0.2));
+    const bool gate = !(dg < C.approach || (nrm_v < 0.5 * C.vel_max && z_init < C.zinit_lt));  // |p - init| < 0.2
     V3 F = mk(0.0, 0.0, 0.0);
     double scale = 1.0;
     if (gate)
       circ_and_scale_w64<TILES, TYPE>(lane, p, v, nrm_v, goal, g, dg, C, k_circ, T, n_obs, rot_g, known_bits, O,
-                                      clist, min_obs, F, scale);
+                                      clist, lane_min, F, scale);
     V3 new_pos;
-    finish_step(p, v, g, F, scale, C, k_attr, k_repel, k_damp, C.dt, sent_p, sent_r, new_pos);
+    finish_step_w64(p, v, g, F, scale, C, k_attr, k_repel, k_damp, sent_p, sent_r, new_pos);
     const V3 dp = new_pos - p;
     p = new_pos;
     g = goal - p;
     const double seg = norm(dp);
     dg = norm(g);
     nrm_v = norm(v);
-    d_init = norm(p - init_pos);
+    z_init = sqn(p - init_pos);
     path_len += seg;
     ws_cost_add(cost_ws, p, CP.ws, CP.k_workspace);
     if (lane == 0) { path[n * 3] = p.x; path[n * 3 + 1] = p.y; path[n * 3 + 2] = p.z; }
@@ -290,6 +290,7 @@ __device__ __forceinline__ void rollout_w64_body(const DevView &D, const CostPar
     if (need_table) wave_lds_fence();
   }
 
+  const double min_obs = wave_min64(lane_min);
   int32_t *ko = D.known_out + pa * n_obs;
 #pragma unroll
   for (int t = 0; t < TILES; t++) {
@@ -642,6 +643,23 @@ static void aos_to_soa(const double *aos, double *soa, int P, int n_obs) {
       for (int c = 0; c < 7; c++) soa[((size_t)p * 7 + c) * n_obs + i] = aos[((size_t)p * n_obs + i) * 7 + c];
 }
 
+// smallest z >= 0 with sqrt(z) > c, i.e. (sqrt(z) > c) == (z >= sq_gt(c)) for all z >= 0.
+// std::sqrt is correctly rounded on the host and bit-identical to the device's
+// (tests/test_parity_gpu.py::test_device_arithmetic_is_ieee_exact).
+static double sq_gt(double c) {
+  double z = c * c;
+  while (z > 0.0 && std::sqrt(z) > c) z = std::nextafter(z, 0.0);
+  while (!(std::sqrt(z) > c)) z = std::nextafter(z, INFINITY);
+  return z;
+}
+// smallest z >= 0 with sqrt(z) >= c, i.e. (sqrt(z) < c) == (z < sq_ge(c))
+static double sq_ge(double c) {
+  double z = c * c;
+  while (z > 0.0 && std::sqrt(z) >= c) z = std::nextafter(z, 0.0);
+  while (!(std::sqrt(z) >= c)) z = std::nextafter(z, INFINITY);
+  return z;
+}
+
 static int pick_lpa(int N, int P, int M) {
   // Heuristic: fill the 1024 SIMDs of the chip with waves, but never use more
   // lanes per agent than there are field obstacles to share.
@@ -816,6 +834,7 @@ int pmaf_create(const pmaf_params *prm, pmaf_planner **out) {
     D.P = P; D.N = N; D.n_obs = n_obs; D.cap = cap;
     D.C.dt = prm->dt; D.C.vel_max = prm->velocity_max; D.C.approach = prm->approach_dist;
     D.C.shell = prm->detect_shell_rad; D.C.mass = prm->agent_mass; D.C.rad = prm->radius;
+    D.C.zf_gt = sq_gt(1e-5); D.C.zacc_gt = sq_gt(13.0); D.C.zinit_lt = sq_ge(0.2);
     h->lpa = lp ? lp : pick_lpa(N, P, M);
     { const char *fg = getenv("PMAF_FORCE_GENERIC"); h->force_generic = fg && fg[0] == '1'; }
     REQUIRE((M + h->lpa - 1) / h->lpa <= 64, "pmaf_create: too many obstacles for this lanes_per_agent (need M <= 64*lanes_per_agent)");

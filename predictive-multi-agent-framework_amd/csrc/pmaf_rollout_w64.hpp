@@ -31,6 +31,45 @@
 
 namespace pmaf {
 
+// finish_step (pmaf_device.hpp) for the w64 kernel: same arithmetic; the
+// acceleration clamp is decided on the squared norm (exact threshold) so the
+// square root is only taken in the rare clamped case.
+__device__ __forceinline__ void finish_step_w64(V3 p, V3 &v, V3 goal_vec, V3 F, double scale, const PopConst &C,
+                                                double k_attr, double k_repel, double k_damp, V3 sent_pos,
+                                                double sent_rad, V3 &new_pos) {
+  {
+    V3 ro = sent_pos - p;
+    V3 dist_vec = -ro;
+    double d = norm(dist_vec) - (C.rad + sent_rad);
+    d = smax(d, 1e-5);
+    V3 repel = mk(0.0, 0.0, 0.0);
+    if (d < C.shell) {
+      V3 otr = normalized(p - sent_pos);
+      double t = 1.0 / d - 1.0 / C.shell;
+      double dd = d * d;
+      repel = ((k_repel * otr) * t) / dd;
+    }
+    V3 total = mk(0.0, 0.0, 0.0) + repel;
+    F = F + total;
+  }
+  if (k_attr != 0.0) {
+    V3 vel_des = (k_attr / k_damp) * goal_vec;
+    double scale_lim = smin(1.0, C.vel_max / norm(vel_des));
+    vel_des = vel_des * scale_lim;
+    F = F + (scale * k_damp) * (vel_des - v);
+  }
+  V3 acc = F;
+  if (C.mass != 1.0) acc = F / C.mass;
+  const double az = sqn(acc);
+  if (az >= C.zacc_gt) acc = acc * (13.0 / __builtin_sqrt(az));  // norm(acc) > 13.0
+  V3 half = ((0.5 * acc) * C.dt) * C.dt;
+  new_pos = (p + half) + (v * C.dt);
+  V3 nv = v + acc * C.dt;
+  double vn = norm(nv);
+  if (vn > C.vel_max) nv = nv * (C.vel_max / vn);
+  v = nv;
+}
+
 // wave-level ordering of LDS accesses: DS instructions of one wave execute in
 // order, so only the compiler has to be kept from reordering them.
 __device__ __forceinline__ void wave_lds_fence() {
@@ -59,13 +98,13 @@ template <int TILES, int TYPE>
 __device__ __forceinline__ void circ_and_scale_w64(int lane, V3 p, V3 v, double nrm_v, V3 goal, V3 g, double dg,
                                                    const PopConst &C, double k_circ, const ObsTab &T,
                                                    int n_obs, double *rot_g, unsigned &known_bits,
-                                                   LaneObstacles<TILES> &O, double *clist, double &min_obs,
+                                                   LaneObstacles<TILES> &O, double *clist, double &lane_min,
                                                    V3 &F, double &scale) {
   const int M = n_obs - 1;
   // goal_vec.normalized(): dg == sqrt(squaredNorm(g)), the value normalized() divides by
   const V3 gn = (dg > 0.0) ? (g / dg) : g;
-  double lane_min = min_obs;
   double best_d = C.shell;
+  double best_s = 0.0, best_gr = 0.0;  // |ro| and g.ro of the lane's closest obstacle
   int best_i = 0x7fffffff;
   int count = 0;
 #pragma unroll
@@ -81,7 +120,7 @@ __device__ __forceinline__ void circ_and_scale_w64(int lane, V3 p, V3 v, double 
     const bool skip = (dot(ron, gn) < -0.01) && (dot(ro, rv) < -0.01);
     double d = s - (C.rad + O.r[t]);
     d = smax(d, 1e-5);
-    if (valid && d < best_d) { best_d = d; best_i = i; }
+    if (valid && d < best_d) { best_d = d; best_i = i; best_s = s; best_gr = dot(g, ro); }
     const bool live = valid && !skip;
     if (live && d < lane_min) lane_min = d;
     const bool in_shell = live && (d < C.shell);
@@ -113,10 +152,9 @@ __device__ __forceinline__ void circ_and_scale_w64(int lane, V3 p, V3 v, double 
       count += __popcll(m);
     }
   }
-  // interleaved DPP reductions
-  const double mo = wave_min64(lane_min);
+  // closest obstacle of the sweep (attractorForceScaling :201-211); the
+  // min_obs_dist_ minimum stays per lane and is reduced once after the rollout
   const double m = wave_min64(best_d);
-  min_obs = mo;
   if (count > 0) {
     wave_lds_fence();
     // F = ((0 + c_0) + c_1) + ... front to back; every lane reads the same
@@ -134,7 +172,7 @@ __device__ __forceinline__ void circ_and_scale_w64(int lane, V3 p, V3 v, double 
     wave_lds_fence();
   }
   // attractorForceScaling (only if |F| > 1e-5, :319)
-  if (norm(F) > 1e-5) {
+  if (sqn(F) >= C.zf_gt) {  // norm(F) > 1e-5
     const bool cand = (best_i != 0x7fffffff) && (best_d == m);
     int bi;
     if (TILES == 1) {  // obstacle index == lane: lowest candidate lane wins
@@ -149,13 +187,11 @@ __device__ __forceinline__ void circ_and_scale_w64(int lane, V3 p, V3 v, double 
       scale = 0.0;
     } else {
       const double w1 = 1 - portable_exp(-__builtin_sqrt(m) / C.shell);
-      const int bl = bi & 63, bt = bi >> 6;
-      V3 bp = mk(0.0, 0.0, 0.0);
-#pragma unroll
-      for (int t = 0; t < TILES; t++)
-        if (t == bt) bp = mk(readlane_d(O.p[t].x, bl), readlane_d(O.p[t].y, bl), readlane_d(O.p[t].z, bl));
-      const V3 ro = bp - p;
-      double w2 = 1 - (dot(g, ro) / (dg * norm(ro)));
+      // |ro| and g.ro of the closest obstacle were computed by the lane that
+      // owns it (same operands, same bits as recomputing them here)
+      const int bl = bi & 63;
+      const double sb = readlane_d(best_s, bl), gr = readlane_d(best_gr, bl);
+      double w2 = 1 - (gr / (dg * sb));
       w2 = w2 * w2;
       scale = w1 * w2;
     }

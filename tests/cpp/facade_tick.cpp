@@ -1,0 +1,65 @@
+// facade_tick.cpp -- drives the C++ facade (include/bimanual_planning_ros/
+// cf_manager.h) exactly like the reference's planner node does
+// (B/src/panda_bimanual_control.cpp:463-471, 501-510, 329-369) on the static1
+// task scene and prints, per tick, best index / type and the next set-point.
+// tests/test_facade.py compares the output with the oracle.
+//   usage: facade_tick <n_agents> <max_prediction_steps> <n_ticks> <random_vecs.bin>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "bimanual_planning_ros/cf_manager.h"
+
+using namespace ghostplanner::cfplanner;
+
+int main(int argc, char **argv) {
+  if (argc < 5) return 2;
+  const int N = atoi(argv[1]), cap = atoi(argv[2]), ticks = atoi(argv[3]);
+  // static1 scene: 9 spheres + repulsive sentinel (values as in pmaf scenes.static1_obstacles)
+  std::vector<Obstacle> obstacles;
+  const double xs[3] = {0.125, 0.125, -0.35}, zs[3] = {1.0, 0.7, 0.6}, ys[3] = {0.0, 0.125, -0.125};
+  for (int g = 0; g < 3; ++g)
+    for (int k = 0; k < 3; ++k) obstacles.push_back(Obstacle(Vector3d(xs[g], ys[k], zs[g]), Vector3d(0, 0, 0), 0.1));
+  obstacles.push_back(Obstacle(Vector3d(100.0, 100.0, 100.0), Vector3d(0, 0, 0), 0.1));
+  std::vector<double> rv((size_t)N * obstacles.size() * 3);
+  FILE *f = fopen(argv[4], "rb");
+  if (!f || fread(rv.data(), sizeof(double), rv.size(), f) != rv.size()) return 3;
+  fclose(f);
+
+  const Vector3d start(-0.6, 0.0, 0.75), goal(0.5, 0.0, 0.7);
+  const double dt = 0.01;
+  Vector6d ws;
+  const double wsv[6] = {1.0, -1.0, 0.3, -0.3, 1.1, 0.2};
+  for (int i = 0; i < 6; ++i) ws(i) = wsv[i];
+
+  CfManager cf_manager_;
+  cf_manager_.setInitialPosition(start);  // planCallback while planning is not active
+  cf_manager_.setRandomVectors(rv);
+  auto do_init = [&] {
+    cf_manager_.init(goal, dt, obstacles, std::vector<double>(N, 4.0), std::vector<double>(N, 0.025),
+                     std::vector<double>(N, 0.08), std::vector<double>(N, 3.0), std::vector<double>(N, 0.0),
+                     std::vector<double>(1, 0.02), 0.2, 0.25, 0.35, cap, 1);
+  };
+  do_init();                               // node start-up, :463-471
+  Vector3d current_pos = start;
+  do_init();                               // taskCallback PLAN, :501-509
+  cf_manager_.setInitialPosition(current_pos);
+  for (int t = 0; t < ticks; ++t) {        // planCallback, :336-352
+    cf_manager_.stopPrediction();
+    int best = cf_manager_.evaluateAgents(obstacles, 100.0, 10.0, 0.001, 1.0, ws);
+    cf_manager_.moveRealEEAgent(obstacles, dt, 1, best);
+    cf_manager_.resetEEAgents(cf_manager_.getNextPosition(), cf_manager_.getNextVelocity(), obstacles);
+    cf_manager_.startPrediction();
+    Vector3d np = cf_manager_.getNextPosition();
+    printf("%d %d %d %.17g %.17g %.17g %.17g\n", t, best, cf_manager_.getBestAgentType(), np.x(), np.y(), np.z(),
+           cf_manager_.getDistFromGoal());
+  }
+  cf_manager_.stopPrediction();
+  auto paths = cf_manager_.getPredictedPaths();
+  auto lens = cf_manager_.getPredictedPathLengths();
+  for (size_t a = 0; a < paths.size(); ++a)
+    printf("P %zu %zu %.17g %.17g %.17g %.17g\n", a, paths[a].size(), paths[a].back().x(), paths[a].back().y(),
+           paths[a].back().z(), lens[a]);
+  printf("T %zu\n", cf_manager_.getPlannedTrajectory().size());
+  return 0;
+}

@@ -1,0 +1,70 @@
+"""The C-ABI shared library: loads, exports every symbol include/pmaf.h
+declares, validates arguments, and fails loudly (no CPU fallback) when no HIP
+device is present. No compute calls here."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import conftest
+
+
+def _declared_symbols():
+    hdr = open(os.path.join(conftest.ROOT, "include", "pmaf.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(pmaf_[a-z0-9_]+)\s*\(", hdr)))
+
+
+def test_every_declared_symbol_is_exported_and_bound(pmaf, hip_lib):
+    declared = _declared_symbols()
+    assert len(declared) >= 30
+    raw = C.CDLL(pmaf.LIB_PATH)
+    for name in declared:
+        assert hasattr(raw, name), "libpmaf_hip.so does not export %s" % name
+    assert sorted(pmaf.SYMBOLS) == declared, "planner.py binding table out of sync with include/pmaf.h"
+    assert hip_lib.pmaf_abi_version() == 1
+
+
+def test_params_struct_matches_header(pmaf):
+    # 8 int32 + 6 doubles + 9 pointers, naturally aligned
+    assert C.sizeof(pmaf.planner.PmafParams) == 8 * 4 + 6 * 8 + 9 * 8
+
+
+def test_argument_validation_messages(pmaf, hip_lib, scenes):
+    h = C.c_void_p()
+    rc = hip_lib.pmaf_create(None, C.byref(h))
+    assert rc == -1 and b"NULL" in hip_lib.pmaf_last_error()
+    prm = pmaf.planner.PmafParams()
+    prm.abi_version = 99
+    assert hip_lib.pmaf_create(C.byref(prm), C.byref(h)) == -1
+    assert b"ABI version" in hip_lib.pmaf_last_error()
+    prm.abi_version = 1
+    prm.n_populations, prm.n_agents, prm.n_obstacles, prm.max_prediction_steps = 1, 4, 0, 10
+    assert hip_lib.pmaf_create(C.byref(prm), C.byref(h)) == -1
+    assert b"obstacle" in hip_lib.pmaf_last_error()  # empty obstacle list (reference underflows)
+    assert hip_lib.pmaf_destroy(None) == 0
+    assert hip_lib.pmaf_start(None) == -1
+
+
+@pytest.mark.skipif(conftest.has_gpu(), reason="checks the no-GPU failure mode")
+def test_no_device_fails_loudly_without_cpu_fallback(pmaf, scenes):
+    sc = scenes.config_scene("C1")
+    with pytest.raises(pmaf.PmafError) as e:
+        pmaf.PmafPlanner(sc)
+    assert e.value.code == -2 and "no CPU fallback" in str(e.value)
+
+
+def test_product_sources_do_not_reference_the_oracle():
+    """only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline may touch oracle/"""
+    pkg = os.path.join(conftest.ROOT, "predictive-multi-agent-framework_amd")
+    inc = os.path.join(conftest.ROOT, "include")
+    for base in (pkg, inc):
+        for dp, _, files in os.walk(base):
+            for f in files:
+                if f.endswith((".py", ".hpp", ".h", ".hip", ".cpp", ".sh")):
+                    txt = open(os.path.join(dp, f), errors="ignore").read()
+                    for line in txt.splitlines():
+                        if re.search(r"^\s*(from|import)\s+oracle|#include\s+\"[^\"]*oracle|libpmaf_oracle|orc_[a-z_]+\(", line):
+                            raise AssertionError("%s references the oracle: %s" % (f, line.strip()))

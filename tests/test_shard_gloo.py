@@ -1,0 +1,118 @@
+"""world_size-2 gloo test of the multi-GPU path (population sharding + winner
+record all-gather + agent-range merge rule). Runs on CPU: the rank-local
+planner is the oracle (test-only compute stand-in); what is under test is the
+sharding / collective logic of predictive-multi-agent-framework_amd/shard.py."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n_scenes, ticks, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    import torch.distributed as dist
+    import __graft_entry__ as graft
+    from oracle import orc
+    pkg = graft.load_package()
+    shard = __import__("pmaf_amd.shard", fromlist=["shard"])
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    mine = shard.partition_populations(n_scenes, world, rank)
+    scs = [pkg.scenes.synthetic_scene(12, 60, 8, 8, s) for s in mine]
+    planners = []
+    for sc in scs:
+        o = orc.OraclePlanner(sc, mgr_init_pos=sc["start"])
+        o.set_initial_position(sc["start"])
+        planners.append(o)
+    cap = scs[0]["max_prediction_steps"]
+    gathered = None
+    for t in range(ticks):
+        recs = []
+        for sc, o in zip(scs, planners):
+            b = o.tick(sc["obstacles"], sc["dt"], sc["cost_gains"], sc["ws_limits"])
+            o.evaluate(sc["cost_gains"], sc["ws_limits"])  # costs of the fresh rollout
+            paths, n = o.paths()
+            bb = o.best_id() - 1
+            recs.append(shard.pack_winner_record(o.costs()[bb], bb, n[bb], o.best_type(), paths[bb], cap))
+        local = torch.from_numpy(np.stack(recs))
+        gathered = shard.all_gather_winner_records(local, dist, world)
+    q.put((rank, gathered.numpy().copy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_population_sharding_and_winner_all_gather_world2():
+    import torch.multiprocessing as mp
+    world, n_scenes, ticks = 2, 4, 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_scenes, ticks, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    # every rank ends with the same gathered table
+    np.testing.assert_array_equal(results[0], results[1])
+    # single-process reference of the same 4 populations
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as graft
+    from oracle import orc
+    pkg = graft.load_package()
+    shard = pkg.shard if hasattr(pkg, "shard") else __import__("pmaf_amd.shard", fromlist=["shard"])
+    cap = 61
+    for s in range(n_scenes):
+        sc = pkg.scenes.synthetic_scene(12, 60, 8, 8, s)
+        o = orc.OraclePlanner(sc, mgr_init_pos=sc["start"])
+        o.set_initial_position(sc["start"])
+        for t in range(ticks):
+            o.tick(sc["obstacles"], sc["dt"], sc["cost_gains"], sc["ws_limits"])
+        o.evaluate(sc["cost_gains"], sc["ws_limits"])
+        paths, n = o.paths()
+        bb = o.best_id() - 1
+        rec = shard.unpack_winner_records(results[0][s % world, s // world], cap)[0]
+        assert rec["index"] == bb and rec["n_points"] == n[bb] and rec["type"] == o.best_type()
+        np.testing.assert_array_equal(rec["path"], paths[bb, :n[bb]])
+        assert rec["cost"] == o.costs()[bb]
+
+
+def test_agent_range_merge_equals_single_population_selection(oracle, scenes):
+    """splitting one population's cost vector over ranks and merging must give
+    evaluateAgents' answer, including first-min ties and hysteresis"""
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as graft
+    pkg = graft.load_package()
+    shard = __import__("pmaf_amd.shard", fromlist=["shard"])
+    sc = scenes.synthetic_scene(24, 80, 10, 8, 11)
+    o = oracle.OraclePlanner(sc, mgr_init_pos=sc["start"])
+    o.set_initial_position(sc["start"])
+    prev = None
+    for t in range(40):
+        b = o.tick(sc["obstacles"], sc["dt"], sc["cost_gains"], sc["ws_limits"])
+        costs = o.costs()
+        for cuts in ([0, 24], [0, 8, 24], [0, 5, 11, 17, 24]):
+            parts = [costs[a:b_] for a, b_ in zip(cuts[:-1], cuts[1:])]
+            assert shard.merge_agent_ranges(parts, prev) == b
+        prev = b
+    # exact ties resolve to the lowest global index
+    assert shard.merge_agent_ranges([np.array([3.0, 2.0]), np.array([2.0, 5.0])], None) == 1
+    assert shard.merge_agent_ranges([np.array([3.0, 2.0]), np.array([1.9, 5.0])], 1) == 1  # 1.9 !< 0.9*2.0
+    assert shard.merge_agent_ranges([np.array([3.0, 2.0]), np.array([1.7, 5.0])], 1) == 2

@@ -88,7 +88,7 @@ def cpu_baseline(pkg, scene, budget_s, threads):
         "value": N * tn / en, "unit": "rollouts/s", "cores": threads, "kind": "port",
         "sample": "%d ticks (%.1f s) of the bench workload through oracle/libpmaf_oracle.so "
                   "(gcc -O2, scalar C restatement, agents split over %d threads)" % (tn, en, threads),
-        "value_1core": N * t1 / e1, "agent_steps_per_s": sn / en, "agent_steps_per_s_1core": s1 / e1,
+        "value_1core": N * t1 / e1,
     }
 
 
@@ -184,6 +184,21 @@ def main():
         achieved = bytes_per_launch / avg_kernel_s / 1e9
         steps_per_launch = agent_steps / max(launches, 1)
         flops = algorithmic_flops_per_agent_step(n_obs - 1) * steps_per_launch
+        tiles = (n_obs - 1 + 63) // 64
+        if cfg["lanes_per_agent"] == 64 and tiles <= 4 and os.environ.get("PMAF_FORCE_GENERIC") != "1":
+            kernel_name = "k_rollout_w64<%d>" % (1 if tiles <= 1 else 2 if tiles == 2 else 4)
+        else:
+            kernel_name = "k_rollout<%d>" % cfg["lanes_per_agent"]
+        # HBM traffic per launch of this kernel from the committed PMC passes
+        # (tools/gpu_prof.sh + tools/traffic_from_pmc.py); PMC counters cannot be
+        # collected from inside the timed run itself
+        traffic = None
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+            if args.config == "C2" and P == 1 and kernel_name in tj:
+                traffic = tj[kernel_name]["traffic_bytes_per_launch"]
+        except (OSError, ValueError, KeyError):
+            traffic = None
         out = {
             "metric": "agent_rollouts_per_s", "value": value, "unit": "rollouts/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -199,8 +214,8 @@ def main():
             "h_eff": steps_per_launch / (N * P),
             "tick_latency_us": {"median": float(np.median(lat) * 1e6), "p99": float(np.percentile(lat, 99) * 1e6)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "k_rollout<%d>" % cfg["lanes_per_agent"],
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": kernel_name,
                          "avg_kernel_us": avg_kernel_s * 1e6,
                          "algorithmic_bytes_per_launch": bytes_per_launch,
                          "note": "FP64-VALU/latency-bound ODE integration; HBM fraction is structurally tiny "

@@ -111,11 +111,20 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
+    # test hooks for a 1-GPU box: PMAF_BENCH_BACKEND=gloo runs the collectives on
+    # CPU tensors, PMAF_BENCH_SINGLE_DEVICE=1 maps every rank to device 0
+    backend = os.environ.get("PMAF_BENCH_BACKEND", "nccl")
+    if os.environ.get("PMAF_BENCH_SINGLE_DEVICE") == "1":
+        local_rank = 0
+    red_dev = "cuda" if backend == "nccl" else "cpu"
     if world > 1:
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     pkg = graft.load_package()
     pkg.load_library()
@@ -144,7 +153,8 @@ def main():
         planner.stop()
         if dist is not None:
             import torch
-            torch.cuda.synchronize()
+            if red_dev == "cuda":
+                torch.cuda.synchronize()
             dist.barrier()
 
     planner.tick(obs, dt, cg, ws)  # obstacles resident in HBM from here on
@@ -162,13 +172,13 @@ def main():
         if args.dynamic:
             obs = np.stack([pkg.scenes.advance_live_obstacles(o) for o in obs])
     planner.stop()
-    if dist is not None:
+    if dist is not None and red_dev == "cuda":
         import torch
         torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if dist is not None:
         import torch
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.barrier()
         elapsed = float(t.item())

@@ -95,7 +95,9 @@ struct PopConst {
   // (sqrt is monotonic and correctly rounded, so each predicate has one
   // boundary double); they let the w64 kernel skip square roots whose value
   // is only compared, never used.
-  double zf_gt, zacc_gt, zinit_lt;
+  //                    sqrt(z) < 0.5 vmax        <=>  z < zvhalf_lt
+  //                    sqrt(z) < vmax - 0.1 vmax <=>  z < zv09_lt
+  double zf_gt, zacc_gt, zinit_lt, zvhalf_lt, zv09_lt;
 };
 
 // LDS-resident obstacle table, structure of arrays, n_obs entries each

@@ -70,6 +70,7 @@ struct DevView {
   double *best_rnd;          // [P][3][n_obs]
   int32_t *best_idx;         // [P] last evaluate result
   unsigned long long *step_counter;  // [1] agent-steps executed by all rollouts
+  const double *zsent_lt;            // [P] exact squared-distance boundary of the repel range test
 };
 
 struct CostParams {
@@ -255,24 +256,26 @@ __device__ __forceinline__ void rollout_w64_body(const DevView &D, const CostPar
   // path-length norm
   V3 g = goal - p;
   double dg = norm(g);
-  double nrm_v = norm(v);
+  double zv = sqn(v);
   double z_init = sqn(p - init_pos);
+  const double zsent_lt = D.zsent_lt[pop];
   while ((dg > 0.1) && (n < D.cap)) {  // wave-uniform guard, B/src/cf_agent.cpp:310-311
     // gate, :315-317
-    const bool gate = !(dg < C.approach || (nrm_v < 0.5 * C.vel_max && z_init < C.zinit_lt));  // |p - init| < 0.2
+    // |v| < 0.5 vmax and |p - init| < 0.2 on exact squared thresholds
+    const bool gate = !(dg < C.approach || (zv < C.zvhalf_lt && z_init < C.zinit_lt));
     V3 F = mk(0.0, 0.0, 0.0);
     double scale = 1.0;
     if (gate)
-      circ_and_scale_w64<TILES, TYPE>(lane, p, v, nrm_v, goal, g, dg, C, k_circ, T, n_obs, rot_g, known_bits, O,
+      circ_and_scale_w64<TILES, TYPE>(lane, p, v, zv, goal, g, dg, C, k_circ, T, n_obs, rot_g, known_bits, O,
                                       clist, lane_min, F, scale);
     V3 new_pos;
-    finish_step_w64(p, v, g, F, scale, C, k_attr, k_repel, k_damp, sent_p, sent_r, new_pos);
+    finish_step_w64(p, v, g, F, scale, C, k_attr, k_repel, k_damp, sent_p, sent_r, zsent_lt, new_pos);
     const V3 dp = new_pos - p;
     p = new_pos;
     g = goal - p;
     const double seg = norm(dp);
     dg = norm(g);
-    nrm_v = norm(v);
+    zv = sqn(v);
     z_init = sqn(p - init_pos);
     path_len += seg;
     ws_cost_add(cost_ws, p, CP.ws, CP.k_workspace);
@@ -660,6 +663,26 @@ static double sq_ge(double c) {
   return z;
 }
 
+// Boundary of the repulsive obstacle's range test (repelForce, B/src/cf_agent.cpp:168-171):
+// smallest z >= 0 for which  max(sqrt(z) - R, 1e-5) < shell  is false; the predicate is
+// monotone in z, so  (max(sqrt(z) - R, 1e-5) < shell) == (z < boundary).
+static double repel_boundary(double R, double shell) {
+  auto in_range = [&](double z) { double d = std::sqrt(z) - R; d = (d < 1e-5) ? 1e-5 : d; return d < shell; };
+  if (!in_range(0.0)) return 0.0;
+  double lo = 0.0, hi = 1.0;
+  while (in_range(hi)) { hi *= 4.0; if (!(hi < 1e300)) return INFINITY; }
+  // bisection on the ordered bit patterns of non-negative doubles
+  uint64_t a, b;
+  std::memcpy(&a, &lo, 8); std::memcpy(&b, &hi, 8);
+  while (b - a > 1) {
+    uint64_t m = a + (b - a) / 2;
+    double z; std::memcpy(&z, &m, 8);
+    if (in_range(z)) a = m; else b = m;
+  }
+  double z; std::memcpy(&z, &b, 8);
+  return z;
+}
+
 static int pick_lpa(int N, int P, int M) {
   // Heuristic: fill the 1024 SIMDs of the chip with waves, but never use more
   // lanes per agent than there are field obstacles to share.
@@ -835,6 +858,8 @@ int pmaf_create(const pmaf_params *prm, pmaf_planner **out) {
     D.C.dt = prm->dt; D.C.vel_max = prm->velocity_max; D.C.approach = prm->approach_dist;
     D.C.shell = prm->detect_shell_rad; D.C.mass = prm->agent_mass; D.C.rad = prm->radius;
     D.C.zf_gt = sq_gt(1e-5); D.C.zacc_gt = sq_gt(13.0); D.C.zinit_lt = sq_ge(0.2);
+    D.C.zvhalf_lt = sq_ge(0.5 * prm->velocity_max);
+    D.C.zv09_lt = sq_ge(prm->velocity_max - 0.1 * prm->velocity_max);
     h->lpa = lp ? lp : pick_lpa(N, P, M);
     { const char *fg = getenv("PMAF_FORCE_GENERIC"); h->force_generic = fg && fg[0] == '1'; }
     REQUIRE((M + h->lpa - 1) / h->lpa <= 64, "pmaf_create: too many obstacles for this lanes_per_agent (need M <= 64*lanes_per_agent)");
@@ -887,6 +912,8 @@ int pmaf_create(const pmaf_params *prm, pmaf_planner **out) {
     D.best_rnd = h->dalloc<double>((size_t)P * 3 * n_obs);
     D.best_idx = h->dalloc<int32_t>(P);
     D.step_counter = h->dalloc<unsigned long long>(1);
+    double *zsent = h->dalloc<double>(P);
+    D.zsent_lt = zsent;
     h->d_reset_in = h->dalloc<double>(P * 6);
     h->d_agent_id = h->dalloc<int32_t>(P);
     HIP_CHECK(hipHostMalloc((void **)&h->h_out, sizeof(double) * P * 8, hipHostMallocMapped));
@@ -911,6 +938,12 @@ int pmaf_create(const pmaf_params *prm, pmaf_planner **out) {
     h->upload(D.real_vel, v0.data(), P * 3);
     std::vector<double> soa((size_t)P * 7 * n_obs);
     aos_to_soa(prm->obstacles, soa.data(), P, n_obs);
+    {
+      std::vector<double> zs(P);
+      for (int p = 0; p < P; p++)
+        zs[p] = repel_boundary(prm->radius + prm->obstacles[((size_t)p * n_obs + (n_obs - 1)) * 7 + 6], prm->detect_shell_rad);
+      h->upload(zsent, zs.data(), P);
+    }
     h->upload(D.obs_start, soa.data(), soa.size());
     h->upload(D.obs_live, soa.data(), soa.size());
     h->upload(ka, prm->k_attr, PN); h->upload(kc, prm->k_circ, PN);

@@ -36,14 +36,15 @@ namespace pmaf {
 // square root is only taken in the rare clamped case.
 __device__ __forceinline__ void finish_step_w64(V3 p, V3 &v, V3 goal_vec, V3 F, double scale, const PopConst &C,
                                                 double k_attr, double k_repel, double k_damp, V3 sent_pos,
-                                                double sent_rad, V3 &new_pos) {
+                                                double sent_rad, double zsent_lt, V3 &new_pos) {
   {
     V3 ro = sent_pos - p;
     V3 dist_vec = -ro;
-    double d = norm(dist_vec) - (C.rad + sent_rad);
-    d = smax(d, 1e-5);
     V3 repel = mk(0.0, 0.0, 0.0);
-    if (d < C.shell) {
+    // max(|dist_vec| - (rad + r), 1e-5) < shell  <=>  |dist_vec|^2 < zsent_lt (host-computed boundary)
+    if (sqn(dist_vec) < zsent_lt) {
+      double d = norm(dist_vec) - (C.rad + sent_rad);
+      d = smax(d, 1e-5);
       V3 otr = normalized(p - sent_pos);
       double t = 1.0 / d - 1.0 / C.shell;
       double dd = d * d;
@@ -93,9 +94,9 @@ __device__ __forceinline__ int lane_rank(unsigned long long m) {
 
 // circForce (B/src/cf_agent.cpp:72-108) + attractorForceScaling (:195-227)
 // for one agent per wave. clist: LDS, 64*TILES entries of 4 doubles.
-// nrm_v = norm(v), dg = norm(g) (already computed by the caller).
+// zv = squaredNorm(v), dg = norm(g) (already computed by the caller).
 template <int TILES, int TYPE>
-__device__ __forceinline__ void circ_and_scale_w64(int lane, V3 p, V3 v, double nrm_v, V3 goal, V3 g, double dg,
+__device__ __forceinline__ void circ_and_scale_w64(int lane, V3 p, V3 v, double zv, V3 goal, V3 g, double dg,
                                                    const PopConst &C, double k_circ, const ObsTab &T,
                                                    int n_obs, double *rot_g, unsigned &known_bits,
                                                    LaneObstacles<TILES> &O, double *clist, double &lane_min,
@@ -183,7 +184,7 @@ __device__ __forceinline__ void circ_and_scale_w64(int lane, V3 p, V3 v, double 
     }
     if (bi == 0x7fffffff) {
       scale = 1;
-    } else if (dot(g, v) <= 0.0 && nrm_v < C.vel_max - 0.1 * C.vel_max && dg > 0.15) {
+    } else if (dot(g, v) <= 0.0 && zv < C.zv09_lt && dg > 0.15) {  // norm(v) < vmax - 0.1 vmax
       scale = 0.0;
     } else {
       const double w1 = 1 - portable_exp(-__builtin_sqrt(m) / C.shell);

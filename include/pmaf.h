@@ -63,6 +63,13 @@ typedef enum pmaf_agent_type {
 
 typedef struct pmaf_planner pmaf_planner;
 
+/* pmaf_params.flags */
+/* Opt-in fast arithmetic in the wave-per-agent rollout kernel: divisions and
+ * square roots by v_rcp_f64 / v_rsq_f64 + two Newton steps (1-2 ulp) instead of
+ * the correctly rounded IEEE sequences. Default (flag clear) is the strict mode
+ * whose results are bit-identical to the CPU restatement. */
+#define PMAF_FLAG_FAST_MATH 1
+
 /*
  * Arguments of CfManager::init (B/src/cf_manager.cpp:41-124,
  * B/include/bimanual_planning_ros/cf_manager.h:93-102) for P populations.
@@ -75,7 +82,7 @@ typedef struct pmaf_params {
   int32_t max_prediction_steps; /* path capacity in points (H+1) */
   int32_t device;               /* HIP device ordinal; -1 = current device */
   int32_t lanes_per_agent;      /* 0 = auto; else 1,2,4,8,16,32,64 */
-  int32_t reserved;
+  int32_t flags;                /* PMAF_FLAG_* bits, 0 = defaults */
   double dt;                    /* prediction_freq_multiple * delta_t */
   double velocity_max;
   double approach_dist;

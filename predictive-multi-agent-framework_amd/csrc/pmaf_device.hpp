@@ -55,11 +55,68 @@ __device__ __forceinline__ V3 cross(V3 a, V3 b) {
 __device__ __forceinline__ double smax(double a, double b) { return (a < b) ? b : a; }
 __device__ __forceinline__ double smin(double a, double b) { return (b < a) ? b : a; }
 
+// ---- arithmetic policy ----------------------------------------------------
+// Mth<false>: IEEE division / square root (correctly rounded; the compiler's
+// expansions: 14 / 16 VALU instructions each). Everything bit-exact rests on it.
+// Mth<true> ("fast math", opt-in via PMAF_FLAG_FAST_MATH): v_rcp_f64 /
+// v_rsq_f64 seeds (2^-24 relative) + two Newton / Goldschmidt iterations in
+// FMA arithmetic: ~1-2 ulp per operation, 6 / 8 instructions, and one shared
+// reciprocal for a vector divided by a scalar. Results then differ from the
+// oracle in the last bits (~1e-13 m over the BASELINE horizons; the parity
+// tests for this mode assert the north-star tolerance 1e-5 m).
+template <bool FAST> struct Mth;
+template <> struct Mth<false> {
+  static __device__ __forceinline__ double sqrt(double z) { return __builtin_sqrt(z); }
+  static __device__ __forceinline__ double div(double a, double b) { return a / b; }
+  static __device__ __forceinline__ V3 div3(V3 a, double s) { return a / s; }
+  static __device__ __forceinline__ double norm(V3 a) { return __builtin_sqrt(sqn(a)); }
+  // s = |a|, u = a.normalized()
+  static __device__ __forceinline__ void norm_unit(V3 a, double &s, V3 &u) {
+    double z = sqn(a);
+    s = __builtin_sqrt(z);
+    u = (z > 0.0) ? (a / s) : a;
+  }
+  static __device__ __forceinline__ V3 normalized(V3 a) { return pmaf::normalized(a); }
+};
+template <> struct Mth<true> {
+  static __device__ __forceinline__ double rcp(double b) {
+    double r = __builtin_amdgcn_rcp(b);
+    r = __builtin_fma(__builtin_fma(-b, r, 1.0), r, r);
+    r = __builtin_fma(__builtin_fma(-b, r, 1.0), r, r);
+    return r;
+  }
+  // g ~ sqrt(z), y ~ 1/sqrt(z); z == 0 gives g = 0, y = 0
+  static __device__ __forceinline__ void sqrt_rsqrt(double z, double &g, double &y) {
+    double y0 = __builtin_amdgcn_rsq(z);
+    y0 = (z > 0.0) ? y0 : 0.0;
+    double gg = z * y0, h = 0.5 * y0;
+    double r = __builtin_fma(-h, gg, 0.5);
+    gg = __builtin_fma(gg, r, gg);
+    h = __builtin_fma(h, r, h);
+    r = __builtin_fma(-h, gg, 0.5);
+    gg = __builtin_fma(gg, r, gg);
+    h = __builtin_fma(h, r, h);
+    g = gg;
+    y = h + h;
+  }
+  static __device__ __forceinline__ double sqrt(double z) { double g, y; sqrt_rsqrt(z, g, y); return g; }
+  static __device__ __forceinline__ double div(double a, double b) { return a * rcp(b); }
+  static __device__ __forceinline__ V3 div3(V3 a, double s) { double r = rcp(s); return a * r; }
+  static __device__ __forceinline__ double norm(V3 a) { return sqrt(sqn(a)); }
+  static __device__ __forceinline__ void norm_unit(V3 a, double &s, V3 &u) {
+    double y;
+    sqrt_rsqrt(sqn(a), s, y);
+    u = a * y;
+  }
+  static __device__ __forceinline__ V3 normalized(V3 a) { double s; V3 u; norm_unit(a, s, u); return u; }
+};
+
 // exp() of attractorForceScaling (B/src/cf_agent.cpp:220). The reference
 // calls the platform libm, whose last bit is not portable; this is the
 // table-free fdlibm e_exp.c algorithm (< 1 ulp) in plain IEEE + - * /, the
 // same function as oracle/pmaf_oracle.c:pmaf_portable_exp, so it produces
 // identical bits on the host and on gfx950.
+template <bool FAST = false>
 __device__ __forceinline__ double portable_exp(double x) {
   const double ln2HI = 6.93147180369123816490e-01, ln2LO = 1.90821492927058770002e-10,
                invln2 = 1.44269504088896338700e+00,
@@ -79,7 +136,7 @@ __device__ __forceinline__ double portable_exp(double x) {
   const double r = hi - lo;
   const double r2 = r * r;
   const double c = r - r2 * (P1 + r2 * (P2 + r2 * (P3 + r2 * (P4 + r2 * P5))));
-  const double y = 1.0 - ((lo - (r * c) / (2.0 - c)) - hi);
+  const double y = 1.0 - ((lo - Mth<FAST>::div(r * c, 2.0 - c)) - hi);
   return y * __longlong_as_double((long long)(1023 + k) << 52);
 }
 
@@ -162,7 +219,7 @@ __device__ __forceinline__ void ordered_accumulate(V3 &F, V3 c, bool has_c, int 
   } else if (LPA == 1) {
     if (has_c) F = F + c;
   } else {
-    const unsigned long long gm = (LPA >= 64) ? ~0ull : ((1ull << LPA) - 1ull);
+    const unsigned long long gm = (LPA >= 64) ? ~0ull : ((1ull << (LPA & 63)) - 1ull);
     unsigned long long sub = (m >> (grp * LPA)) & gm;
     while (__any(sub != 0ull)) {
       int src = grp * LPA + (sub ? (__ffsll((long long)sub) - 1) : 0);
@@ -218,18 +275,20 @@ __device__ __forceinline__ int wave_min64_i(int v) {
 // 463-475 (GoalObstacle), 520-537 (Vel), 545-557 (Random), 585-597 (Had).
 // to_obs = normalized(obstacle - agent_pos), identical to the value the
 // reference recomputes inside each currentVector.
+template <bool FAST = false>
 __device__ __forceinline__ V3 current_vector(int type, V3 agent_vel, V3 goal_vec, V3 to_obs, V3 rot) {
+  typedef Mth<FAST> M;
   if (type == T_GOAL) {
     V3 cur = goal_vec - to_obs * dot(to_obs, goal_vec);
-    if (norm(cur) < 1e-10) cur = mk(0.0, 0.0, 1.0);
-    return normalized(cur);
+    if (M::norm(cur) < 1e-10) cur = mk(0.0, 0.0, 1.0);
+    return M::normalized(cur);
   } else if (type == T_VEL) {
-    V3 nvel = normalized(agent_vel);
+    V3 nvel = M::normalized(agent_vel);
     V3 cur = nvel - to_obs * dot(nvel, to_obs);
-    if (norm(cur) < 1e-10) cur = mk(0.0, 0.0, 1.0);
-    return normalized(cur);
+    if (M::norm(cur) < 1e-10) cur = mk(0.0, 0.0, 1.0);
+    return M::normalized(cur);
   } else if (type == T_OBST || type == T_GOALOBST || type == T_RANDOM || type == T_HAD) {
-    return normalized(cross(to_obs, rot));
+    return M::normalized(cross(to_obs, rot));
   }
   return mk(0.0, 0.0, 0.0);
 }

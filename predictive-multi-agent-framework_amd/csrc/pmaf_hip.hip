@@ -71,6 +71,7 @@ struct DevView {
   int32_t *best_idx;         // [P] last evaluate result
   unsigned long long *step_counter;  // [1] agent-steps executed by all rollouts
   const double *zsent_lt;            // [P] exact squared-distance boundary of the repel range test
+  int ablate;                        // timing experiments only (PMAF_ABLATE), 0 in production
 };
 
 struct CostParams {
@@ -192,7 +193,7 @@ __global__ __launch_bounds__(64) void k_rollout(DevView D, CostParams CP) {
 // ---------------------------------------------------------------------------
 // the step loop, specialised on the agent's heuristic so the per-step code
 // carries no type dispatch (the type is uniform per wave)
-template <int TILES, int TYPE>
+template <int TILES, int TYPE, bool FAST>
 __device__ __forceinline__ void rollout_w64_body(const DevView &D, const CostParams &CP, const int lane,
                                                  const int pop, const int a) {
   extern __shared__ double smem[];
@@ -255,7 +256,7 @@ __device__ __forceinline__ void rollout_w64_body(const DevView &D, const CostPar
   // step, where they share a basic block (and the FP64 pipeline) with the
   // path-length norm
   V3 g = goal - p;
-  double dg = norm(g);
+  double dg = Mth<FAST>::norm(g);
   double zv = sqn(v);
   double z_init = sqn(p - init_pos);
   const double zsent_lt = D.zsent_lt[pop];
@@ -263,18 +264,19 @@ __device__ __forceinline__ void rollout_w64_body(const DevView &D, const CostPar
     // gate, :315-317
     // |v| < 0.5 vmax and |p - init| < 0.2 on exact squared thresholds
     const bool gate = !(dg < C.approach || (zv < C.zvhalf_lt && z_init < C.zinit_lt));
+    const V3 verr = attractor_velocity_error<FAST>(v, g, C, k_attr, k_damp);
     V3 F = mk(0.0, 0.0, 0.0);
     double scale = 1.0;
-    if (gate)
-      circ_and_scale_w64<TILES, TYPE>(lane, p, v, zv, goal, g, dg, C, k_circ, T, n_obs, rot_g, known_bits, O,
-                                      clist, lane_min, F, scale);
+    if (gate && !(D.ablate & 8))
+      circ_and_scale_w64<TILES, TYPE, FAST>(lane, p, v, zv, goal, g, dg, C, k_circ, T, n_obs, rot_g, known_bits, O,
+                                      clist, lane_min, F, scale, D.ablate);
     V3 new_pos;
-    finish_step_w64(p, v, g, F, scale, C, k_attr, k_repel, k_damp, sent_p, sent_r, zsent_lt, new_pos);
+    finish_step_w64<FAST>(p, v, verr, F, scale, C, k_attr, k_repel, k_damp, sent_p, sent_r, zsent_lt, new_pos);
     const V3 dp = new_pos - p;
     p = new_pos;
     g = goal - p;
-    const double seg = norm(dp);
-    dg = norm(g);
+    const double seg = Mth<FAST>::norm(dp);
+    dg = Mth<FAST>::norm(g);
     zv = sqn(v);
     z_init = sqn(p - init_pos);
     path_len += seg;
@@ -313,18 +315,18 @@ __device__ __forceinline__ void rollout_w64_body(const DevView &D, const CostPar
   }
 }
 
-template <int TILES>
+template <int TILES, bool FAST>
 __global__ __launch_bounds__(64) void k_rollout_w64(DevView D, CostParams CP) {
   const int lane = threadIdx.x;
   const int pop = blockIdx.y;
   const int a = blockIdx.x;  // grid.x == N
   switch (D.types[a]) {
-    case T_GOAL: rollout_w64_body<TILES, T_GOAL>(D, CP, lane, pop, a); break;
-    case T_OBST: rollout_w64_body<TILES, T_OBST>(D, CP, lane, pop, a); break;
-    case T_GOALOBST: rollout_w64_body<TILES, T_GOALOBST>(D, CP, lane, pop, a); break;
-    case T_VEL: rollout_w64_body<TILES, T_VEL>(D, CP, lane, pop, a); break;
-    case T_RANDOM: rollout_w64_body<TILES, T_RANDOM>(D, CP, lane, pop, a); break;
-    case T_HAD: rollout_w64_body<TILES, T_HAD>(D, CP, lane, pop, a); break;
+    case T_GOAL: rollout_w64_body<TILES, T_GOAL, FAST>(D, CP, lane, pop, a); break;
+    case T_OBST: rollout_w64_body<TILES, T_OBST, FAST>(D, CP, lane, pop, a); break;
+    case T_GOALOBST: rollout_w64_body<TILES, T_GOALOBST, FAST>(D, CP, lane, pop, a); break;
+    case T_VEL: rollout_w64_body<TILES, T_VEL, FAST>(D, CP, lane, pop, a); break;
+    case T_RANDOM: rollout_w64_body<TILES, T_RANDOM, FAST>(D, CP, lane, pop, a); break;
+    case T_HAD: rollout_w64_body<TILES, T_HAD, FAST>(D, CP, lane, pop, a); break;
     default: break;
   }
 }
@@ -593,6 +595,7 @@ struct pmaf_planner {
   DevView D{};
   int device = 0;
   int lpa = 64;
+  bool fast_math = false;      // PMAF_FLAG_FAST_MATH (w64 rollout kernels only)
   bool force_generic = false;  // PMAF_FORCE_GENERIC=1: always use the generic k_rollout<LPA>
   int n_blocks = 0;
   size_t lds_rollout = 0, lds_manager = 0;
@@ -733,9 +736,13 @@ static void launch_rollout(pmaf_planner *h) {
   const int tiles64 = (h->D.n_obs - 1 + 63) / 64;
   if (h->lpa == 64 && tiles64 <= 4 && !h->force_generic) {
     dim3 g64((unsigned)h->D.N, (unsigned)h->D.P);
-    if (tiles64 <= 1) hipLaunchKernelGGL((k_rollout_w64<1>), g64, block, h->lds_rollout, h->stream, h->D, h->cp);
-    else if (tiles64 == 2) hipLaunchKernelGGL((k_rollout_w64<2>), g64, block, h->lds_rollout, h->stream, h->D, h->cp);
-    else hipLaunchKernelGGL((k_rollout_w64<4>), g64, block, h->lds_rollout, h->stream, h->D, h->cp);
+#define PMAF_W64(T, F) hipLaunchKernelGGL((k_rollout_w64<T, F>), g64, block, h->lds_rollout, h->stream, h->D, h->cp)
+    if (h->fast_math) {
+      if (tiles64 <= 1) PMAF_W64(1, true); else if (tiles64 == 2) PMAF_W64(2, true); else PMAF_W64(4, true);
+    } else {
+      if (tiles64 <= 1) PMAF_W64(1, false); else if (tiles64 == 2) PMAF_W64(2, false); else PMAF_W64(4, false);
+    }
+#undef PMAF_W64
   } else
   switch (h->lpa) {
 #define PMAF_CASE(L) case L: hipLaunchKernelGGL((k_rollout<L>), grid, block, h->lds_rollout, h->stream, h->D, h->cp); break;
@@ -860,8 +867,10 @@ int pmaf_create(const pmaf_params *prm, pmaf_planner **out) {
     D.C.zf_gt = sq_gt(1e-5); D.C.zacc_gt = sq_gt(13.0); D.C.zinit_lt = sq_ge(0.2);
     D.C.zvhalf_lt = sq_ge(0.5 * prm->velocity_max);
     D.C.zv09_lt = sq_ge(prm->velocity_max - 0.1 * prm->velocity_max);
+    h->fast_math = (prm->flags & PMAF_FLAG_FAST_MATH) != 0;
     h->lpa = lp ? lp : pick_lpa(N, P, M);
     { const char *fg = getenv("PMAF_FORCE_GENERIC"); h->force_generic = fg && fg[0] == '1'; }
+    { const char *ab = getenv("PMAF_ABLATE"); D.ablate = ab ? atoi(ab) : 0; }
     REQUIRE((M + h->lpa - 1) / h->lpa <= 64, "pmaf_create: too many obstacles for this lanes_per_agent (need M <= 64*lanes_per_agent)");
     h->n_blocks = (N * h->lpa + 63) / 64;
     {

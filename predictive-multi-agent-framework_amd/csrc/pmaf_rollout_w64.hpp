@@ -34,7 +34,26 @@ namespace pmaf {
 // finish_step (pmaf_device.hpp) for the w64 kernel: same arithmetic; the
 // acceleration clamp is decided on the squared norm (exact threshold) so the
 // square root is only taken in the rare clamped case.
-__device__ __forceinline__ void finish_step_w64(V3 p, V3 &v, V3 goal_vec, V3 F, double scale, const PopConst &C,
+// attractorForce's velocity error (B/src/cf_agent.cpp:188-192): depends only on
+// the step's start state, so it is evaluated BEFORE the obstacle sweep, where
+// its sqrt / divide chain overlaps the sweep's instead of extending the
+// dependent chain after the force sum.
+template <bool FAST>
+__device__ __forceinline__ V3 attractor_velocity_error(V3 v, V3 goal_vec, const PopConst &C, double k_attr,
+                                                       double k_damp) {
+  V3 vel_des = (k_attr / k_damp) * goal_vec;
+  double scale_lim = smin(1.0, Mth<FAST>::div(C.vel_max, Mth<FAST>::norm(vel_des)));
+  vel_des = vel_des * scale_lim;
+  return vel_des - v;
+}
+
+// finish_step (pmaf_device.hpp) for the w64 kernel: same arithmetic and order;
+// verr = attractor_velocity_error(...) of this step; the acceleration clamp is
+// decided on the squared norm (exact threshold) so its square root is only
+// taken in the rare clamped case; the speed clamp is a select so the block is
+// not split (the next step's norms can overlap it).
+template <bool FAST>
+__device__ __forceinline__ void finish_step_w64(V3 p, V3 &v, V3 verr, V3 F, double scale, const PopConst &C,
                                                 double k_attr, double k_repel, double k_damp, V3 sent_pos,
                                                 double sent_rad, double zsent_lt, V3 &new_pos) {
   {
@@ -42,7 +61,7 @@ __device__ __forceinline__ void finish_step_w64(V3 p, V3 &v, V3 goal_vec, V3 F, 
     V3 dist_vec = -ro;
     V3 repel = mk(0.0, 0.0, 0.0);
     // max(|dist_vec| - (rad + r), 1e-5) < shell  <=>  |dist_vec|^2 < zsent_lt (host-computed boundary)
-    if (sqn(dist_vec) < zsent_lt) {
+    if (sqn(dist_vec) < zsent_lt) {  // rare: strict arithmetic in both modes
       double d = norm(dist_vec) - (C.rad + sent_rad);
       d = smax(d, 1e-5);
       V3 otr = normalized(p - sent_pos);
@@ -53,22 +72,18 @@ __device__ __forceinline__ void finish_step_w64(V3 p, V3 &v, V3 goal_vec, V3 F, 
     V3 total = mk(0.0, 0.0, 0.0) + repel;
     F = F + total;
   }
-  if (k_attr != 0.0) {
-    V3 vel_des = (k_attr / k_damp) * goal_vec;
-    double scale_lim = smin(1.0, C.vel_max / norm(vel_des));
-    vel_des = vel_des * scale_lim;
-    F = F + (scale * k_damp) * (vel_des - v);
-  }
+  if (k_attr != 0.0) F = F + (scale * k_damp) * verr;
   V3 acc = F;
   if (C.mass != 1.0) acc = F / C.mass;
   const double az = sqn(acc);
-  if (az >= C.zacc_gt) acc = acc * (13.0 / __builtin_sqrt(az));  // norm(acc) > 13.0
+  if (az >= C.zacc_gt) acc = acc * (13.0 / __builtin_sqrt(az));  // norm(acc) > 13.0 (rare)
   V3 half = ((0.5 * acc) * C.dt) * C.dt;
   new_pos = (p + half) + (v * C.dt);
   V3 nv = v + acc * C.dt;
-  double vn = norm(nv);
-  if (vn > C.vel_max) nv = nv * (C.vel_max / vn);
-  v = nv;
+  const double vn = Mth<FAST>::norm(nv);
+  const double f = Mth<FAST>::div(C.vel_max, vn);
+  const V3 cl = nv * f;
+  v = (vn > C.vel_max) ? cl : nv;
 }
 
 // wave-level ordering of LDS accesses: DS instructions of one wave execute in
@@ -95,15 +110,16 @@ __device__ __forceinline__ int lane_rank(unsigned long long m) {
 // circForce (B/src/cf_agent.cpp:72-108) + attractorForceScaling (:195-227)
 // for one agent per wave. clist: LDS, 64*TILES entries of 4 doubles.
 // zv = squaredNorm(v), dg = norm(g) (already computed by the caller).
-template <int TILES, int TYPE>
+template <int TILES, int TYPE, bool FAST>
 __device__ __forceinline__ void circ_and_scale_w64(int lane, V3 p, V3 v, double zv, V3 goal, V3 g, double dg,
                                                    const PopConst &C, double k_circ, const ObsTab &T,
                                                    int n_obs, double *rot_g, unsigned &known_bits,
                                                    LaneObstacles<TILES> &O, double *clist, double &lane_min,
-                                                   V3 &F, double &scale) {
+                                                   V3 &F, double &scale, const int ablate = 0) {
   const int M = n_obs - 1;
   // goal_vec.normalized(): dg == sqrt(squaredNorm(g)), the value normalized() divides by
-  const V3 gn = (dg > 0.0) ? (g / dg) : g;
+  typedef Mth<FAST> MT;
+  const V3 gn = (dg > 0.0) ? MT::div3(g, dg) : g;
   double best_d = C.shell;
   double best_s = 0.0, best_gr = 0.0;  // |ro| and g.ro of the lane's closest obstacle
   int best_i = 0x7fffffff;
@@ -115,9 +131,9 @@ __device__ __forceinline__ void circ_and_scale_w64(int lane, V3 p, V3 v, double 
     const V3 op = O.p[t];
     const V3 ro = op - p;
     const V3 rv = v - O.v[t];
-    const double z = sqn(ro);
-    const double s = __builtin_sqrt(z);
-    const V3 ron = (z > 0.0) ? (ro / s) : ro;
+    double s;
+    V3 ron;
+    MT::norm_unit(ro, s, ron);
     const bool skip = (dot(ron, gn) < -0.01) && (dot(ro, rv) < -0.01);
     double d = s - (C.rad + O.r[t]);
     d = smax(d, 1e-5);
@@ -125,7 +141,7 @@ __device__ __forceinline__ void circ_and_scale_w64(int lane, V3 p, V3 v, double 
     const bool live = valid && !skip;
     if (live && d < lane_min) lane_min = d;
     const bool in_shell = live && (d < C.shell);
-    if (__any(in_shell)) {
+    if (__any(in_shell) && !(ablate & 4)) {
       // first contact: latch the rotation vector (rare)
       const bool need_latch = in_shell && !((known_bits >> t) & 1u);
       if (__any(need_latch)) {
@@ -139,10 +155,12 @@ __device__ __forceinline__ void circ_and_scale_w64(int lane, V3 p, V3 v, double 
       // per-lane circular-field term, evaluated by every lane (lanes outside
       // the shell compute values that are discarded by has_c)
       const V3 rot = mk(O.rx[t], O.ry[t], O.rz[t]);
-      const double vn = norm(rv);
-      const V3 nv = rv / vn;
-      const V3 cur = current_vector(TYPE, rv, g, ron, rot);
-      const V3 c = (k_circ / (d * d)) * cross(nv, cross(cur, nv));
+      double vn;
+      V3 nv;
+      if (FAST) { MT::norm_unit(rv, vn, nv); }
+      else { vn = norm(rv); nv = rv / vn; }
+      const V3 cur = current_vector<FAST>(TYPE, rv, g, ron, rot);
+      const V3 c = MT::div(k_circ, d * d) * cross(nv, cross(cur, nv));
       const bool has_c = in_shell && (vn != 0);
       // compact the contributing terms, ascending obstacle index, into LDS
       const unsigned long long m = __ballot(has_c);
@@ -156,7 +174,7 @@ __device__ __forceinline__ void circ_and_scale_w64(int lane, V3 p, V3 v, double 
   // closest obstacle of the sweep (attractorForceScaling :201-211); the
   // min_obs_dist_ minimum stays per lane and is reduced once after the rollout
   const double m = wave_min64(best_d);
-  if (count > 0) {
+  if (count > 0 && !(ablate & 2)) {
     wave_lds_fence();
     // F = ((0 + c_0) + c_1) + ... front to back; every lane reads the same
     // address (LDS broadcast), so every lane ends with the same F
@@ -173,7 +191,7 @@ __device__ __forceinline__ void circ_and_scale_w64(int lane, V3 p, V3 v, double 
     wave_lds_fence();
   }
   // attractorForceScaling (only if |F| > 1e-5, :319)
-  if (sqn(F) >= C.zf_gt) {  // norm(F) > 1e-5
+  if (sqn(F) >= C.zf_gt && !(ablate & 1)) {  // norm(F) > 1e-5
     const bool cand = (best_i != 0x7fffffff) && (best_d == m);
     int bi;
     if (TILES == 1) {  // obstacle index == lane: lowest candidate lane wins
@@ -187,12 +205,12 @@ __device__ __forceinline__ void circ_and_scale_w64(int lane, V3 p, V3 v, double 
     } else if (dot(g, v) <= 0.0 && zv < C.zv09_lt && dg > 0.15) {  // norm(v) < vmax - 0.1 vmax
       scale = 0.0;
     } else {
-      const double w1 = 1 - portable_exp(-__builtin_sqrt(m) / C.shell);
+      const double w1 = 1 - portable_exp<FAST>(-MT::div(MT::sqrt(m), C.shell));
       // |ro| and g.ro of the closest obstacle were computed by the lane that
       // owns it (same operands, same bits as recomputing them here)
       const int bl = bi & 63;
       const double sb = readlane_d(best_s, bl), gr = readlane_d(best_gr, bl);
-      double w2 = 1 - (gr / (dg * sb));
+      double w2 = 1 - MT::div(gr, dg * sb);
       w2 = w2 * w2;
       scale = w1 * w2;
     }

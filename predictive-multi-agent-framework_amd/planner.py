@@ -28,7 +28,7 @@ class PmafParams(C.Structure):
     _fields_ = [
         ("abi_version", C.c_int32), ("n_populations", C.c_int32), ("n_agents", C.c_int32),
         ("n_obstacles", C.c_int32), ("max_prediction_steps", C.c_int32), ("device", C.c_int32),
-        ("lanes_per_agent", C.c_int32), ("reserved", C.c_int32),
+        ("lanes_per_agent", C.c_int32), ("flags", C.c_int32),
         ("dt", C.c_double), ("velocity_max", C.c_double), ("approach_dist", C.c_double),
         ("detect_shell_rad", C.c_double), ("agent_mass", C.c_double), ("radius", C.c_double),
         ("goal", _dp), ("init_pos", _dp), ("obstacles", _dp),
@@ -130,7 +130,7 @@ class PmafPlanner:
     a list of P scene dicts (see scenes.py) sharing N, n_obs, capacity and the
     scalar parameters. Method names follow the C-ABI / CfManager."""
 
-    def __init__(self, scenes, device=-1, lanes_per_agent=0, mgr_init_pos=None):
+    def __init__(self, scenes, device=-1, lanes_per_agent=0, mgr_init_pos=None, fast_math=False):
         if isinstance(scenes, dict):
             scenes = [scenes]
         self.L = load_library()
@@ -148,6 +148,7 @@ class PmafPlanner:
         prm.max_prediction_steps = self.cap
         prm.device = device
         prm.lanes_per_agent = lanes_per_agent
+        prm.flags = 1 if fast_math else 0  # PMAF_FLAG_FAST_MATH
         prm.dt = s0["dt"]
         prm.velocity_max = s0["velocity_max"]
         prm.approach_dist = s0["approach_dist"]

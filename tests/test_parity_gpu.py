@@ -317,3 +317,51 @@ def test_device_arithmetic_is_ieee_exact(pmaf, oracle):
     assert (pmaf.debug_math(4, a, b) == a + b).all()
     x = -rng.uniform(0.0, 3.0, 200_000)
     assert (pmaf.debug_math(2, x) == oracle.portable_exp(x)).all()
+
+
+# ---------------------------------------------------------------------------
+# opt-in fast arithmetic (PMAF_FLAG_FAST_MATH): tolerance parity only
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("cfg,ticks", [("C1", 40), ("C2", 40), ("C3", 3)])
+def test_fast_math_within_north_star_tolerance(pmaf, oracle, scenes, cfg, ticks, mode):
+    """rcp/rsq + Newton arithmetic (1-2 ulp per op) instead of IEEE div/sqrt:
+    not bit-exact by construction. The SELECTED trajectory (the real agent's
+    path and the winning agent's predicted path) must stay within 1e-5 m of
+    BOTH oracle modes (north star). Individual non-selected agents may diverge
+    at C3 (500 steps through 128 obstacles is chaotic: any last-bit
+    perturbation, including another libm's exp, is amplified); their share is
+    printed. Agent indices are compared through their cost (exactly tied
+    agents may swap)."""
+    oracle.set_exp_mode(mode)
+    sc = scenes.config_scene(cfg)
+    hip = pmaf.PmafPlanner(sc, device=0, mgr_init_pos=sc["start"], fast_math=True)
+    ora = oracle.OraclePlanner(sc, mgr_init_pos=sc["start"])
+    hip.set_initial_position(sc["start"])
+    ora.set_initial_position(sc["start"])
+    bh, ph = drive(hip, sc, ticks)
+    bo, po = drive(ora, sc, ticks)
+    hip.stop()
+    assert np.abs(ph - po).max() <= LIBM_TOL
+    pth, nh = hip.paths()
+    pto, no = ora.paths()
+    co = ora.costs()
+    assert np.all(np.abs(co[bh[-1]] - co[bo[-1]]) <= 1e-9 * max(1.0, abs(co[bo[-1]])))
+    best = int(bo[-1])
+    per_agent = np.array([np.abs(pth[a, :min(nh[a], no[a])] - pto[a, :min(nh[a], no[a])]).max() for a in range(len(nh))])
+    assert per_agent[best] <= LIBM_TOL
+    if cfg != "C3":
+        np.testing.assert_array_equal(nh, no)
+        assert per_agent.max() <= LIBM_TOL
+    print("%s fast-math vs oracle(mode %d): best agent %.3g m, all agents max %.3g m, %d/%d agents within 1e-5 m"
+          % (cfg, mode, per_agent[best], per_agent.max(), int((per_agent <= LIBM_TOL).sum()), len(nh)))
+    hip.close()
+
+
+def test_generic_kernel_forced_for_wave_per_agent_mapping(pmaf, oracle, scenes, monkeypatch):
+    """PMAF_FORCE_GENERIC=1 keeps k_rollout<64> (the LDS-table kernel) covered
+    now that lanes_per_agent = 64 normally dispatches to k_rollout_w64"""
+    monkeypatch.setenv("PMAF_FORCE_GENERIC", "1")
+    sc = scenes.static1_scene(13, 120)
+    hip, _ = run_both(pmaf, oracle, scenes, sc, 6, lanes_per_agent=64)
+    hip.close()

@@ -4,6 +4,16 @@ import sys
 import numpy as np
 import pytest
 
+# PyTorch-ROCm wheels bundle their own HIP/HSA runtime; a process that loads
+# libpmaf_hip.so (system ROCm) first and torch afterwards ends up with two HSA
+# runtimes and torch reports "No HIP GPUs are available". Importing torch first
+# makes both share one runtime (tests that own device buffers through torch
+# need this; the product library itself never needs torch).
+try:
+    import torch  # noqa: F401
+except ImportError:  # pragma: no cover
+    torch = None
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

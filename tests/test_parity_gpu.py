@@ -365,3 +365,95 @@ def test_generic_kernel_forced_for_wave_per_agent_mapping(pmaf, oracle, scenes, 
     sc = scenes.static1_scene(13, 120)
     hip, _ = run_both(pmaf, oracle, scenes, sc, 6, lanes_per_agent=64)
     hip.close()
+
+
+# ---------------------------------------------------------------------------
+# BASELINE full sizes
+# ---------------------------------------------------------------------------
+def test_c5_full_size_8x1024_agents_bit_exact(pmaf, oracle, scenes):
+    """BASELINE config C5 at full size on one GPU: 8 scenes x 1024 agents x
+    200 steps x 32 obstacles in one handle, two ticks, every path point of
+    all 8192 agents compared with 8 oracles (bit-exact)."""
+    scs = [scenes.config_scene("C5", scene_id=s) for s in range(8)]
+    starts = np.stack([s["start"] for s in scs])
+    hip = pmaf.PmafPlanner(scs, device=0, mgr_init_pos=starts)
+    hip.set_initial_position(starts)
+    oras = []
+    for s in scs:
+        o = oracle.OraclePlanner(s, mgr_init_pos=s["start"])
+        o.set_initial_position(s["start"])
+        oras.append(o)
+    obs = np.stack([s["obstacles"] for s in scs])
+    sc = scs[0]
+    for t in range(2):
+        bh = hip.tick(obs, sc["dt"], sc["cost_gains"], sc["ws_limits"])
+        bo = [o.tick(obs[i], sc["dt"], sc["cost_gains"], sc["ws_limits"]) for i, o in enumerate(oras)]
+        np.testing.assert_array_equal(bh, bo)
+    ph, nh = hip.paths()
+    for i, o in enumerate(oras):
+        po, no = o.paths()
+        np.testing.assert_array_equal(nh[i], no)
+        np.testing.assert_array_equal(ph[i], po)
+        np.testing.assert_array_equal(hip.costs()[i], o.costs())
+    # size-independent invariants on the full batch (SURVEY A.9)
+    vmax, dt = sc["velocity_max"], sc["dt"]
+    seg = np.linalg.norm(np.diff(ph, axis=2), axis=3)
+    valid = np.arange(1, ph.shape[2])[None, None, :] < nh[:, :, None]
+    assert (seg[valid] <= vmax * dt + 0.5 * 13.0 * dt * dt + 1e-12).all()
+    mo = hip.min_obs_dist()
+    assert (mo >= 1e-5).all() and (mo <= sc["detect_shell_rad"]).all()
+    hip.close()
+
+
+@pytest.mark.parametrize("lpa", [8, 16])
+def test_c5_reduced_generic_lane_mappings(pmaf, oracle, scenes, lpa):
+    """the throughput mappings (several agents per wave) on a C5-shaped batch"""
+    scs = [scenes.synthetic_scene(200, 200, 32, 5, s) for s in range(3)]
+    starts = np.stack([s["start"] for s in scs])
+    hip = pmaf.PmafPlanner(scs, device=0, mgr_init_pos=starts, lanes_per_agent=lpa)
+    hip.set_initial_position(starts)
+    obs = np.stack([s["obstacles"] for s in scs])
+    sc = scs[0]
+    oras = []
+    for s in scs:
+        o = oracle.OraclePlanner(s, mgr_init_pos=s["start"])
+        o.set_initial_position(s["start"])
+        oras.append(o)
+    for t in range(3):
+        bh = hip.tick(obs, sc["dt"], sc["cost_gains"], sc["ws_limits"])
+        bo = [o.tick(obs[i], sc["dt"], sc["cost_gains"], sc["ws_limits"]) for i, o in enumerate(oras)]
+        np.testing.assert_array_equal(bh, bo)
+    ph, nh = hip.paths()
+    for i, o in enumerate(oras):
+        po, no = o.paths()
+        np.testing.assert_array_equal(nh[i], no)
+        np.testing.assert_array_equal(ph[i], po)
+    hip.close()
+
+
+def test_winner_records_written_on_device(pmaf, oracle, scenes):
+    """pmaf_write_winner_records (send buffer of the all-gather) against the
+    host getters; needs torch only to own the device buffer"""
+    torch = pytest.importorskip("torch")
+    scs = [scenes.synthetic_scene(24, 90, 12, 5, s) for s in range(3)]
+    starts = np.stack([s["start"] for s in scs])
+    hip = pmaf.PmafPlanner(scs, device=0, mgr_init_pos=starts)
+    hip.set_initial_position(starts)
+    sc = scs[0]
+    obs = np.stack([s["obstacles"] for s in scs])
+    for t in range(4):
+        hip.tick(obs, sc["dt"], sc["cost_gains"], sc["ws_limits"])
+    hip.stop()
+    best = hip.evaluate(sc["cost_gains"], sc["ws_limits"])
+    rec = hip.winner_record_doubles()
+    buf = torch.zeros((3, rec), dtype=torch.float64, device="cuda:0")
+    hip.write_winner_records(buf.data_ptr(), buf.numel() * 8)
+    hip.stop()
+    out = pmaf.shard.unpack_winner_records(buf.cpu().numpy(), sc["max_prediction_steps"])
+    paths, n = hip.paths()
+    costs = hip.costs()
+    for p in range(3):
+        assert out[p]["index"] == best[p] and out[p]["n_points"] == n[p, best[p]]
+        assert out[p]["cost"] == costs[p, best[p]]
+        np.testing.assert_array_equal(out[p]["path"], paths[p, best[p], :n[p, best[p]]])
+    hip.close()

@@ -1,0 +1,99 @@
+// plan_task.cpp -- head-less run of a task file through the planner node
+// mirror (include/bimanual_planning_ros/planner_node.h): the controller is
+// replaced by "set-point reached" echo, obstacles move like
+// dynamic_obstacle_node. Prints one line per tick:
+//   <tick> <best index> <x> <y> <z> <goal distance>
+// usage: plan_task <task.yaml> --start x y z [--max-ticks N] [--seed S] [--random-vecs f.bin] [--dump-params]
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "bimanual_planning_ros/planner_node.h"
+
+using namespace ghostplanner::cfplanner;
+
+static void dump(const TaskParams &t) {
+  printf("{\"num_agents_ee\": %d, \"num_agents_body\": %d, \"k_attr\": %.17g, \"k_circ\": %.17g, \"k_repel\": %.17g, "
+         "\"k_damp\": %.17g, \"k_manip\": %.17g, \"k_repel_body\": %.17g, \"k_goal_dist\": %.17g, \"k_path_len\": %.17g, "
+         "\"k_safe_dist\": %.17g, \"k_workspace\": %.17g, \"max_prediction_steps\": %d, \"prediction_freq_multiple\": %d, "
+         "\"approach_dist\": %.17g, \"detect_shell_rad\": %.17g, \"frequency_ros\": %.17g, \"velocity\": %.17g, "
+         "\"open_loop\": %s, \"desired_ws_limits\": [",
+         t.num_agents_ee, t.num_agents_body, t.k_attr, t.k_circ, t.k_repel, t.k_damp, t.k_manip, t.k_repel_body,
+         t.k_goal_dist, t.k_path_len, t.k_safe_dist, t.k_workspace, t.max_prediction_steps, t.prediction_freq_multiple,
+         t.approach_dist, t.detect_shell_rad, t.frequency_ros, t.velocity, t.open_loop ? "true" : "false");
+  for (int i = 0; i < 6; ++i) printf("%s%.17g", i ? ", " : "", t.desired_ws_limits(i));
+  printf("], \"obstacles\": [");
+  for (size_t i = 0; i < t.obstacles.size(); ++i) {
+    Vector3d p = t.obstacles[i].getPosition(), v = t.obstacles[i].getVelocity();
+    printf("%s[%.17g, %.17g, %.17g, %.17g, %.17g, %.17g, %.17g]", i ? ", " : "", p[0], p[1], p[2], v[0], v[1], v[2],
+           t.obstacles[i].getRadius());
+  }
+  printf("], \"goals\": [");
+  for (size_t i = 0; i < t.goals.size(); ++i) {
+    const GoalSpec &g = t.goals[i];
+    printf("%s{\"type\": \"%s\", \"end_condition\": \"%s\", \"pos\": [%.17g, %.17g, %.17g], \"overrides\": {", i ? ", " : "",
+           g.type.c_str(), g.end_condition.c_str(), g.pos[0], g.pos[1], g.pos[2]);
+    bool first = true;
+    for (auto &kv : g.overrides) { printf("%s\"%s\": %.17g", first ? "" : ", ", kv.first.c_str(), kv.second); first = false; }
+    printf("}}");
+  }
+  printf("]}\n");
+}
+
+int main(int argc, char **argv) {
+  if (argc < 2) { fprintf(stderr, "usage: plan_task <task.yaml> --start x y z [--max-ticks N] [--seed S] [--dump-params]\n"); return 2; }
+  double start[3] = {0, 0, 0};
+  long max_ticks = 5000;
+  unsigned long long seed = 1;
+  bool dump_only = false;
+  const char *rv_file = nullptr;
+  for (int i = 2; i < argc; ++i) {
+    if (!strcmp(argv[i], "--start") && i + 3 < argc) { for (int c = 0; c < 3; ++c) start[c] = atof(argv[++i]); }
+    else if (!strcmp(argv[i], "--max-ticks") && i + 1 < argc) max_ticks = atol(argv[++i]);
+    else if (!strcmp(argv[i], "--seed") && i + 1 < argc) seed = strtoull(argv[++i], nullptr, 10);
+    else if (!strcmp(argv[i], "--dump-params")) dump_only = true;
+    else if (!strcmp(argv[i], "--random-vecs") && i + 1 < argc) rv_file = argv[++i];
+  }
+  try {
+    TaskParams task = loadTaskFile(argv[1]);
+    if (dump_only) { dump(task); return 0; }
+    PlannerNode node(task, seed);
+    if (rv_file) {  // explicit Random-agent vectors [N][n_obs][3] (tests)
+      std::vector<double> rv((size_t)task.num_agents_ee * task.obstacles.size() * 3);
+      FILE *f = fopen(rv_file, "rb");
+      if (!f || fread(rv.data(), sizeof(double), rv.size(), f) != rv.size()) throw std::runtime_error("cannot read --random-vecs file");
+      fclose(f);
+      node.manager().setRandomVectors(rv);
+    }
+    DynamicObstacleSource source(task.obstacles, task.frequency_ros);
+    Position position{{start[0], start[1], start[2]}};
+    node.planCallback(position, nullptr);              // planning not active: records the initial position
+    long tick = 0;
+    for (const GoalSpec &goal : task.goals) {
+      if (goal.type != "plan") continue;               // key / gesture / goto ...: operator or robot actions
+      Position sp = node.startPlan(goal);
+      position = Position{{sp.data[0], sp.data[1], sp.data[2] - 0.00001}};
+      Vector3d prev(position.data[0], position.data[1], position.data[2]);
+      while (tick < max_ticks) {
+        int best = -1;
+        Position next;
+        node.planCallback(position, &next, &best);     // controller is ready for the next set-point
+        Vector3d nv(next.data[0], next.data[1], next.data[2]);
+        std::string why;
+        if (!validateSetPoint(prev, nv, &why)) fprintf(stderr, "tick %ld: rejected by the consumer contract: %s\n", tick, why.c_str());
+        printf("%ld %d %.17g %.17g %.17g %.17g\n", tick, best, next.data[0], next.data[1], next.data[2], node.goalDistance());
+        prev = nv;
+        position = next;                               // echo: the set-point is reached
+        node.obstacleCallback(source.step());          // obstacle stream between ticks
+        ++tick;
+        if (goal.end_condition == "reached" && node.reached()) break;
+      }
+      node.finishGoal();
+      printf("# goal %s after %ld ticks, distance %.6g\n", node.reached() ? "reached" : "not reached", tick, node.goalDistance());
+    }
+  } catch (const std::exception &e) {
+    fprintf(stderr, "plan_task: %s\n", e.what());
+    return 1;
+  }
+  return 0;
+}

@@ -29,6 +29,7 @@
 #include "../../include/pmaf.h"
 #include "pmaf_device.hpp"
 #include "pmaf_rollout_w64.hpp"
+#include "pmaf_rollout_grp.hpp"
 
 using namespace pmaf;
 
@@ -328,6 +329,145 @@ __global__ __launch_bounds__(64) void k_rollout_w64(DevView D, CostParams CP) {
     case T_RANDOM: rollout_w64_body<TILES, T_RANDOM, FAST>(D, CP, lane, pop, a); break;
     case T_HAD: rollout_w64_body<TILES, T_HAD, FAST>(D, CP, lane, pop, a); break;
     default: break;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// k_rollout_grp<LPA, TILES>: 64/LPA agents per wave (see pmaf_rollout_grp.hpp)
+// ---------------------------------------------------------------------------
+template <int LPA, int TILES>
+__global__ __launch_bounds__(64) void k_rollout_grp(DevView D, CostParams CP) {
+  extern __shared__ double smem[];
+  constexpr int APW = 64 / LPA;
+  const int lane = threadIdx.x;
+  const int pop = blockIdx.y;
+  const int sub = lane % LPA;
+  const int grp = lane / LPA;
+  const int a = blockIdx.x * APW + grp;
+  const bool active = a < D.N;
+  const int aa = active ? a : 0;
+  const int n_obs = D.n_obs;
+  const int M = n_obs - 1;
+  const PopConst C = D.C;
+  const size_t pa = (size_t)pop * D.N + aa;
+  const int type = D.types[aa];
+  // the "closest other obstacle" search of Obstacle / GoalObstacle agents reads the LDS table
+  const bool wave_needs_table = __any(active && (type == T_OBST || type == T_GOALOBST));
+
+  ObsTab T = carve_obstab(smem, n_obs);
+  const double *src = D.obs_start + (size_t)pop * 7 * n_obs;
+  const int32_t *ks = D.known_start + (size_t)pop * n_obs;
+  double *rot_g = D.rot + pa * 3 * n_obs;
+  const double *rnd_g = D.rnd + pa * 3 * n_obs;
+
+  // LDS table of obstacle positions, maintained by lanes l = obstacle index (mod 64)
+  if (wave_needs_table) {
+    for (int i = lane; i < 3 * n_obs; i += 64) smem[i] = src[i];
+  }
+  LaneObstacles<TILES> O;
+  unsigned known_bits = 0u;
+#pragma unroll
+  for (int t = 0; t < TILES; t++) {
+    int i = t * LPA + sub;
+    bool valid = i < M;
+    int ii = valid ? i : 0;
+    O.p[t] = mk(src[ii], src[n_obs + ii], src[2 * n_obs + ii]);
+    O.v[t] = mk(src[3 * n_obs + ii], src[4 * n_obs + ii], src[5 * n_obs + ii]);
+    O.r[t] = src[6 * n_obs + ii];
+    O.rx[t] = rot_g[ii]; O.ry[t] = rot_g[n_obs + ii]; O.rz[t] = rot_g[2 * n_obs + ii];
+    O.qx[t] = rnd_g[ii]; O.qy[t] = rnd_g[n_obs + ii]; O.qz[t] = rnd_g[2 * n_obs + ii];
+    if (valid && ks[ii]) known_bits |= (1u << t);
+  }
+  V3 sent_p = mk(src[M], src[n_obs + M], src[2 * n_obs + M]);
+  const V3 sent_v = mk(src[3 * n_obs + M], src[4 * n_obs + M], src[5 * n_obs + M]);
+  const double sent_r = src[6 * n_obs + M];
+  wave_lds_fence();
+
+  const V3 goal = mk(D.goal[pop * 3], D.goal[pop * 3 + 1], D.goal[pop * 3 + 2]);
+  const V3 init_pos = mk(D.agent_init_pos[pop * 3], D.agent_init_pos[pop * 3 + 1], D.agent_init_pos[pop * 3 + 2]);
+  V3 p = mk(D.start_pos[pop * 3], D.start_pos[pop * 3 + 1], D.start_pos[pop * 3 + 2]);
+  V3 v = mk(D.start_vel[pop * 3], D.start_vel[pop * 3 + 1], D.start_vel[pop * 3 + 2]);
+  const double k_attr = D.k_attr[pa], k_circ = D.k_circ[pa], k_repel = D.k_repel[pa], k_damp = D.k_damp[pa];
+  double *path = D.paths + pa * (size_t)D.cap * 3;
+  const double zsent_lt = D.zsent_lt[pop];
+
+  int clist_off = 7 * n_obs + (n_obs + 1) / 2;
+  clist_off += clist_off & 1;
+  double *clist = smem + clist_off + (size_t)grp * (LPA * TILES * 4);
+
+  double lane_min = C.shell;
+  double cost_ws = 0.0;
+  double path_len = 0.0;
+  int n = 1;
+  bool ran = false;
+  ws_cost_add(cost_ws, p, CP.ws, CP.k_workspace);
+  if (active && sub == 0) { path[0] = p.x; path[1] = p.y; path[2] = p.z; }
+
+  V3 g = goal - p;
+  double dg = norm(g);
+  double zv = sqn(v);
+  double z_init = sqn(p - init_pos);
+  while (true) {
+    const bool run = active && (dg > 0.1) && (n < D.cap);  // B/src/cf_agent.cpp:310-311, per agent
+    if (!__any(run)) break;
+    const bool gate = !(dg < C.approach || (zv < C.zvhalf_lt && z_init < C.zinit_lt));  // :315-317
+    const V3 verr = attractor_velocity_error<false>(v, g, C, k_attr, k_damp);
+    V3 F = mk(0.0, 0.0, 0.0);
+    double scale = 1.0;
+    if (__any(run && gate))
+      circ_and_scale_grp<LPA, TILES>(run && gate, sub, grp, type, p, v, zv, goal, g, dg, C, k_circ, T, n_obs, rot_g,
+                                     known_bits, O, clist, lane_min, F, scale);
+    V3 new_pos;
+    V3 nv = v;
+    finish_step_w64<false>(p, nv, verr, F, scale, C, k_attr, k_repel, k_damp, sent_p, sent_r, zsent_lt, new_pos);
+    if (run) {
+      const V3 dp = new_pos - p;
+      p = new_pos;
+      v = nv;
+      g = goal - p;
+      path_len += norm(dp);
+      dg = norm(g);
+      zv = sqn(v);
+      z_init = sqn(p - init_pos);
+      ws_cost_add(cost_ws, p, CP.ws, CP.k_workspace);
+      if (sub == 0) { path[n * 3] = p.x; path[n * 3 + 1] = p.y; path[n * 3 + 2] = p.z; }
+      n++;
+      ran = true;
+    }
+    // predictObstacles, B/src/cf_agent.cpp:270-276, in registers (+ the LDS table when a latch may search it)
+#pragma unroll
+    for (int t = 0; t < TILES; t++) O.p[t] = O.p[t] + O.v[t] * C.dt;
+    sent_p = sent_p + sent_v * C.dt;
+    if (wave_needs_table) {
+      // table entry i is advanced by lane i (mod 64) with the same arithmetic
+      for (int i = lane; i < M; i += 64) {
+        T.px[i] = T.px[i] + src[3 * n_obs + i] * C.dt;
+        T.py[i] = T.py[i] + src[4 * n_obs + i] * C.dt;
+        T.pz[i] = T.pz[i] + src[5 * n_obs + i] * C.dt;
+      }
+      wave_lds_fence();
+    }
+  }
+
+  const double min_obs = group_min_dpp<LPA>(lane_min);
+  if (active) {
+    int32_t *ko = D.known_out + pa * n_obs;
+#pragma unroll
+    for (int t = 0; t < TILES; t++) {
+      int i = t * LPA + sub;
+      if (i < M) ko[i] = (int32_t)((known_bits >> t) & 1u);
+    }
+    if (sub == 0) {
+      ko[M] = ks[M];
+      D.n_points[pa] = n;
+      D.agent_vel[pa * 3] = v.x; D.agent_vel[pa * 3 + 1] = v.y; D.agent_vel[pa * 3 + 2] = v.z;
+      D.min_obs[pa] = min_obs;
+      D.cost_ws[pa] = cost_ws;
+      D.path_len[pa] = path_len;
+      D.goal_dist[pa] = dg;
+      if (ran) D.reached[pa] = dg < 0.100001;  // B/src/cf_agent.cpp:330-337
+      atomicAdd(D.step_counter, (unsigned long long)(n - 1));
+    }
   }
 }
 
@@ -743,6 +883,14 @@ static void launch_rollout(pmaf_planner *h) {
       if (tiles64 <= 1) PMAF_W64(1, false); else if (tiles64 == 2) PMAF_W64(2, false); else PMAF_W64(4, false);
     }
 #undef PMAF_W64
+  } else if (!h->force_generic && (h->lpa == 32 || h->lpa == 16 || h->lpa == 8) &&
+             (h->D.n_obs - 1 + h->lpa - 1) / h->lpa <= 4) {
+    const int tl = (h->D.n_obs - 1 + h->lpa - 1) / h->lpa;
+#define PMAF_GRP(L, T) hipLaunchKernelGGL((k_rollout_grp<L, T>), grid, block, h->lds_rollout, h->stream, h->D, h->cp)
+#define PMAF_GRP_T(L) do { if (tl <= 1) PMAF_GRP(L, 1); else if (tl == 2) PMAF_GRP(L, 2); else PMAF_GRP(L, 4); } while (0)
+    if (h->lpa == 32) PMAF_GRP_T(32); else if (h->lpa == 16) PMAF_GRP_T(16); else PMAF_GRP_T(8);
+#undef PMAF_GRP_T
+#undef PMAF_GRP
   } else
   switch (h->lpa) {
 #define PMAF_CASE(L) case L: hipLaunchKernelGGL((k_rollout<L>), grid, block, h->lds_rollout, h->stream, h->D, h->cp); break;

@@ -1,0 +1,149 @@
+// pmaf_rollout_grp.hpp -- k_rollout_grp<LPA, TILES>: the throughput shape of
+// the rollout (many agents / populations, e.g. BASELINE C5 = 8 x 1024 agents):
+// 64/LPA agents per wave64, each evaluated by a group of LPA = 8, 16 or 32
+// adjacent lanes that split the obstacle sweep (TILES = ceil(M/LPA) <= 4 slots
+// per lane). Same techniques and the same arithmetic as the wave-per-agent
+// kernel (pmaf_rollout_w64.hpp): obstacle / rotation / random vectors of the
+// lane's slots in registers, no barriers in the step loop, the reference's
+// sequential force sum reproduced through a per-group LDS list, group
+// reductions by DPP (quad_perm, row_half_mirror, row_mirror) + ds_swizzle.
+// Per-agent values are held replicated in the group's lanes; per-agent control
+// flow (loop guard, gate, scaling cases, agent type) is predicated, with
+// wave-level __any() guards around the expensive regions. Against the w64
+// kernel this divides the redundantly executed per-agent ("scalar") part and
+// the idle lanes of the sweep by 64/LPA, which is what matters once the chip
+// is full of waves (FP64-VALU issue bound).
+#pragma once
+#include "pmaf_device.hpp"
+#include "pmaf_rollout_w64.hpp"
+
+namespace pmaf {
+
+__device__ __forceinline__ double swz16_d(double v) {  // lane ^ 16
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_ds_swizzle(lo, 0x401F);
+  hi = __builtin_amdgcn_ds_swizzle(hi, 0x401F);
+  return __hiloint2double(hi, lo);
+}
+
+// minimum over the LPA lanes of each group, result in every lane of the group
+template <int LPA>
+__device__ __forceinline__ double group_min_dpp(double v) {
+  v = sel_min(v, dpp_d<0xB1, 0xf>(v));
+  v = sel_min(v, dpp_d<0x4E, 0xf>(v));
+  v = sel_min(v, dpp_d<0x141, 0xf>(v));
+  if (LPA >= 16) v = sel_min(v, dpp_d<0x140, 0xf>(v));
+  if (LPA >= 32) v = sel_min(v, swz16_d(v));
+  return v;
+}
+template <int LPA>
+__device__ __forceinline__ int group_min_dpp_i(int v) {
+  int o;
+  o = dpp_i<0xB1, 0xf>(v); v = o < v ? o : v;
+  o = dpp_i<0x4E, 0xf>(v); v = o < v ? o : v;
+  o = dpp_i<0x141, 0xf>(v); v = o < v ? o : v;
+  if (LPA >= 16) { o = dpp_i<0x140, 0xf>(v); v = o < v ? o : v; }
+  if (LPA >= 32) { o = __builtin_amdgcn_ds_swizzle(v, 0x401F); v = o < v ? o : v; }
+  return v;
+}
+
+// circForce + attractorForceScaling for the agents of one wave. `act`: the
+// lane's agent takes a step and its gate is open (uniform within the group).
+// clist: this GROUP's list in LDS (LPA*TILES entries of 4 doubles).
+template <int LPA, int TILES>
+__device__ __forceinline__ void circ_and_scale_grp(bool act, int sub, int grp, int type, V3 p, V3 v, double zv,
+                                                   V3 goal, V3 g, double dg, const PopConst &C, double k_circ,
+                                                   const ObsTab &T, int n_obs, double *rot_g, unsigned &known_bits,
+                                                   LaneObstacles<TILES> &O, double *clist, double &lane_min, V3 &F,
+                                                   double &scale) {
+  const int M = n_obs - 1;
+  const V3 gn = (dg > 0.0) ? (g / dg) : g;
+  double best_d = C.shell;
+  double best_s = 0.0, best_gr = 0.0;
+  int best_i = 0x7fffffff;
+  int count = 0;
+  const unsigned long long gmask = ((1ull << LPA) - 1ull) << (grp * LPA);
+  const unsigned long long below = gmask & ((1ull << (grp * LPA + sub)) - 1ull);
+#pragma unroll
+  for (int t = 0; t < TILES; t++) {
+    const int i = t * LPA + sub;
+    const bool valid = act && (i < M);
+    const V3 op = O.p[t];
+    const V3 ro = op - p;
+    const V3 rv = v - O.v[t];
+    const double z = sqn(ro);
+    const double s = __builtin_sqrt(z);
+    const V3 ron = (z > 0.0) ? (ro / s) : ro;
+    const bool skip = (dot(ron, gn) < -0.01) && (dot(ro, rv) < -0.01);
+    double d = s - (C.rad + O.r[t]);
+    d = smax(d, 1e-5);
+    if (valid && d < best_d) { best_d = d; best_i = i; best_s = s; best_gr = dot(g, ro); }
+    const bool live = valid && !skip;
+    if (live && d < lane_min) lane_min = d;
+    const bool in_shell = live && (d < C.shell);
+    if (__any(in_shell)) {
+      const bool need_latch = in_shell && !((known_bits >> t) & 1u);
+      if (__any(need_latch)) {
+        if (need_latch) {
+          V3 rot = calc_rot_vec(type, p, goal, T, n_obs, i, op, mk(O.qx[t], O.qy[t], O.qz[t]));
+          rot_g[i] = rot.x; rot_g[n_obs + i] = rot.y; rot_g[2 * n_obs + i] = rot.z;
+          O.rx[t] = rot.x; O.ry[t] = rot.y; O.rz[t] = rot.z;
+          known_bits |= (1u << t);
+        }
+      }
+      const V3 rot = mk(O.rx[t], O.ry[t], O.rz[t]);
+      const double vn = norm(rv);
+      const V3 nv = rv / vn;
+      const V3 cur = current_vector(type, rv, g, ron, rot);
+      const V3 c = (k_circ / (d * d)) * cross(nv, cross(cur, nv));
+      const bool has_c = in_shell && (vn != 0);
+      const unsigned long long m = __ballot(has_c);
+      if (has_c) {
+        double *e = clist + (size_t)(count + __popcll(m & below)) * 4;
+        e[0] = c.x; e[1] = c.y; e[2] = c.z;
+      }
+      count += __popcll(m & gmask);
+    }
+  }
+  const double m = group_min_dpp<LPA>(best_d);
+  if (__any(count > 0)) {
+    wave_lds_fence();
+    // F = ((0 + c_0) + c_1) + ... per group; a group that has run out of terms adds +0.0 (exact no-op)
+    for (int k = 0; __any(k < count); k += 4) {
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const bool more = (k + j) < count;
+        const double *e = clist + (size_t)(more ? (k + j) : 0) * 4;
+        const double cx = e[0], cy = e[1], cz = e[2];
+        F.x = F.x + (more ? cx : 0.0);
+        F.y = F.y + (more ? cy : 0.0);
+        F.z = F.z + (more ? cz : 0.0);
+      }
+    }
+    wave_lds_fence();
+  }
+  const bool want_scale = act && (sqn(F) >= C.zf_gt);  // norm(F) > 1e-5
+  if (__any(want_scale)) {
+    const bool cand = (best_i != 0x7fffffff) && (best_d == m);
+    const int bi = group_min_dpp_i<LPA>(cand ? best_i : 0x7fffffff);
+    const int src = grp * LPA + ((bi == 0x7fffffff) ? 0 : (bi & (LPA - 1)));
+    // closest obstacle's |ro| and g.ro live in the owning lane's slot registers
+    // of tile bi / LPA; its best_* registers hold them iff that lane's own
+    // minimum is this obstacle -- true by construction of cand
+    const double sb = __shfl(best_s, src), gr = __shfl(best_gr, src);
+    double sc = 1.0;
+    if (bi == 0x7fffffff) {
+      sc = 1;
+    } else if (dot(g, v) <= 0.0 && zv < C.zv09_lt && dg > 0.15) {
+      sc = 0.0;
+    } else {
+      const double w1 = 1 - portable_exp<false>(-__builtin_sqrt(m) / C.shell);
+      double w2 = 1 - (gr / (dg * sb));
+      w2 = w2 * w2;
+      sc = w1 * w2;
+    }
+    if (want_scale) scale = sc;
+  }
+}
+
+}  // namespace pmaf

@@ -62,6 +62,9 @@ def lib():
         L.orc_agent_steps.restype = C.c_int64
         L.orc_agent_steps.argtypes = [C.c_void_p]
         L.orc_set_exp_mode.argtypes = [C.c_int]
+        L.orc_rollout_omp.argtypes = [C.c_void_p, C.c_int]
+        L.orc_tick_omp.restype = C.c_int
+        L.orc_tick_omp.argtypes = [C.c_void_p, _dp, C.c_double, _dp, _dp, C.c_int]
         L.pmaf_portable_exp.restype = C.c_double
         L.pmaf_portable_exp.argtypes = [C.c_double]
         _LIB = L
@@ -156,6 +159,12 @@ class OraclePlanner:
         _, g = _d(cost_gains)
         _, w = _d(ws)
         return self._L.orc_tick(self._h, o, float(dt), g, w)
+
+    def tick_omp(self, obstacles, dt, cost_gains, ws, n_threads):
+        _, o = _d(obstacles)
+        _, g = _d(cost_gains)
+        _, w = _d(ws)
+        return self._L.orc_tick_omp(self._h, o, float(dt), g, w, int(n_threads))
 
     def link_force(self, link_pos, k_r_force, obstacles):
         lp, lp_p = _d(link_pos)

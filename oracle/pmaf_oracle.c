@@ -513,6 +513,29 @@ void orc_rollout_range(orc_planner *p, int a0, int a1) {
 
 void orc_rollout(orc_planner *p) { orc_rollout_range(p, 0, p->n_agents); }
 
+/* all agents' rollouts on n_threads OpenMP threads (agents are independent,
+ * like the reference's thread per agent, B/src/cf_manager.cpp:118-123); used
+ * by the multi-core CPU baseline of bench.py */
+void orc_rollout_omp(orc_planner *p, int n_threads) {
+  int64_t steps = 0;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(n_threads) reduction(+ : steps)
+  for (int i = 0; i < p->n_agents; i++) steps += run_prediction(p, i);
+  p->agent_steps += steps;
+}
+
+/* planCallback sequence with the multi-threaded rollout */
+int orc_tick_omp(orc_planner *p, const double *obstacles, double dt, const double *cost_gains, const double *ws,
+                 int n_threads) {
+  int best = orc_evaluate(p, cost_gains[0], cost_gains[1], cost_gains[2], cost_gains[3], ws);
+  orc_move_real(p, obstacles, dt, 1, best);
+  v3 np = latest(&p->real);
+  double pos[3] = {np.x, np.y, np.z};
+  double vel[3] = {p->real.vel.x, p->real.vel.y, p->real.vel.z};
+  orc_reset_agents(p, pos, vel, obstacles);
+  orc_rollout_omp(p, n_threads);
+  return best;
+}
+
 /* CfAgent::getPathLength, B/src/cf_agent.cpp:26-32 */
 static double path_length(const agent_t *a) {
   double len = 0;

@@ -80,6 +80,11 @@ void orc_rollout(orc_planner *p);
 /* As orc_rollout but only agents [a0,a1) -- used by the threaded CPU baseline. */
 void orc_rollout_range(orc_planner *p, int a0, int a1);
 
+/* orc_rollout on n_threads OpenMP threads; orc_tick with that rollout */
+void orc_rollout_omp(orc_planner *p, int n_threads);
+int orc_tick_omp(orc_planner *p, const double *obstacles, double dt, const double *cost_gains, const double *ws,
+                 int n_threads);
+
 /* CfManager::evaluateAgents, B/src/cf_manager.cpp:293-356. ws = [xmax,xmin,ymax,ymin,zmax,zmin] */
 int orc_evaluate(orc_planner *p, double k_goal_dist, double k_path_len,
                  double k_safe_dist, double k_workspace, const double *ws);

@@ -653,6 +653,17 @@ __global__ __launch_bounds__(64) void k_manager(DevView D, CostParams CP, Manage
   }
 }
 
+// CfAgent::setPosition for every predicted agent (clear + push_back,
+// B/src/cf_agent.cpp:39-42): 1-point paths at pos[pop]
+__global__ void k_restart_paths(DevView D, const double *pos) {
+  int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= D.P * D.N) return;
+  int pop = idx / D.N;
+  double *path = D.paths + (size_t)idx * D.cap * 3;
+  path[0] = pos[pop * 3]; path[1] = pos[pop * 3 + 1]; path[2] = pos[pop * 3 + 2];
+  D.n_points[idx] = 1;
+}
+
 // CfAgent::bodyForce -> repelForce, B/src/cf_agent.cpp:229-234, 159-181
 __global__ void k_link_force(int n, const double *link_pos, const double *k_r, const double *sent /*7*/,
                              double rad, double shell, double *out) {
@@ -1186,15 +1197,11 @@ int pmaf_set_initial_position(pmaf_planner *h, const double *pos) {
     h->upload(D.real_pos, pos, P * 3);
     h->upload(D.start_pos, pos, P * 3);
     // CfAgent::setPosition = clear + push_back for every predicted agent
-    std::vector<int32_t> np((size_t)P * N, 1);
-    h->upload(D.n_points, np.data(), np.size());
-    for (int p = 0; p < P; p++) {
-      for (int a = 0; a < N; a++)
-        HIP_CHECK(hipMemcpyAsync(D.paths + ((size_t)p * N + a) * cap * 3, pos + p * 3, sizeof(double) * 3,
-                                 hipMemcpyHostToDevice, h->stream));
-      // RealCfAgent::setPosition = push_back
+    hipLaunchKernelGGL(k_restart_paths, dim3((P * N + 255) / 256), dim3(256), 0, h->stream, D, D.start_pos);
+    HIP_CHECK(hipGetLastError());
+    (void)cap;
+    for (int p = 0; p < P; p++)  // RealCfAgent::setPosition = push_back
       h->real_path[p].insert(h->real_path[p].end(), {pos[p * 3], pos[p * 3 + 1], pos[p * 3 + 2]});
-    }
     sync(h);
     h->scores_valid = false;
     h->rollout_pending = true;

@@ -86,3 +86,43 @@ def merge_agent_ranges(costs_per_rank, prev_best_global):
             return min_idx
         return prev_best_global
     return min_idx
+
+
+class DualArmCoupling:
+    """BASELINE config 4 (build-defined): two independent agent
+    populations, one per arm; each arm's trailing repulsive obstacle (the
+    reference's "self collision" sphere, README.md:80) follows the OTHER arm's
+    current end-effector position. Works on any set of planner objects exposing
+    tick()/real_state(): two populations in one handle on one GPU, or one
+    population per rank with the set-points exchanged by a 3-double all-gather.
+
+    tick(k) uses the other arm's position after tick k-1 (the positions both
+    arms published last), so the arms stay independent within a tick."""
+
+    def __init__(self, obstacles, self_collision_radius=0.1):
+        # obstacles: [2][n_obs][7], row -1 of each arm is replaced every tick
+        self.obstacles = np.array(obstacles, dtype=np.float64, copy=True)
+        self.radius = self_collision_radius
+
+    def coupled_obstacles(self, ee_positions, advance=None):
+        """ee_positions [2][3] = both arms' current real-agent positions"""
+        obs = self.obstacles
+        if advance is not None:
+            obs = np.stack([advance(o) for o in obs])
+        for arm in (0, 1):
+            obs[arm, -1, 0:3] = ee_positions[1 - arm]
+            obs[arm, -1, 3:6] = 0.0
+            obs[arm, -1, 6] = self.radius
+        self.obstacles = obs
+        return obs
+
+
+def all_gather_positions(local_pos, dist, world):
+    """[P_local][3] set-points of every rank -> [world*P_local][3] (rank-major)"""
+    import torch
+    local = torch.as_tensor(np.ascontiguousarray(local_pos, dtype=np.float64))
+    out = torch.empty((world * local.shape[0], 3), dtype=torch.float64)
+    if dist is None or world == 1:
+        return local.numpy()
+    dist.all_gather_into_tensor(out, local)
+    return out.numpy()

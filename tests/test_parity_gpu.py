@@ -457,3 +457,47 @@ def test_winner_records_written_on_device(pmaf, oracle, scenes):
         assert out[p]["cost"] == costs[p, best[p]]
         np.testing.assert_array_equal(out[p]["path"], paths[p, best[p], :n[p, best[p]]])
     hip.close()
+
+
+def test_c4_dual_arm_two_coupled_populations(pmaf, oracle, scenes):
+    """BASELINE config 4 on one GPU: 2 x 256 agents, each arm's repulsive
+    self-collision sphere tracks the other arm's end effector
+    (shard.DualArmCoupling); both arms against two coupled oracles, bit-exact."""
+    scs = []
+    for arm, (y0, y1) in enumerate(((-0.12, 0.10), (0.12, -0.10))):
+        s = scenes.synthetic_scene(256, 150, 24, 4, arm)
+        s["start"] = np.array([-0.45, y0, 0.7])
+        s["goal"] = np.array([0.45, y1, 0.7])  # the arms' paths cross -> the spheres come into range
+        scs.append(s)
+    starts = np.stack([s["start"] for s in scs])
+    hip = pmaf.PmafPlanner(scs, device=0, mgr_init_pos=starts)
+    hip.set_initial_position(starts)
+    oras = []
+    for s in scs:
+        o = oracle.OraclePlanner(s, mgr_init_pos=s["start"])
+        o.set_initial_position(s["start"])
+        oras.append(o)
+    ch = pmaf.shard.DualArmCoupling(np.stack([s["obstacles"] for s in scs]), 0.1)
+    co = pmaf.shard.DualArmCoupling(np.stack([s["obstacles"] for s in scs]), 0.1)
+    sc = scs[0]
+    pos_h, pos_o = starts.copy(), starts.copy()
+    min_gap = 1e9
+    for t in range(260):
+        oh = ch.coupled_obstacles(pos_h)
+        oo = co.coupled_obstacles(pos_o)
+        bh = hip.tick(oh, sc["dt"], sc["cost_gains"], sc["ws_limits"])
+        bo = [o.tick(oo[i], sc["dt"], sc["cost_gains"], sc["ws_limits"]) for i, o in enumerate(oras)]
+        np.testing.assert_array_equal(bh, bo)
+        pos_h = hip.real_state()[0].copy()
+        pos_o = np.stack([o.real_state()[0] for o in oras])
+        np.testing.assert_array_equal(pos_h, pos_o)
+        min_gap = min(min_gap, np.linalg.norm(pos_h[0] - pos_h[1]))
+    ph, nh = hip.paths()
+    for i, o in enumerate(oras):
+        po, no = o.paths()
+        np.testing.assert_array_equal(nh[i], no)
+        np.testing.assert_array_equal(ph[i], po)
+    # the coupling was exercised: the two end effectors came within the detection shell
+    assert min_gap < sc["detect_shell_rad"] + 0.15
+    print("dual arm: closest approach of the two end effectors %.3f m" % min_gap)
+    hip.close()

@@ -116,3 +116,75 @@ def test_agent_range_merge_equals_single_population_selection(oracle, scenes):
     assert shard.merge_agent_ranges([np.array([3.0, 2.0]), np.array([2.0, 5.0])], None) == 1
     assert shard.merge_agent_ranges([np.array([3.0, 2.0]), np.array([1.9, 5.0])], 1) == 1  # 1.9 !< 0.9*2.0
     assert shard.merge_agent_ranges([np.array([3.0, 2.0]), np.array([1.7, 5.0])], 1) == 2
+
+
+def _arm_scene(pkg, arm):
+    s = pkg.scenes.synthetic_scene(16, 60, 10, 4, arm)
+    s["start"] = np.array([-0.45, -0.12 if arm == 0 else 0.12, 0.7])
+    s["goal"] = np.array([0.45, 0.10 if arm == 0 else -0.10, 0.7])
+    return s
+
+
+def _dual_worker(rank, world, port, ticks, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    import __graft_entry__ as graft
+    from oracle import orc
+    pkg = graft.load_package()
+    shard = __import__("pmaf_amd.shard", fromlist=["shard"])
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    scs = [_arm_scene(pkg, a) for a in range(2)]
+    sc = scs[rank]
+    o = orc.OraclePlanner(sc, mgr_init_pos=sc["start"])
+    o.set_initial_position(sc["start"])
+    coupling = shard.DualArmCoupling(np.stack([s["obstacles"] for s in scs]), 0.1)
+    pos = np.stack([s["start"] for s in scs])
+    out = []
+    for t in range(ticks):
+        obs = coupling.coupled_obstacles(pos)
+        o.tick(obs[rank], sc["dt"], sc["cost_gains"], sc["ws_limits"])
+        pos = shard.all_gather_positions(o.real_state()[0][None, :], dist, world)  # one 3-double exchange per tick
+        out.append(pos.copy())
+    q.put((rank, np.stack(out)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_dual_arm_one_population_per_rank_world2():
+    """BASELINE config 4 layout: arm r on rank r, set-points exchanged with one
+    all-gather per tick; must equal the single-process coupled run"""
+    import torch.multiprocessing as mp
+    world, ticks = 2, 40
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_dual_worker, args=(r, world, port, ticks, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    np.testing.assert_array_equal(results[0], results[1])
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as graft
+    from oracle import orc
+    pkg = graft.load_package()
+    shard = __import__("pmaf_amd.shard", fromlist=["shard"])
+    scs = [_arm_scene(pkg, a) for a in range(2)]
+    oras = []
+    for s in scs:
+        o = orc.OraclePlanner(s, mgr_init_pos=s["start"])
+        o.set_initial_position(s["start"])
+        oras.append(o)
+    coupling = shard.DualArmCoupling(np.stack([s["obstacles"] for s in scs]), 0.1)
+    pos = np.stack([s["start"] for s in scs])
+    for t in range(ticks):
+        obs = coupling.coupled_obstacles(pos)
+        for i, o in enumerate(oras):
+            o.tick(obs[i], scs[i]["dt"], scs[i]["cost_gains"], scs[i]["ws_limits"])
+        pos = np.stack([o.real_state()[0] for o in oras])
+        np.testing.assert_array_equal(results[0][t], pos)

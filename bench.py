@@ -223,7 +223,9 @@ def main():
                                    % (args.config, N, H, n_obs - 1, P, "moving" if args.dynamic else "static"),
                        "agents": N, "horizon": H, "obstacles": n_obs - 1, "populations_per_gpu": P,
                        "parallelism": "population-per-gpu x%d" % world,
-                       "lanes_per_agent": cfg["lanes_per_agent"], "rollout_blocks": cfg["n_blocks"]},
+                       "lanes_per_agent": cfg["lanes_per_agent"], "rollout_blocks": cfg["n_blocks"],
+                       "arithmetic": "f64, hand-expanded IEEE div/sqrt sequences (default policy; bit-identical to "
+                                     "the CPU oracle)"},
             "agent_steps_per_s": agent_steps / max(launches, 1) * world * args.steps / elapsed,
             "h_eff": steps_per_launch / (N * P),
             "tick_latency_us": {"median": float(np.median(lat) * 1e6), "p99": float(np.percentile(lat, 99) * 1e6)},

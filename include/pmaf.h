@@ -27,6 +27,8 @@
  *    is available from pmaf_last_error(). Nothing throws across the ABI.
  *  - a handle is not thread-safe (neither is CfManager: all calls come from the
  *    single-threaded ROS spinner, B/src/panda_bimanual_control.cpp:475).
+ *  - numeric range: every input value must be finite and either 0 or
+ *    2^-100 <= |x| <= 2^100 (PMAF_ERR_INVALID otherwise).
  *  - there is NO CPU fallback: without a HIP device pmaf_create fails with
  *    PMAF_ERR_DEVICE.
  */
@@ -69,6 +71,11 @@ typedef struct pmaf_planner pmaf_planner;
  * the correctly rounded IEEE sequences. Default (flag clear) is the strict mode
  * whose results are bit-identical to the CPU restatement. */
 #define PMAF_FLAG_FAST_MATH 1
+/* Use the compiler's fully general IEEE division / sqrt expansions in the
+ * rollout kernels instead of the default hand-expanded ones (same bits for
+ * all operands within 2^+-250, which the validated input range guarantees;
+ * ~13 % slower). See csrc/pmaf_device.hpp "arithmetic policy". */
+#define PMAF_FLAG_IEEE_SEQUENCES 2
 
 /*
  * Arguments of CfManager::init (B/src/cf_manager.cpp:41-124,
@@ -211,7 +218,9 @@ int pmaf_get_launch_config(pmaf_planner *h, int32_t *lanes_per_agent,
 
 /* Self-test of the device arithmetic the parity argument rests on: evaluates
  * op over n elements ON THE GPU (0: a/b, 1: sqrt(a), 2: the kernels' portable exp(a), 3: a*b,
- * 4: a+b). Tests compare the result bitwise with the host's IEEE results. */
+ * 4: a+b; 5: the kernels' guarded sqrt, 6: guarded divide, 7 / 8: vector /
+ * scalar through the guarded / the compiler's divide). Tests compare the
+ * results bitwise with the host's IEEE results. */
 int pmaf_debug_math(int32_t op, int32_t n, const double *a, const double *b, double *out);
 
 #ifdef __cplusplus

@@ -56,16 +56,32 @@ __device__ __forceinline__ double smax(double a, double b) { return (a < b) ? b 
 __device__ __forceinline__ double smin(double a, double b) { return (b < a) ? b : a; }
 
 // ---- arithmetic policy ----------------------------------------------------
-// Mth<false>: IEEE division / square root (correctly rounded; the compiler's
-// expansions: 14 / 16 VALU instructions each). Everything bit-exact rests on it.
-// Mth<true> ("fast math", opt-in via PMAF_FLAG_FAST_MATH): v_rcp_f64 /
-// v_rsq_f64 seeds (2^-24 relative) + two Newton / Goldschmidt iterations in
-// FMA arithmetic: ~1-2 ulp per operation, 6 / 8 instructions, and one shared
-// reciprocal for a vector divided by a scalar. Results then differ from the
-// oracle in the last bits (~1e-13 m over the BASELINE horizons; the parity
-// tests for this mode assert the north-star tolerance 1e-5 m).
-template <bool FAST> struct Mth;
-template <> struct Mth<false> {
+// How divisions and square roots are evaluated in the tuned rollout kernels.
+//
+// MATH_IEEE (0)  the compiler's expansions (v_div_scale .. v_div_fmas,
+//                v_div_fixup; v_rsq + Goldschmidt with range scaling):
+//                correctly rounded for every input. They serialise on VCC and
+//                cost 65-72 / 110 cycles each on a lone wave even when several
+//                are independent (tools/ubench.hip). PMAF_FLAG_IEEE_SEQUENCES.
+// MATH_XACT (2)  DEFAULT. The same Newton / Goldschmidt iterations written out
+//                without the range-scaling instructions, one refined reciprocal
+//                shared by the three components of a vector divided by its
+//                norm, v_div_fixup for zero / infinite / NaN operands. For
+//                operands whose exponents lie within +-250 (every quantity of
+//                this path for inputs in the validated range 2^-100..2^100:
+//                lengths in metres, speeds, gains) the hardware's scaling is
+//                the identity, so these sequences return the same bits as
+//                MATH_IEEE -- the whole GPU parity suite is bit-exact in both
+//                modes and test_xact_sequences_match_ieee sweeps the range.
+//                Outside it (denormal-scale operands) results stay accurate to
+//                rounding error but are not guaranteed bit-identical.
+// MATH_FAST (1)  opt-in (PMAF_FLAG_FAST_MATH): v_rcp_f64 / v_rsq_f64 seeds
+//                (2^-24) + two Newton iterations, no residual correction:
+//                1-2 ulp per operation; tolerance parity only.
+enum : int { MATH_IEEE = 0, MATH_FAST = 1, MATH_XACT = 2 };
+
+template <int MATH> struct Mth;
+template <> struct Mth<MATH_IEEE> {
   static __device__ __forceinline__ double sqrt(double z) { return __builtin_sqrt(z); }
   static __device__ __forceinline__ double div(double a, double b) { return a / b; }
   static __device__ __forceinline__ V3 div3(V3 a, double s) { return a / s; }
@@ -78,7 +94,50 @@ template <> struct Mth<false> {
   }
   static __device__ __forceinline__ V3 normalized(V3 a) { return pmaf::normalized(a); }
 };
-template <> struct Mth<true> {
+template <> struct Mth<MATH_XACT> {
+  static __device__ __forceinline__ double sqrt(double z) {
+    double y = __builtin_amdgcn_rsq(z);
+    double g = z * y, h = 0.5 * y;
+    double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    h = __builtin_fma(h, r, h);
+    double d = __builtin_fma(-g, g, z);
+    g = __builtin_fma(d, h, g);
+    d = __builtin_fma(-g, g, z);
+    g = __builtin_fma(d, h, g);
+    return (z == 0.0 || z == __builtin_huge_val()) ? z : g;  // sqrt(+-0) = +-0, sqrt(inf) = inf
+  }
+  static __device__ __forceinline__ double rcp_refined(double b) {
+    double r = __builtin_amdgcn_rcp(b);
+    double e = __builtin_fma(-b, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-b, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    return r;
+  }
+  // a / b given r = rcp_refined(b); v_div_fixup supplies the IEEE results for
+  // zero / infinite / NaN operands
+  static __device__ __forceinline__ double div_r(double a, double b, double r) {
+    double q = a * r;
+    double e = __builtin_fma(-b, q, a);
+    q = __builtin_fma(e, r, q);
+    return __builtin_amdgcn_div_fixup(q, b, a);
+  }
+  static __device__ __forceinline__ double div(double a, double b) { return div_r(a, b, rcp_refined(b)); }
+  static __device__ __forceinline__ V3 div3(V3 a, double s) {
+    const double r = rcp_refined(s);
+    return mk(div_r(a.x, s, r), div_r(a.y, s, r), div_r(a.z, s, r));
+  }
+  static __device__ __forceinline__ double norm(V3 a) { return sqrt(sqn(a)); }
+  static __device__ __forceinline__ void norm_unit(V3 a, double &s, V3 &u) {
+    double z = sqn(a);
+    s = sqrt(z);
+    V3 q = div3(a, s);
+    u = (z > 0.0) ? q : a;
+  }
+  static __device__ __forceinline__ V3 normalized(V3 a) { double s; V3 u; norm_unit(a, s, u); return u; }
+};
+template <> struct Mth<MATH_FAST> {
   static __device__ __forceinline__ double rcp(double b) {
     double r = __builtin_amdgcn_rcp(b);
     r = __builtin_fma(__builtin_fma(-b, r, 1.0), r, r);
@@ -116,7 +175,7 @@ template <> struct Mth<true> {
 // table-free fdlibm e_exp.c algorithm (< 1 ulp) in plain IEEE + - * /, the
 // same function as oracle/pmaf_oracle.c:pmaf_portable_exp, so it produces
 // identical bits on the host and on gfx950.
-template <bool FAST = false>
+template <int MATH = MATH_IEEE>
 __device__ __forceinline__ double portable_exp(double x) {
   const double ln2HI = 6.93147180369123816490e-01, ln2LO = 1.90821492927058770002e-10,
                invln2 = 1.44269504088896338700e+00,
@@ -136,7 +195,7 @@ __device__ __forceinline__ double portable_exp(double x) {
   const double r = hi - lo;
   const double r2 = r * r;
   const double c = r - r2 * (P1 + r2 * (P2 + r2 * (P3 + r2 * (P4 + r2 * P5))));
-  const double y = 1.0 - ((lo - Mth<FAST>::div(r * c, 2.0 - c)) - hi);
+  const double y = 1.0 - ((lo - Mth<MATH>::div(r * c, 2.0 - c)) - hi);
   return y * __longlong_as_double((long long)(1023 + k) << 52);
 }
 
@@ -275,9 +334,9 @@ __device__ __forceinline__ int wave_min64_i(int v) {
 // 463-475 (GoalObstacle), 520-537 (Vel), 545-557 (Random), 585-597 (Had).
 // to_obs = normalized(obstacle - agent_pos), identical to the value the
 // reference recomputes inside each currentVector.
-template <bool FAST = false>
+template <int MATH = MATH_IEEE>
 __device__ __forceinline__ V3 current_vector(int type, V3 agent_vel, V3 goal_vec, V3 to_obs, V3 rot) {
-  typedef Mth<FAST> M;
+  typedef Mth<MATH> M;
   if (type == T_GOAL) {
     V3 cur = goal_vec - to_obs * dot(to_obs, goal_vec);
     if (M::norm(cur) < 1e-10) cur = mk(0.0, 0.0, 1.0);

@@ -194,7 +194,7 @@ __global__ __launch_bounds__(64) void k_rollout(DevView D, CostParams CP) {
 // ---------------------------------------------------------------------------
 // the step loop, specialised on the agent's heuristic so the per-step code
 // carries no type dispatch (the type is uniform per wave)
-template <int TILES, int TYPE, bool FAST>
+template <int TILES, int TYPE, int MATH>
 __device__ __forceinline__ void rollout_w64_body(const DevView &D, const CostParams &CP, const int lane,
                                                  const int pop, const int a) {
   extern __shared__ double smem[];
@@ -257,7 +257,7 @@ __device__ __forceinline__ void rollout_w64_body(const DevView &D, const CostPar
   // step, where they share a basic block (and the FP64 pipeline) with the
   // path-length norm
   V3 g = goal - p;
-  double dg = Mth<FAST>::norm(g);
+  double dg = Mth<MATH>::norm(g);
   double zv = sqn(v);
   double z_init = sqn(p - init_pos);
   const double zsent_lt = D.zsent_lt[pop];
@@ -265,19 +265,19 @@ __device__ __forceinline__ void rollout_w64_body(const DevView &D, const CostPar
     // gate, :315-317
     // |v| < 0.5 vmax and |p - init| < 0.2 on exact squared thresholds
     const bool gate = !(dg < C.approach || (zv < C.zvhalf_lt && z_init < C.zinit_lt));
-    const V3 verr = attractor_velocity_error<FAST>(v, g, C, k_attr, k_damp);
+    const V3 verr = attractor_velocity_error<MATH>(v, g, C, k_attr, k_damp);
     V3 F = mk(0.0, 0.0, 0.0);
     double scale = 1.0;
     if (gate && !(D.ablate & 8))
-      circ_and_scale_w64<TILES, TYPE, FAST>(lane, p, v, zv, goal, g, dg, C, k_circ, T, n_obs, rot_g, known_bits, O,
+      circ_and_scale_w64<TILES, TYPE, MATH>(lane, p, v, zv, goal, g, dg, C, k_circ, T, n_obs, rot_g, known_bits, O,
                                       clist, lane_min, F, scale, D.ablate);
     V3 new_pos;
-    finish_step_w64<FAST>(p, v, verr, F, scale, C, k_attr, k_repel, k_damp, sent_p, sent_r, zsent_lt, new_pos);
+    finish_step_w64<MATH>(p, v, verr, F, scale, C, k_attr, k_repel, k_damp, sent_p, sent_r, zsent_lt, new_pos);
     const V3 dp = new_pos - p;
     p = new_pos;
     g = goal - p;
-    const double seg = Mth<FAST>::norm(dp);
-    dg = Mth<FAST>::norm(g);
+    const double seg = Mth<MATH>::norm(dp);
+    dg = Mth<MATH>::norm(g);
     zv = sqn(v);
     z_init = sqn(p - init_pos);
     path_len += seg;
@@ -316,18 +316,18 @@ __device__ __forceinline__ void rollout_w64_body(const DevView &D, const CostPar
   }
 }
 
-template <int TILES, bool FAST>
+template <int TILES, int MATH>
 __global__ __launch_bounds__(64) void k_rollout_w64(DevView D, CostParams CP) {
   const int lane = threadIdx.x;
   const int pop = blockIdx.y;
   const int a = blockIdx.x;  // grid.x == N
   switch (D.types[a]) {
-    case T_GOAL: rollout_w64_body<TILES, T_GOAL, FAST>(D, CP, lane, pop, a); break;
-    case T_OBST: rollout_w64_body<TILES, T_OBST, FAST>(D, CP, lane, pop, a); break;
-    case T_GOALOBST: rollout_w64_body<TILES, T_GOALOBST, FAST>(D, CP, lane, pop, a); break;
-    case T_VEL: rollout_w64_body<TILES, T_VEL, FAST>(D, CP, lane, pop, a); break;
-    case T_RANDOM: rollout_w64_body<TILES, T_RANDOM, FAST>(D, CP, lane, pop, a); break;
-    case T_HAD: rollout_w64_body<TILES, T_HAD, FAST>(D, CP, lane, pop, a); break;
+    case T_GOAL: rollout_w64_body<TILES, T_GOAL, MATH>(D, CP, lane, pop, a); break;
+    case T_OBST: rollout_w64_body<TILES, T_OBST, MATH>(D, CP, lane, pop, a); break;
+    case T_GOALOBST: rollout_w64_body<TILES, T_GOALOBST, MATH>(D, CP, lane, pop, a); break;
+    case T_VEL: rollout_w64_body<TILES, T_VEL, MATH>(D, CP, lane, pop, a); break;
+    case T_RANDOM: rollout_w64_body<TILES, T_RANDOM, MATH>(D, CP, lane, pop, a); break;
+    case T_HAD: rollout_w64_body<TILES, T_HAD, MATH>(D, CP, lane, pop, a); break;
     default: break;
   }
 }
@@ -335,7 +335,7 @@ __global__ __launch_bounds__(64) void k_rollout_w64(DevView D, CostParams CP) {
 // ---------------------------------------------------------------------------
 // k_rollout_grp<LPA, TILES>: 64/LPA agents per wave (see pmaf_rollout_grp.hpp)
 // ---------------------------------------------------------------------------
-template <int LPA, int TILES>
+template <int LPA, int TILES, int MATH>
 __global__ __launch_bounds__(64) void k_rollout_grp(DevView D, CostParams CP) {
   extern __shared__ double smem[];
   constexpr int APW = 64 / LPA;
@@ -404,29 +404,29 @@ __global__ __launch_bounds__(64) void k_rollout_grp(DevView D, CostParams CP) {
   if (active && sub == 0) { path[0] = p.x; path[1] = p.y; path[2] = p.z; }
 
   V3 g = goal - p;
-  double dg = norm(g);
+  double dg = Mth<MATH>::norm(g);
   double zv = sqn(v);
   double z_init = sqn(p - init_pos);
   while (true) {
     const bool run = active && (dg > 0.1) && (n < D.cap);  // B/src/cf_agent.cpp:310-311, per agent
     if (!__any(run)) break;
     const bool gate = !(dg < C.approach || (zv < C.zvhalf_lt && z_init < C.zinit_lt));  // :315-317
-    const V3 verr = attractor_velocity_error<false>(v, g, C, k_attr, k_damp);
+    const V3 verr = attractor_velocity_error<MATH>(v, g, C, k_attr, k_damp);
     V3 F = mk(0.0, 0.0, 0.0);
     double scale = 1.0;
     if (__any(run && gate))
-      circ_and_scale_grp<LPA, TILES>(run && gate, sub, grp, type, p, v, zv, goal, g, dg, C, k_circ, T, n_obs, rot_g,
+      circ_and_scale_grp<LPA, TILES, MATH>(run && gate, sub, grp, type, p, v, zv, goal, g, dg, C, k_circ, T, n_obs, rot_g,
                                      known_bits, O, clist, lane_min, F, scale);
     V3 new_pos;
     V3 nv = v;
-    finish_step_w64<false>(p, nv, verr, F, scale, C, k_attr, k_repel, k_damp, sent_p, sent_r, zsent_lt, new_pos);
+    finish_step_w64<MATH>(p, nv, verr, F, scale, C, k_attr, k_repel, k_damp, sent_p, sent_r, zsent_lt, new_pos);
     if (run) {
       const V3 dp = new_pos - p;
       p = new_pos;
       v = nv;
       g = goal - p;
-      path_len += norm(dp);
-      dg = norm(g);
+      path_len += Mth<MATH>::norm(dp);
+      dg = Mth<MATH>::norm(g);
       zv = sqn(v);
       z_init = sqn(p - init_pos);
       ws_cost_add(cost_ws, p, CP.ws, CP.k_workspace);
@@ -687,7 +687,9 @@ __global__ void k_link_force(int n, const double *link_pos, const double *k_r, c
 }
 
 // elementary operations the parity argument rests on, exposed for the GPU
-// self-test: 0 a/b, 1 sqrt(a), 2 exp(a), 3 a*b, 4 a+b
+// self-test: 0 a/b, 1 sqrt(a), 2 exp(a), 3 a*b, 4 a+b (compiler sequences);
+// 5 Xact::sqrt(a), 6 Xact::div(a,b), 7 / 8 a 3-vector divided by a scalar
+// through Xact::div3 / the compiler (summed to one double)
 __global__ void k_debug_math(int op, int n, const double *a, const double *b, double *out) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -698,6 +700,10 @@ __global__ void k_debug_math(int op, int n, const double *a, const double *b, do
     case 2: r = portable_exp(a[i]); break;
     case 3: r = a[i] * b[i]; break;
     case 4: r = a[i] + b[i]; break;
+    case 5: r = Mth<MATH_XACT>::sqrt(a[i]); break;
+    case 6: r = Mth<MATH_XACT>::div(a[i], b[i]); break;
+    case 7: { V3 q = Mth<MATH_XACT>::div3(mk(a[i], b[i], a[i] * 0.5), b[i] + a[i]); r = (q.x + q.y) + q.z; } break;
+    case 8: { V3 q = mk(a[i], b[i], a[i] * 0.5) / (b[i] + a[i]); r = (q.x + q.y) + q.z; } break;
   }
   out[i] = r;
 }
@@ -742,11 +748,23 @@ struct StatusError {
 };
 static void fail(int code, const std::string &msg) { throw StatusError{code, msg}; }
 
+// Supported numeric range of every input (metres, m/s, gains, seconds): finite
+// and either exactly 0 or 2^-100 <= |x| <= 2^100. Keeps all divisions / square
+// roots of the path inside the exponent range where the hand-expanded
+// sequences (MATH_XACT) equal the IEEE ones.
+static void check_range(const double *v, size_t n, const char *what) {
+  for (size_t i = 0; i < n; i++) {
+    const double a = std::fabs(v[i]);
+    if (!(a == 0.0 || (a >= 0x1p-100 && a <= 0x1p100)))
+      fail(PMAF_ERR_INVALID, std::string(what) + ": value outside the supported numeric range (finite, 0 or 2^-100 <= |x| <= 2^100)");
+  }
+}
+
 struct pmaf_planner {
   DevView D{};
   int device = 0;
   int lpa = 64;
-  bool fast_math = false;      // PMAF_FLAG_FAST_MATH (w64 rollout kernels only)
+  int math = MATH_XACT;        // arithmetic policy of the w64 rollout kernels (pmaf_device.hpp)
   bool force_generic = false;  // PMAF_FORCE_GENERIC=1: always use the generic k_rollout<LPA>
   int n_blocks = 0;
   size_t lds_rollout = 0, lds_manager = 0;
@@ -888,18 +906,22 @@ static void launch_rollout(pmaf_planner *h) {
   if (h->lpa == 64 && tiles64 <= 4 && !h->force_generic) {
     dim3 g64((unsigned)h->D.N, (unsigned)h->D.P);
 #define PMAF_W64(T, F) hipLaunchKernelGGL((k_rollout_w64<T, F>), g64, block, h->lds_rollout, h->stream, h->D, h->cp)
-    if (h->fast_math) {
-      if (tiles64 <= 1) PMAF_W64(1, true); else if (tiles64 == 2) PMAF_W64(2, true); else PMAF_W64(4, true);
+    if (h->math == MATH_FAST) {
+      if (tiles64 <= 1) PMAF_W64(1, MATH_FAST); else if (tiles64 == 2) PMAF_W64(2, MATH_FAST); else PMAF_W64(4, MATH_FAST);
+    } else if (h->math == MATH_IEEE) {
+      if (tiles64 <= 1) PMAF_W64(1, MATH_IEEE); else if (tiles64 == 2) PMAF_W64(2, MATH_IEEE); else PMAF_W64(4, MATH_IEEE);
     } else {
-      if (tiles64 <= 1) PMAF_W64(1, false); else if (tiles64 == 2) PMAF_W64(2, false); else PMAF_W64(4, false);
+      if (tiles64 <= 1) PMAF_W64(1, MATH_XACT); else if (tiles64 == 2) PMAF_W64(2, MATH_XACT); else PMAF_W64(4, MATH_XACT);
     }
 #undef PMAF_W64
   } else if (!h->force_generic && (h->lpa == 32 || h->lpa == 16 || h->lpa == 8) &&
              (h->D.n_obs - 1 + h->lpa - 1) / h->lpa <= 4) {
     const int tl = (h->D.n_obs - 1 + h->lpa - 1) / h->lpa;
-#define PMAF_GRP(L, T) hipLaunchKernelGGL((k_rollout_grp<L, T>), grid, block, h->lds_rollout, h->stream, h->D, h->cp)
-#define PMAF_GRP_T(L) do { if (tl <= 1) PMAF_GRP(L, 1); else if (tl == 2) PMAF_GRP(L, 2); else PMAF_GRP(L, 4); } while (0)
-    if (h->lpa == 32) PMAF_GRP_T(32); else if (h->lpa == 16) PMAF_GRP_T(16); else PMAF_GRP_T(8);
+#define PMAF_GRP(L, T, M) hipLaunchKernelGGL((k_rollout_grp<L, T, M>), grid, block, h->lds_rollout, h->stream, h->D, h->cp)
+#define PMAF_GRP_T(L, M) do { if (tl <= 1) PMAF_GRP(L, 1, M); else if (tl == 2) PMAF_GRP(L, 2, M); else PMAF_GRP(L, 4, M); } while (0)
+    // (the opt-in fast arithmetic exists for the w64 kernels only)
+    if (h->math == MATH_IEEE) { if (h->lpa == 32) PMAF_GRP_T(32, MATH_IEEE); else if (h->lpa == 16) PMAF_GRP_T(16, MATH_IEEE); else PMAF_GRP_T(8, MATH_IEEE); }
+    else { if (h->lpa == 32) PMAF_GRP_T(32, MATH_XACT); else if (h->lpa == 16) PMAF_GRP_T(16, MATH_XACT); else PMAF_GRP_T(8, MATH_XACT); }
 #undef PMAF_GRP_T
 #undef PMAF_GRP
   } else
@@ -945,6 +967,7 @@ static void ensure_scores(pmaf_planner *h) {
 
 static void upload_live_obstacles(pmaf_planner *h, const double *obstacles) {
   if (!obstacles) return;
+  check_range(obstacles, (size_t)h->D.P * h->D.n_obs * 7, "obstacles");
   // ring of pinned staging buffers: wait only for the copy that last used this slot
   int s = h->stage_next;
   h->stage_next = (s + 1) % pmaf_planner::kStage;
@@ -991,6 +1014,7 @@ static int guarded(F &&f) {
 
 #define REQUIRE(c, msg) do { if (!(c)) fail(PMAF_ERR_INVALID, msg); } while (0)
 
+
 extern "C" {
 
 const char *pmaf_last_error(void) { return g_err.c_str(); }
@@ -1006,6 +1030,17 @@ int pmaf_create(const pmaf_params *prm, pmaf_planner **out) {
     REQUIRE(prm->max_prediction_steps >= 1, "pmaf_create: max_prediction_steps must be >= 1");
     REQUIRE(prm->goal && prm->obstacles && prm->k_attr && prm->k_circ && prm->k_repel && prm->k_damp,
             "pmaf_create: goal, obstacles and gain arrays are required");
+    {
+      const size_t P_ = (size_t)prm->n_populations, N_ = (size_t)prm->n_agents, O_ = (size_t)prm->n_obstacles;
+      check_range(prm->goal, P_ * 3, "pmaf_create: goal");
+      if (prm->init_pos) check_range(prm->init_pos, P_ * 3, "pmaf_create: init_pos");
+      check_range(prm->obstacles, P_ * O_ * 7, "pmaf_create: obstacles");
+      check_range(prm->k_attr, P_ * N_, "pmaf_create: k_attr"); check_range(prm->k_circ, P_ * N_, "pmaf_create: k_circ");
+      check_range(prm->k_repel, P_ * N_, "pmaf_create: k_repel"); check_range(prm->k_damp, P_ * N_, "pmaf_create: k_damp");
+      if (prm->random_vecs) check_range(prm->random_vecs, P_ * N_ * O_ * 3, "pmaf_create: random_vecs");
+      const double sc[6] = {prm->dt, prm->velocity_max, prm->approach_dist, prm->detect_shell_rad, prm->agent_mass, prm->radius};
+      check_range(sc, 6, "pmaf_create: scalar parameter");
+    }
     int lp = prm->lanes_per_agent;
     REQUIRE(lp == 0 || (lp >= 1 && lp <= 64 && (lp & (lp - 1)) == 0), "pmaf_create: lanes_per_agent must be 0 or a power of two <= 64");
     int ndev = 0;
@@ -1026,7 +1061,7 @@ int pmaf_create(const pmaf_params *prm, pmaf_planner **out) {
     D.C.zf_gt = sq_gt(1e-5); D.C.zacc_gt = sq_gt(13.0); D.C.zinit_lt = sq_ge(0.2);
     D.C.zvhalf_lt = sq_ge(0.5 * prm->velocity_max);
     D.C.zv09_lt = sq_ge(prm->velocity_max - 0.1 * prm->velocity_max);
-    h->fast_math = (prm->flags & PMAF_FLAG_FAST_MATH) != 0;
+    h->math = (prm->flags & PMAF_FLAG_FAST_MATH) ? MATH_FAST : (prm->flags & PMAF_FLAG_IEEE_SEQUENCES) ? MATH_IEEE : MATH_XACT;
     h->lpa = lp ? lp : pick_lpa(N, P, M);
     { const char *fg = getenv("PMAF_FORCE_GENERIC"); h->force_generic = fg && fg[0] == '1'; }
     { const char *ab = getenv("PMAF_ABLATE"); D.ablate = ab ? atoi(ab) : 0; }
@@ -1188,6 +1223,7 @@ int pmaf_destroy(pmaf_planner *h) {
 int pmaf_set_initial_position(pmaf_planner *h, const double *pos) {
   return guarded([&] {
     REQUIRE(h && pos, "pmaf_set_initial_position: NULL argument");
+    check_range(pos, (size_t)h->D.P * 3, "pmaf_set_initial_position");
     h->use_device();
     sync(h);
     DevView &D = h->D;
@@ -1211,6 +1247,7 @@ int pmaf_set_initial_position(pmaf_planner *h, const double *pos) {
 int pmaf_set_real_position(pmaf_planner *h, const double *pos) {
   return guarded([&] {
     REQUIRE(h && pos, "pmaf_set_real_position: NULL argument");
+    check_range(pos, (size_t)h->D.P * 3, "pmaf_set_real_position");
     h->use_device();
     sync(h);
     h->upload(h->D.real_pos, pos, h->D.P * 3);
@@ -1290,6 +1327,8 @@ int pmaf_move_real(pmaf_planner *h, const double *obstacles, double dt, int32_t 
 int pmaf_reset_agents(pmaf_planner *h, const double *pos, const double *vel, const double *obstacles) {
   return guarded([&] {
     REQUIRE(h && pos && vel, "pmaf_reset_agents: NULL argument");
+    check_range(pos, (size_t)h->D.P * 3, "pmaf_reset_agents: pos");
+    check_range(vel, (size_t)h->D.P * 3, "pmaf_reset_agents: vel");
     h->use_device();
     sync(h);
     upload_live_obstacles(h, obstacles);
@@ -1567,7 +1606,7 @@ int pmaf_reset_kernel_stats(pmaf_planner *h) {
 }
 int pmaf_debug_math(int32_t op, int32_t n, const double *a, const double *b, double *out) {
   return guarded([&] {
-    REQUIRE(a && b && out && n > 0 && op >= 0 && op <= 4, "pmaf_debug_math: bad argument");
+    REQUIRE(a && b && out && n > 0 && op >= 0 && op <= 8, "pmaf_debug_math: bad argument");
     double *da = nullptr, *db = nullptr, *dout = nullptr;
     HIP_CHECK(hipMalloc((void **)&da, sizeof(double) * n));
     HIP_CHECK(hipMalloc((void **)&db, sizeof(double) * n));

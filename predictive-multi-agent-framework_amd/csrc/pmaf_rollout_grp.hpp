@@ -50,14 +50,15 @@ __device__ __forceinline__ int group_min_dpp_i(int v) {
 // circForce + attractorForceScaling for the agents of one wave. `act`: the
 // lane's agent takes a step and its gate is open (uniform within the group).
 // clist: this GROUP's list in LDS (LPA*TILES entries of 4 doubles).
-template <int LPA, int TILES>
+template <int LPA, int TILES, int MATH>
 __device__ __forceinline__ void circ_and_scale_grp(bool act, int sub, int grp, int type, V3 p, V3 v, double zv,
                                                    V3 goal, V3 g, double dg, const PopConst &C, double k_circ,
                                                    const ObsTab &T, int n_obs, double *rot_g, unsigned &known_bits,
                                                    LaneObstacles<TILES> &O, double *clist, double &lane_min, V3 &F,
                                                    double &scale) {
+  typedef Mth<MATH> MT;
   const int M = n_obs - 1;
-  const V3 gn = (dg > 0.0) ? (g / dg) : g;
+  const V3 gn = (dg > 0.0) ? MT::div3(g, dg) : g;
   double best_d = C.shell;
   double best_s = 0.0, best_gr = 0.0;
   int best_i = 0x7fffffff;
@@ -71,9 +72,9 @@ __device__ __forceinline__ void circ_and_scale_grp(bool act, int sub, int grp, i
     const V3 op = O.p[t];
     const V3 ro = op - p;
     const V3 rv = v - O.v[t];
-    const double z = sqn(ro);
-    const double s = __builtin_sqrt(z);
-    const V3 ron = (z > 0.0) ? (ro / s) : ro;
+    double s;
+    V3 ron;
+    MT::norm_unit(ro, s, ron);
     const bool skip = (dot(ron, gn) < -0.01) && (dot(ro, rv) < -0.01);
     double d = s - (C.rad + O.r[t]);
     d = smax(d, 1e-5);
@@ -92,10 +93,10 @@ __device__ __forceinline__ void circ_and_scale_grp(bool act, int sub, int grp, i
         }
       }
       const V3 rot = mk(O.rx[t], O.ry[t], O.rz[t]);
-      const double vn = norm(rv);
-      const V3 nv = rv / vn;
-      const V3 cur = current_vector(type, rv, g, ron, rot);
-      const V3 c = (k_circ / (d * d)) * cross(nv, cross(cur, nv));
+      const double vn = MT::norm(rv);
+      const V3 nv = MT::div3(rv, vn);
+      const V3 cur = current_vector<MATH>(type, rv, g, ron, rot);
+      const V3 c = MT::div(k_circ, d * d) * cross(nv, cross(cur, nv));
       const bool has_c = in_shell && (vn != 0);
       const unsigned long long m = __ballot(has_c);
       if (has_c) {
@@ -137,8 +138,8 @@ __device__ __forceinline__ void circ_and_scale_grp(bool act, int sub, int grp, i
     } else if (dot(g, v) <= 0.0 && zv < C.zv09_lt && dg > 0.15) {
       sc = 0.0;
     } else {
-      const double w1 = 1 - portable_exp<false>(-__builtin_sqrt(m) / C.shell);
-      double w2 = 1 - (gr / (dg * sb));
+      const double w1 = 1 - portable_exp<MATH>(-MT::div(MT::sqrt(m), C.shell));
+      double w2 = 1 - MT::div(gr, dg * sb);
       w2 = w2 * w2;
       sc = w1 * w2;
     }

@@ -38,11 +38,11 @@ namespace pmaf {
 // the step's start state, so it is evaluated BEFORE the obstacle sweep, where
 // its sqrt / divide chain overlaps the sweep's instead of extending the
 // dependent chain after the force sum.
-template <bool FAST>
+template <int MATH>
 __device__ __forceinline__ V3 attractor_velocity_error(V3 v, V3 goal_vec, const PopConst &C, double k_attr,
                                                        double k_damp) {
   V3 vel_des = (k_attr / k_damp) * goal_vec;
-  double scale_lim = smin(1.0, Mth<FAST>::div(C.vel_max, Mth<FAST>::norm(vel_des)));
+  double scale_lim = smin(1.0, Mth<MATH>::div(C.vel_max, Mth<MATH>::norm(vel_des)));
   vel_des = vel_des * scale_lim;
   return vel_des - v;
 }
@@ -52,7 +52,7 @@ __device__ __forceinline__ V3 attractor_velocity_error(V3 v, V3 goal_vec, const 
 // decided on the squared norm (exact threshold) so its square root is only
 // taken in the rare clamped case; the speed clamp is a select so the block is
 // not split (the next step's norms can overlap it).
-template <bool FAST>
+template <int MATH>
 __device__ __forceinline__ void finish_step_w64(V3 p, V3 &v, V3 verr, V3 F, double scale, const PopConst &C,
                                                 double k_attr, double k_repel, double k_damp, V3 sent_pos,
                                                 double sent_rad, double zsent_lt, V3 &new_pos) {
@@ -80,8 +80,8 @@ __device__ __forceinline__ void finish_step_w64(V3 p, V3 &v, V3 verr, V3 F, doub
   V3 half = ((0.5 * acc) * C.dt) * C.dt;
   new_pos = (p + half) + (v * C.dt);
   V3 nv = v + acc * C.dt;
-  const double vn = Mth<FAST>::norm(nv);
-  const double f = Mth<FAST>::div(C.vel_max, vn);
+  const double vn = Mth<MATH>::norm(nv);
+  const double f = Mth<MATH>::div(C.vel_max, vn);
   const V3 cl = nv * f;
   v = (vn > C.vel_max) ? cl : nv;
 }
@@ -110,7 +110,7 @@ __device__ __forceinline__ int lane_rank(unsigned long long m) {
 // circForce (B/src/cf_agent.cpp:72-108) + attractorForceScaling (:195-227)
 // for one agent per wave. clist: LDS, 64*TILES entries of 4 doubles.
 // zv = squaredNorm(v), dg = norm(g) (already computed by the caller).
-template <int TILES, int TYPE, bool FAST>
+template <int TILES, int TYPE, int MATH>
 __device__ __forceinline__ void circ_and_scale_w64(int lane, V3 p, V3 v, double zv, V3 goal, V3 g, double dg,
                                                    const PopConst &C, double k_circ, const ObsTab &T,
                                                    int n_obs, double *rot_g, unsigned &known_bits,
@@ -118,7 +118,7 @@ __device__ __forceinline__ void circ_and_scale_w64(int lane, V3 p, V3 v, double 
                                                    V3 &F, double &scale, const int ablate = 0) {
   const int M = n_obs - 1;
   // goal_vec.normalized(): dg == sqrt(squaredNorm(g)), the value normalized() divides by
-  typedef Mth<FAST> MT;
+  typedef Mth<MATH> MT;
   const V3 gn = (dg > 0.0) ? MT::div3(g, dg) : g;
   double best_d = C.shell;
   double best_s = 0.0, best_gr = 0.0;  // |ro| and g.ro of the lane's closest obstacle
@@ -157,9 +157,9 @@ __device__ __forceinline__ void circ_and_scale_w64(int lane, V3 p, V3 v, double 
       const V3 rot = mk(O.rx[t], O.ry[t], O.rz[t]);
       double vn;
       V3 nv;
-      if (FAST) { MT::norm_unit(rv, vn, nv); }
-      else { vn = norm(rv); nv = rv / vn; }
-      const V3 cur = current_vector<FAST>(TYPE, rv, g, ron, rot);
+      if (MATH == MATH_FAST) { MT::norm_unit(rv, vn, nv); }
+      else { vn = MT::norm(rv); nv = MT::div3(rv, vn); }
+      const V3 cur = current_vector<MATH>(TYPE, rv, g, ron, rot);
       const V3 c = MT::div(k_circ, d * d) * cross(nv, cross(cur, nv));
       const bool has_c = in_shell && (vn != 0);
       // compact the contributing terms, ascending obstacle index, into LDS
@@ -205,7 +205,7 @@ __device__ __forceinline__ void circ_and_scale_w64(int lane, V3 p, V3 v, double 
     } else if (dot(g, v) <= 0.0 && zv < C.zv09_lt && dg > 0.15) {  // norm(v) < vmax - 0.1 vmax
       scale = 0.0;
     } else {
-      const double w1 = 1 - portable_exp<FAST>(-MT::div(MT::sqrt(m), C.shell));
+      const double w1 = 1 - portable_exp<MATH>(-MT::div(MT::sqrt(m), C.shell));
       // |ro| and g.ro of the closest obstacle were computed by the lane that
       // owns it (same operands, same bits as recomputing them here)
       const int bl = bi & 63;

@@ -130,7 +130,8 @@ class PmafPlanner:
     a list of P scene dicts (see scenes.py) sharing N, n_obs, capacity and the
     scalar parameters. Method names follow the C-ABI / CfManager."""
 
-    def __init__(self, scenes, device=-1, lanes_per_agent=0, mgr_init_pos=None, fast_math=False):
+    def __init__(self, scenes, device=-1, lanes_per_agent=0, mgr_init_pos=None, fast_math=False,
+                 ieee_sequences=False):
         if isinstance(scenes, dict):
             scenes = [scenes]
         self.L = load_library()
@@ -148,7 +149,7 @@ class PmafPlanner:
         prm.max_prediction_steps = self.cap
         prm.device = device
         prm.lanes_per_agent = lanes_per_agent
-        prm.flags = 1 if fast_math else 0  # PMAF_FLAG_FAST_MATH
+        prm.flags = (1 if fast_math else 0) | (2 if ieee_sequences else 0)  # PMAF_FLAG_FAST_MATH / _IEEE_SEQUENCES
         prm.dt = s0["dt"]
         prm.velocity_max = s0["velocity_max"]
         prm.approach_dist = s0["approach_dist"]

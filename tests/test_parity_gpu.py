@@ -501,3 +501,55 @@ def test_c4_dual_arm_two_coupled_populations(pmaf, oracle, scenes):
     assert min_gap < sc["detect_shell_rad"] + 0.15
     print("dual arm: closest approach of the two end effectors %.3f m" % min_gap)
     hip.close()
+
+
+def test_xact_sequences_match_ieee(pmaf):
+    """the default arithmetic policy (MATH_XACT, pmaf_device.hpp): hand-expanded
+    sqrt / divide sequences must return the correctly rounded IEEE bits for
+    operands with exponents within +-250 (the validated input range keeps the
+    path's operands far inside) and handle zeros / infinities / NaN like IEEE."""
+    rng = np.random.default_rng(7)
+    n = 2_000_000
+    a = rng.uniform(1e-12, 50.0, n) * rng.choice([-1.0, 1.0], n)
+    b = rng.uniform(1e-12, 50.0, n) * rng.choice([-1.0, 1.0], n)
+    with np.errstate(all="ignore"):
+        assert (pmaf.debug_math(5, np.abs(a)) == np.sqrt(np.abs(a))).all()
+        assert (pmaf.debug_math(6, a, b) == a / b).all()
+        assert (pmaf.debug_math(7, a, b) == pmaf.debug_math(8, a, b)).all()
+        # exponent sweep over the guaranteed range
+        wa = np.ldexp(rng.uniform(1.0, 2.0, n), rng.integers(-250, 250, n)) * rng.choice([-1.0, 1.0], n)
+        wb = np.ldexp(rng.uniform(1.0, 2.0, n), rng.integers(-250, 250, n)) * rng.choice([-1.0, 1.0], n)
+        assert (pmaf.debug_math(5, np.abs(wa)) == np.sqrt(np.abs(wa))).all()
+        assert (pmaf.debug_math(6, wa, wb) == wa / wb).all()
+        special = np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 1.0, -1.0, 3.0, 2.0 ** -250, 2.0 ** 250, -7.5])
+        A, B = [x.ravel() for x in np.meshgrid(special, special)]
+        for op, ref in ((5, np.sqrt(A)), (6, A / B)):
+            got = pmaf.debug_math(op, A, B)
+            same = (got == ref) | (np.isnan(got) & np.isnan(ref))
+            assert same.all(), (op, A[~same], B[~same], got[~same], ref[~same])
+            assert (np.signbit(got) == np.signbit(ref))[~np.isnan(ref)].all()  # signed zeros / infinities
+
+
+@pytest.mark.parametrize("cfg,ticks", [("C1", 30), ("C2", 20), ("C3", 2)])
+def test_compiler_ieee_sequences_flag_gives_the_same_bits(pmaf, oracle, scenes, cfg, ticks):
+    """PMAF_FLAG_IEEE_SEQUENCES (fully general compiler expansions) against the
+    oracle, bit-exact like the default policy"""
+    sc = scenes.config_scene(cfg)
+    hip, _ = run_both(pmaf, oracle, scenes, sc, ticks, ieee_sequences=True)
+    hip.close()
+
+
+def test_inputs_outside_the_supported_numeric_range_are_rejected(pmaf, scenes):
+    sc = scenes.config_scene("C1")
+    bad = dict(sc)
+    bad["obstacles"] = sc["obstacles"].copy()
+    bad["obstacles"][2, 1] = 1e-200
+    with pytest.raises(pmaf.PmafError) as e:
+        pmaf.PmafPlanner(bad, device=0)
+    assert e.value.code == -1 and "numeric range" in str(e.value)
+    hip = pmaf.PmafPlanner(sc, device=0)
+    with pytest.raises(pmaf.PmafError):
+        hip.set_initial_position([np.nan, 0.0, 0.0])
+    with pytest.raises(pmaf.PmafError):
+        hip.set_initial_position([1e40, 0.0, 0.0])
+    hip.close()

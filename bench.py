@@ -196,11 +196,11 @@ def main():
         flops = algorithmic_flops_per_agent_step(n_obs - 1) * steps_per_launch
         tiles = (n_obs - 1 + 63) // 64
         if cfg["lanes_per_agent"] == 64 and tiles <= 4 and os.environ.get("PMAF_FORCE_GENERIC") != "1":
-            kernel_name = "k_rollout_w64<%d>" % (1 if tiles <= 1 else 2 if tiles == 2 else 4)
+            kernel_name = "k_rollout_w64<%d, 2>" % (1 if tiles <= 1 else 2 if tiles == 2 else 4)  # <TILES, MATH_XACT>
         elif cfg["lanes_per_agent"] in (8, 16, 32) and (n_obs - 2) // cfg["lanes_per_agent"] + 1 <= 4 \
                 and os.environ.get("PMAF_FORCE_GENERIC") != "1":
             tl = (n_obs - 2) // cfg["lanes_per_agent"] + 1
-            kernel_name = "k_rollout_grp<%d, %d>" % (cfg["lanes_per_agent"], 1 if tl <= 1 else 2 if tl == 2 else 4)
+            kernel_name = "k_rollout_grp<%d, %d, 2>" % (cfg["lanes_per_agent"], 1 if tl <= 1 else 2 if tl == 2 else 4)
         else:
             kernel_name = "k_rollout<%d>" % cfg["lanes_per_agent"]
         # HBM traffic per launch of this kernel from the committed PMC passes

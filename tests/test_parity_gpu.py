@@ -553,3 +553,13 @@ def test_inputs_outside_the_supported_numeric_range_are_rejected(pmaf, scenes):
     with pytest.raises(pmaf.PmafError):
         hip.set_initial_position([1e40, 0.0, 0.0])
     hip.close()
+
+
+@pytest.mark.parametrize("m,lpa", [(200, 0), (300, 0), (70, 32), (40, 8)])
+def test_large_and_ragged_obstacle_counts(pmaf, oracle, scenes, m, lpa):
+    """obstacle counts that exercise 4 slots per lane (M = 200: w64 TILES 4;
+    M = 70 @ 32 lanes and M = 40 @ 8 lanes: group kernel TILES 4 / generic),
+    the generic fallback (M = 300 > 4 x 64) and ragged last tiles"""
+    sc = scenes.synthetic_scene(20, 120, m, 6, m)
+    hip, _ = run_both(pmaf, oracle, scenes, sc, 3, lanes_per_agent=lpa)
+    hip.close()

@@ -563,3 +563,36 @@ def test_large_and_ragged_obstacle_counts(pmaf, oracle, scenes, m, lpa):
     sc = scenes.synthetic_scene(20, 120, m, 6, m)
     hip, _ = run_both(pmaf, oracle, scenes, sc, 3, lanes_per_agent=lpa)
     hip.close()
+
+
+def test_hip_path_reproduces_the_survey_probe_record(pmaf, scenes):
+    """the only reference-derived numbers available (SURVEY.md 8c probe record,
+    tests/golden/survey_probe.json: the reference's own cf_agent.cpp /
+    cf_manager.cpp run by the survey) against the HIP path directly"""
+    import json
+    import os
+    from conftest import std_mt19937_unit_vectors
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "survey_probe.json")))
+    N = 10
+    rv = np.zeros((N, 10, 3))
+    rv[5:] = std_mt19937_unit_vectors(12345, (N - 5) * 10).reshape(N - 5, 10, 3)
+    sc = scenes.static1_scene(N, 100, random_vecs=rv)
+    hip = pmaf.PmafPlanner(sc, device=0, mgr_init_pos=sc["start"])
+    hip.set_initial_position(sc["start"])
+    for rec in gold["probe1"]["ticks"]:
+        b = hip.tick(sc["obstacles"], sc["dt"], sc["cost_gains"], sc["ws_limits"])
+        assert b == rec["best_index"] and hip.best_type() == rec["best_type"]
+        np.testing.assert_allclose(hip.real_state()[0], rec["next"], rtol=0, atol=6e-10)
+    assert abs(hip.path_lengths()[0] - gold["probe1"]["agent0_path_length_after_tick2"]) < 6e-10
+    hip.close()
+    # dyn1 closed loop: goal reached at the probe's tick
+    rv = np.zeros((N, 4, 3))
+    rv[5:] = std_mt19937_unit_vectors(12345, (N - 5) * 4).reshape(N - 5, 4, 3)
+    sc = scenes.dyn1_scene(N, 1500, random_vecs=rv)
+    hip = pmaf.PmafPlanner(sc, device=0, mgr_init_pos=sc["start"])
+    hip.set_initial_position(sc["start"])
+    best, pos = drive(hip, sc, 2000, True, scenes.advance_live_obstacles, until_reached=True)
+    assert len(best) - 1 == gold["probe2"]["reached_tick"]
+    final = np.asarray(gold["probe2"]["final_real_position"])
+    assert np.abs(pos[-1] - final).max() < 1e-3
+    hip.close()

@@ -240,12 +240,13 @@ def main():
                           "frac": flops / avg_kernel_s / 1e12 / FP64_VALU_PEAK_TF,
                           "flops_per_agent_step_est": algorithmic_flops_per_agent_step(n_obs - 1)},
         }
-        if args.cpu_seconds > 0:
+        if args.cpu_seconds > 0 and world == 1:  # reported at N = 1 only
             out["cpu_baseline"] = cpu_baseline(pkg, sc, args.cpu_seconds, max(1, min(N, os.cpu_count() or 1)))
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
 
 

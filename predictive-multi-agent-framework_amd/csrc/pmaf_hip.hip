@@ -635,8 +635,12 @@ __global__ __launch_bounds__(64) void k_manager(DevView D, CostParams CP, Manage
       D.n_points[pa] = 1;
       D.agent_vel[pa * 3] = sv.x; D.agent_vel[pa * 3 + 1] = sv.y; D.agent_vel[pa * 3 + 2] = sv.z;
       D.min_obs[pa] = C.shell;
-      int32_t *ko = D.known_out + pa * n_obs;
-      for (int i = 0; i < n_obs; i++) ko[i] = rk[i];
+    }
+    // known_obstacles_ of every agent <- the real agent's flags (setObstacles, cf_agent.cpp:68):
+    // one coalesced sweep over [N][n_obs] instead of a per-agent loop
+    {
+      int32_t *ko = D.known_out + (size_t)pop * N * n_obs;
+      for (int k = lane; k < N * n_obs; k += 64) ko[k] = rk[k % n_obs];
     }
     if (lane == 0) {
       D.start_pos[pop * 3] = sp.x; D.start_pos[pop * 3 + 1] = sp.y; D.start_pos[pop * 3 + 2] = sp.z;

@@ -156,7 +156,11 @@ int pmaf_link_force(pmaf_planner *h, int32_t pop, int32_t n,
                     const double *link_pos, const double *k_r_force,
                     const double *obstacles, double *out);
 
-/* ---- getters (all synchronise with the running rollout first) ---- */
+/* ---- getters ---- */
+/* Getters of rollout results (paths, costs, lengths, distances, flags,
+ * rotation vectors) wait for the running rollout; the real-agent getters
+ * (pmaf_get_real_state, pmaf_get_dist_from_goal, pmaf_get_real_path) are served
+ * from host copies and return at once, like the reference's. */
 /* getPredictedPaths / getNumPredictionSteps: paths [P][N][cap][3], n_points [P][N] */
 int pmaf_get_paths(pmaf_planner *h, double *paths, int32_t *n_points);
 /* costs of the last pmaf_evaluate / pmaf_tick, [P][N] */

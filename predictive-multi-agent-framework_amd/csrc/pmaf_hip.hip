@@ -504,7 +504,7 @@ struct ManagerArgs {
   double dt_real;
   const int32_t *agent_id; // [P] gains index for the real step; NULL = best_idx of this launch
   const double *reset_in;  // [P][6] pos, vel
-  double *out;             // [P][8] host-visible: best_idx, next_pos[3], next_vel[3], dist_from_goal
+  double *out;             // [P][12] host-visible: best_idx, next_pos[3], next_vel[3], dist_from_goal, force[3]
 };
 
 __global__ __launch_bounds__(64) void k_manager(DevView D, CostParams CP, ManagerArgs A) {
@@ -565,6 +565,7 @@ __global__ __launch_bounds__(64) void k_manager(DevView D, CostParams CP, Manage
 
   V3 rp = mk(D.real_pos[pop * 3], D.real_pos[pop * 3 + 1], D.real_pos[pop * 3 + 2]);
   V3 rv = mk(D.real_vel[pop * 3], D.real_vel[pop * 3 + 1], D.real_vel[pop * 3 + 2]);
+  V3 rf = mk(D.real_force[pop * 3], D.real_force[pop * 3 + 1], D.real_force[pop * 3 + 2]);
 
   if (A.do_move) {
     // RealCfAgent::cfPlanner one step, B/src/cf_agent.cpp:343-366
@@ -596,6 +597,7 @@ __global__ __launch_bounds__(64) void k_manager(DevView D, CostParams CP, Manage
     V3 new_pos;
     finish_step(rp, rv, g, F, scale, C, k_attr, k_repel, k_damp, A.dt_real, T.pos(n_obs - 1), T.r[n_obs - 1], new_pos);
     rp = new_pos;
+    rf = F;
     for (int t = 0; t < ntiles; t++) {
       int i = t * 64 + lane;
       if (i < M) rk[i] = (int32_t)((kb >> t) & 1ull);
@@ -649,11 +651,12 @@ __global__ __launch_bounds__(64) void k_manager(DevView D, CostParams CP, Manage
   }
 
   if (lane == 0 && A.out) {
-    double *o = A.out + pop * 8;
+    double *o = A.out + pop * 12;
     o[0] = (double)best;
     o[1] = rp.x; o[2] = rp.y; o[3] = rp.z;
     o[4] = rv.x; o[5] = rv.y; o[6] = rv.z;
     o[7] = norm(goal - rp);
+    o[8] = rf.x; o[9] = rf.y; o[10] = rf.z;
   }
 }
 
@@ -775,7 +778,10 @@ struct pmaf_planner {
   hipStream_t stream = nullptr;
   hipEvent_t ev_mgr = nullptr;
   std::vector<void *> allocs;
-  double *h_out = nullptr;      // pinned [P][8]
+  double *h_out = nullptr;      // pinned [P][12] mailbox written by k_manager
+  // host copy of the real agent's state (getNextPosition / getNextVelocity /
+  // getEEForce / getDistFromGoal must not wait for the running rollout)
+  std::vector<double> real_pos_h, real_vel_h, real_force_h;
   double *d_out = nullptr;      // device alias of h_out
   static constexpr int kStage = 4;
   double *h_stage[kStage] = {nullptr, nullptr, nullptr, nullptr};  // pinned staging ring for obstacle SoA uploads
@@ -987,9 +993,22 @@ static void launch_manager(pmaf_planner *h, const ManagerArgs &A) {
   HIP_CHECK(hipGetLastError());
 }
 
+// copy the mailbox into the host-side real-agent state (call after the
+// k_manager launch has completed)
+static void refresh_real_cache(pmaf_planner *h) {
+  for (int p = 0; p < h->D.P; p++) {
+    const double *o = h->h_out + p * 12;
+    for (int c = 0; c < 3; c++) {
+      h->real_pos_h[p * 3 + c] = o[1 + c];
+      h->real_vel_h[p * 3 + c] = o[4 + c];
+      h->real_force_h[p * 3 + c] = o[8 + c];
+    }
+  }
+}
+
 static void append_real_path(pmaf_planner *h) {
   for (int p = 0; p < h->D.P; p++) {
-    const double *o = h->h_out + p * 8;
+    const double *o = h->h_out + p * 12;
     h->real_path[p].insert(h->real_path[p].end(), {o[1], o[2], o[3]});
   }
 }
@@ -1123,13 +1142,13 @@ int pmaf_create(const pmaf_params *prm, pmaf_planner **out) {
     D.zsent_lt = zsent;
     h->d_reset_in = h->dalloc<double>(P * 6);
     h->d_agent_id = h->dalloc<int32_t>(P);
-    HIP_CHECK(hipHostMalloc((void **)&h->h_out, sizeof(double) * P * 8, hipHostMallocMapped));
+    HIP_CHECK(hipHostMalloc((void **)&h->h_out, sizeof(double) * P * 12, hipHostMallocMapped));
     HIP_CHECK(hipHostGetDevicePointer((void **)&h->d_out, h->h_out, 0));
     for (int i = 0; i < pmaf_planner::kStage; i++) {
       HIP_CHECK(hipHostMalloc((void **)&h->h_stage[i], sizeof(double) * (size_t)P * 7 * n_obs, hipHostMallocDefault));
       HIP_CHECK(hipEventCreateWithFlags(&h->ev_stage[i], hipEventDisableTiming));
     }
-    std::memset(h->h_out, 0, sizeof(double) * P * 8);
+    std::memset(h->h_out, 0, sizeof(double) * P * 12);
 
     // ---- initial state = freshly constructed agents (cf_agent.h:69-97) ----
     std::vector<double> init(P * 3, 0.0);
@@ -1196,6 +1215,9 @@ int pmaf_create(const pmaf_params *prm, pmaf_planner **out) {
       h->upload(D.min_obs, mo.data(), mo.size());
       h->upload(D.agent_vel, av.data(), av.size());
     }
+    h->real_pos_h = init;
+    h->real_vel_h = v0;
+    h->real_force_h.assign(P * 3, 0.0);
     h->real_path.assign(P, {});
     for (int p = 0; p < P; p++) h->real_path[p].insert(h->real_path[p].end(), {init[p * 3], init[p * 3 + 1], init[p * 3 + 2]});
     h->rollout_pending = true;
@@ -1240,6 +1262,7 @@ int pmaf_set_initial_position(pmaf_planner *h, const double *pos) {
     hipLaunchKernelGGL(k_restart_paths, dim3((P * N + 255) / 256), dim3(256), 0, h->stream, D, D.start_pos);
     HIP_CHECK(hipGetLastError());
     (void)cap;
+    h->real_pos_h.assign(pos, pos + P * 3);
     for (int p = 0; p < P; p++)  // RealCfAgent::setPosition = push_back
       h->real_path[p].insert(h->real_path[p].end(), {pos[p * 3], pos[p * 3 + 1], pos[p * 3 + 2]});
     sync(h);
@@ -1255,6 +1278,7 @@ int pmaf_set_real_position(pmaf_planner *h, const double *pos) {
     h->use_device();
     sync(h);
     h->upload(h->D.real_pos, pos, h->D.P * 3);
+    h->real_pos_h.assign(pos, pos + h->D.P * 3);
     for (int p = 0; p < h->D.P; p++)
       h->real_path[p].insert(h->real_path[p].end(), {pos[p * 3], pos[p * 3 + 1], pos[p * 3 + 2]});
   });
@@ -1298,8 +1322,9 @@ int pmaf_evaluate(pmaf_planner *h, const double *cost_gains, const double *ws, i
     A.out = h->d_out;
     launch_manager(h, A);
     sync(h);
+    refresh_real_cache(h);
     if (best_idx)
-      for (int p = 0; p < h->D.P; p++) best_idx[p] = (int32_t)h->h_out[p * 8];
+      for (int p = 0; p < h->D.P; p++) best_idx[p] = (int32_t)h->h_out[p * 12];
   });
 }
 
@@ -1323,6 +1348,7 @@ int pmaf_move_real(pmaf_planner *h, const double *obstacles, double dt, int32_t 
       A.out = h->d_out;
       launch_manager(h, A);
       sync(h);
+      refresh_real_cache(h);
       append_real_path(h);
     }
   });
@@ -1343,8 +1369,10 @@ int pmaf_reset_agents(pmaf_planner *h, const double *pos, const double *vel, con
     ManagerArgs A{};
     A.do_reset = 1;
     A.reset_in = h->d_reset_in;
+    A.out = h->d_out;
     launch_manager(h, A);
     sync(h);
+    refresh_real_cache(h);
     h->scores_valid = false;
     h->rollout_pending = true;
   });
@@ -1368,9 +1396,10 @@ int pmaf_tick(pmaf_planner *h, const double *obstacles, double dt, const double 
     launch_rollout(h);
     // outputs of k_manager land in mapped pinned memory; wait for it only
     HIP_CHECK(hipEventSynchronize(h->ev_mgr));
+    refresh_real_cache(h);
     append_real_path(h);
     for (int p = 0; p < h->D.P; p++) {
-      const double *o = h->h_out + p * 8;
+      const double *o = h->h_out + p * 12;
       if (best_idx) best_idx[p] = (int32_t)o[0];
       if (next_pos) { next_pos[p * 3] = o[1]; next_pos[p * 3 + 1] = o[2]; next_pos[p * 3 + 2] = o[3]; }
       if (next_vel) { next_vel[p * 3] = o[4]; next_vel[p * 3 + 1] = o[5]; next_vel[p * 3 + 2] = o[6]; }
@@ -1468,10 +1497,13 @@ int pmaf_get_rotation_vectors(pmaf_planner *h, double *rot, int32_t *known) {
 }
 int pmaf_get_real_state(pmaf_planner *h, double *pos, double *vel, double *force) {
   return guarded([&] {
-    GETTER_PROLOGUE("pmaf_get_real_state")
-    if (pos) h->download(pos, D.real_pos, D.P * 3);
-    if (vel) h->download(vel, D.real_vel, D.P * 3);
-    if (force) h->download(force, D.real_force, D.P * 3);
+    // served from the host copy kept current by every call that changes the real
+    // agent: no wait for the running rollout (the reference's getters are instant)
+    REQUIRE(h, "pmaf_get_real_state: NULL handle");
+    const size_t n = sizeof(double) * 3 * (size_t)h->D.P;
+    if (pos) std::memcpy(pos, h->real_pos_h.data(), n);
+    if (vel) std::memcpy(vel, h->real_vel_h.data(), n);
+    if (force) std::memcpy(force, h->real_force_h.data(), n);
   });
 }
 int pmaf_get_real_known(pmaf_planner *h, int32_t *known, double *rot) {
@@ -1499,13 +1531,11 @@ int pmaf_get_real_path(pmaf_planner *h, int32_t pop, double *out, int32_t max_po
 }
 int pmaf_get_dist_from_goal(pmaf_planner *h, double *out) {
   return guarded([&] {
-    GETTER_PROLOGUE("pmaf_get_dist_from_goal")
-    REQUIRE(out, "NULL out");
-    // (goal_pos_ - real.getLatestPosition()).norm(), cf_manager.h:87-89; same
-    // operation order as the device code, evaluated on the 3 downloaded doubles
-    std::vector<double> rp(D.P * 3);
-    h->download(rp.data(), D.real_pos, rp.size());
-    for (int p = 0; p < D.P; p++) {
+    REQUIRE(h && out, "pmaf_get_dist_from_goal: NULL argument");
+    // (goal_pos_ - real.getLatestPosition()).norm(), cf_manager.h:87-89, from the
+    // host copy of the real position; same operation order as the device code
+    const std::vector<double> &rp = h->real_pos_h;
+    for (int p = 0; p < h->D.P; p++) {
       double dx = h->goal_h[p * 3] - rp[p * 3], dy = h->goal_h[p * 3 + 1] - rp[p * 3 + 1], dz = h->goal_h[p * 3 + 2] - rp[p * 3 + 2];
 #ifdef PMAF_DOT_RIGHT_ASSOC
       out[p] = std::sqrt(dx * dx + (dy * dy + dz * dz));

@@ -393,7 +393,9 @@ __global__ __launch_bounds__(64) void k_rollout_grp(DevView D, CostParams CP) {
 
   int clist_off = 7 * n_obs + (n_obs + 1) / 2;
   clist_off += clist_off & 1;
-  double *clist = smem + clist_off + (size_t)grp * (LPA * TILES * 4);
+  double *clist = smem + clist_off + (size_t)grp * ((LPA * TILES + 1) * 4);
+  if (sub < 4) clist[(size_t)LPA * TILES * 4 + sub] = 0.0;  // the group's all-zero list entry
+  wave_lds_fence();
 
   double lane_min = C.shell;
   double cost_ws = 0.0;
@@ -1095,7 +1097,7 @@ int pmaf_create(const pmaf_params *prm, pmaf_planner **out) {
       // circular-field terms: 64 * TILES entries of 4 doubles
       size_t off = 7 * (size_t)n_obs + ((size_t)n_obs + 1) / 2;
       off += off & 1;
-      h->lds_rollout = sizeof(double) * (off + 64 * 4 * 4);
+      h->lds_rollout = sizeof(double) * (off + 64 * 4 * 4 + 8 * 4);  // + one zero entry per group (<= 8 groups)
     }
     h->lds_manager = sizeof(double) * 7 * n_obs;
     REQUIRE(h->lds_rollout <= 160 * 1024, "pmaf_create: obstacle table does not fit in LDS");

@@ -49,7 +49,8 @@ __device__ __forceinline__ int group_min_dpp_i(int v) {
 
 // circForce + attractorForceScaling for the agents of one wave. `act`: the
 // lane's agent takes a step and its gate is open (uniform within the group).
-// clist: this GROUP's list in LDS (LPA*TILES entries of 4 doubles).
+// clist: this GROUP's list in LDS (LPA*TILES entries of 4 doubles + one
+// all-zero entry at index LPA*TILES).
 template <int LPA, int TILES, int MATH>
 __device__ __forceinline__ void circ_and_scale_grp(bool act, int sub, int grp, int type, V3 p, V3 v, double zv,
                                                    V3 goal, V3 g, double dg, const PopConst &C, double k_circ,
@@ -110,15 +111,15 @@ __device__ __forceinline__ void circ_and_scale_grp(bool act, int sub, int grp, i
   if (__any(count > 0)) {
     wave_lds_fence();
     // F = ((0 + c_0) + c_1) + ... per group; a group that has run out of terms adds +0.0 (exact no-op)
+    // (lanes past their group's last term read the group's all-zero slot)
     for (int k = 0; __any(k < count); k += 4) {
 #pragma unroll
       for (int j = 0; j < 4; j++) {
-        const bool more = (k + j) < count;
-        const double *e = clist + (size_t)(more ? (k + j) : 0) * 4;
-        const double cx = e[0], cy = e[1], cz = e[2];
-        F.x = F.x + (more ? cx : 0.0);
-        F.y = F.y + (more ? cy : 0.0);
-        F.z = F.z + (more ? cz : 0.0);
+        const int idx = ((k + j) < count) ? (k + j) : (LPA * TILES);
+        const double *e = clist + (size_t)idx * 4;
+        F.x = F.x + e[0];
+        F.y = F.y + e[1];
+        F.z = F.z + e[2];
       }
     }
     wave_lds_fence();

@@ -116,64 +116,105 @@ __device__ __forceinline__ void circ_and_scale_w64(int lane, V3 p, V3 v, double 
                                                    int n_obs, double *rot_g, unsigned &known_bits,
                                                    LaneObstacles<TILES> &O, double *clist, double &lane_min,
                                                    V3 &F, double &scale, const int ablate = 0) {
+  typedef Mth<MATH> MT;
   const int M = n_obs - 1;
   // goal_vec.normalized(): dg == sqrt(squaredNorm(g)), the value normalized() divides by
-  typedef Mth<MATH> MT;
   const V3 gn = (dg > 0.0) ? MT::div3(g, dg) : g;
   double best_d = C.shell;
   double best_s = 0.0, best_gr = 0.0;  // |ro| and g.ro of the lane's closest obstacle
   int best_i = 0x7fffffff;
-  int count = 0;
+  // ---- sweep geometry (circForce :76-88, attractorForceScaling :201-211) ----
+  V3 ron_t[TILES], rv_t[TILES];
+  double d_t[TILES];
+  bool in_t[TILES];
+  bool any_in = false;
 #pragma unroll
   for (int t = 0; t < TILES; t++) {
     const int i = t * 64 + lane;
     const bool valid = i < M;
-    const V3 op = O.p[t];
-    const V3 ro = op - p;
-    const V3 rv = v - O.v[t];
+    const V3 ro = O.p[t] - p;
+    rv_t[t] = v - O.v[t];
     double s;
-    V3 ron;
-    MT::norm_unit(ro, s, ron);
-    const bool skip = (dot(ron, gn) < -0.01) && (dot(ro, rv) < -0.01);
+    MT::norm_unit(ro, s, ron_t[t]);
+    const bool skip = (dot(ron_t[t], gn) < -0.01) && (dot(ro, rv_t[t]) < -0.01);
     double d = s - (C.rad + O.r[t]);
     d = smax(d, 1e-5);
+    d_t[t] = d;
     if (valid && d < best_d) { best_d = d; best_i = i; best_s = s; best_gr = dot(g, ro); }
     const bool live = valid && !skip;
     if (live && d < lane_min) lane_min = d;
-    const bool in_shell = live && (d < C.shell);
-    if (__any(in_shell) && !(ablate & 4)) {
-      // first contact: latch the rotation vector (rare)
-      const bool need_latch = in_shell && !((known_bits >> t) & 1u);
-      if (__any(need_latch)) {
-        if (need_latch) {
-          V3 rot = calc_rot_vec(TYPE, p, goal, T, n_obs, i, op, mk(O.qx[t], O.qy[t], O.qz[t]));
-          rot_g[i] = rot.x; rot_g[n_obs + i] = rot.y; rot_g[2 * n_obs + i] = rot.z;
-          O.rx[t] = rot.x; O.ry[t] = rot.y; O.rz[t] = rot.z;
-          known_bits |= (1u << t);
-        }
+    in_t[t] = live && (d < C.shell);
+    any_in = any_in || in_t[t];
+  }
+  if (!__any(any_in) || (ablate & 4)) return;  // nothing inside the shell: F stays 0, scale stays 1
+
+  // ---- attractorForceScaling value (:212-226), evaluated SPECULATIVELY: it
+  // depends only on the sweep geometry, so its reduction / sqrt / exp chain is
+  // placed before the circular-field terms and overlaps their normalisations
+  // and the LDS round trip of the force sum instead of following them; it is
+  // applied below iff |F| > 1e-5 (:319)
+  double sc = 1.0;
+  {
+    const double m = wave_min64(best_d);
+    const bool cand = (best_i != 0x7fffffff) && (best_d == m);
+    int bi;
+    if (TILES == 1) {  // obstacle index == lane: lowest candidate lane wins
+      const unsigned long long bm = __ballot(cand);
+      bi = bm ? (__ffsll((long long)bm) - 1) : 0x7fffffff;
+    } else {
+      bi = wave_min64_i(cand ? best_i : 0x7fffffff);
+    }
+    if (bi != 0x7fffffff) {
+      if (dot(g, v) <= 0.0 && zv < C.zv09_lt && dg > 0.15) {  // norm(v) < vmax - 0.1 vmax
+        sc = 0.0;
+      } else {
+        const double w1 = 1 - portable_exp<MATH>(-MT::div(MT::sqrt(m), C.shell));
+        // |ro| and g.ro of the closest obstacle were computed by the lane that
+        // owns it (same operands, same bits as recomputing them here)
+        const int bl = bi & 63;
+        const double sb = readlane_d(best_s, bl), gr = readlane_d(best_gr, bl);
+        double w2 = 1 - MT::div(gr, dg * sb);
+        w2 = w2 * w2;
+        sc = w1 * w2;
       }
-      // per-lane circular-field term, evaluated by every lane (lanes outside
-      // the shell compute values that are discarded by has_c)
-      const V3 rot = mk(O.rx[t], O.ry[t], O.rz[t]);
-      double vn;
-      V3 nv;
-      if (MATH == MATH_FAST) { MT::norm_unit(rv, vn, nv); }
-      else { vn = MT::norm(rv); nv = MT::div3(rv, vn); }
-      const V3 cur = current_vector<MATH>(TYPE, rv, g, ron, rot);
-      const V3 c = MT::div(k_circ, d * d) * cross(nv, cross(cur, nv));
-      const bool has_c = in_shell && (vn != 0);
-      // compact the contributing terms, ascending obstacle index, into LDS
-      const unsigned long long m = __ballot(has_c);
-      if (has_c) {
-        double *e = clist + (size_t)(count + lane_rank(m)) * 4;
-        e[0] = c.x; e[1] = c.y; e[2] = c.z;
-      }
-      count += __popcll(m);
     }
   }
-  // closest obstacle of the sweep (attractorForceScaling :201-211); the
-  // min_obs_dist_ minimum stays per lane and is reduced once after the rollout
-  const double m = wave_min64(best_d);
+
+  // ---- circular-field terms (:89-106) ----
+  int count = 0;
+#pragma unroll
+  for (int t = 0; t < TILES; t++) {
+    if (!__any(in_t[t])) continue;
+    const int i = t * 64 + lane;
+    // first contact: latch the rotation vector (rare)
+    const bool need_latch = in_t[t] && !((known_bits >> t) & 1u);
+    if (__any(need_latch)) {
+      if (need_latch) {
+        V3 rot = calc_rot_vec(TYPE, p, goal, T, n_obs, i, O.p[t], mk(O.qx[t], O.qy[t], O.qz[t]));
+        rot_g[i] = rot.x; rot_g[n_obs + i] = rot.y; rot_g[2 * n_obs + i] = rot.z;
+        O.rx[t] = rot.x; O.ry[t] = rot.y; O.rz[t] = rot.z;
+        known_bits |= (1u << t);
+      }
+    }
+    // evaluated by every lane (lanes outside the shell compute values that are
+    // discarded by has_c)
+    const V3 rot = mk(O.rx[t], O.ry[t], O.rz[t]);
+    const V3 rv = rv_t[t];
+    double vn;
+    V3 nv;
+    if (MATH == MATH_FAST) { MT::norm_unit(rv, vn, nv); }
+    else { vn = MT::norm(rv); nv = MT::div3(rv, vn); }
+    const V3 cur = current_vector<MATH>(TYPE, rv, g, ron_t[t], rot);
+    const V3 c = MT::div(k_circ, d_t[t] * d_t[t]) * cross(nv, cross(cur, nv));
+    const bool has_c = in_t[t] && (vn != 0);
+    // compact the contributing terms, ascending obstacle index, into LDS
+    const unsigned long long m = __ballot(has_c);
+    if (has_c) {
+      double *e = clist + (size_t)(count + lane_rank(m)) * 4;
+      e[0] = c.x; e[1] = c.y; e[2] = c.z;
+    }
+    count += __popcll(m);
+  }
   if (count > 0 && !(ablate & 2)) {
     wave_lds_fence();
     // F = ((0 + c_0) + c_1) + ... front to back; every lane reads the same
@@ -190,31 +231,7 @@ __device__ __forceinline__ void circ_and_scale_w64(int lane, V3 p, V3 v, double 
     }
     wave_lds_fence();
   }
-  // attractorForceScaling (only if |F| > 1e-5, :319)
-  if (sqn(F) >= C.zf_gt && !(ablate & 1)) {  // norm(F) > 1e-5
-    const bool cand = (best_i != 0x7fffffff) && (best_d == m);
-    int bi;
-    if (TILES == 1) {  // obstacle index == lane: lowest candidate lane wins
-      const unsigned long long bm = __ballot(cand);
-      bi = bm ? (__ffsll((long long)bm) - 1) : 0x7fffffff;
-    } else {
-      bi = wave_min64_i(cand ? best_i : 0x7fffffff);
-    }
-    if (bi == 0x7fffffff) {
-      scale = 1;
-    } else if (dot(g, v) <= 0.0 && zv < C.zv09_lt && dg > 0.15) {  // norm(v) < vmax - 0.1 vmax
-      scale = 0.0;
-    } else {
-      const double w1 = 1 - portable_exp<MATH>(-MT::div(MT::sqrt(m), C.shell));
-      // |ro| and g.ro of the closest obstacle were computed by the lane that
-      // owns it (same operands, same bits as recomputing them here)
-      const int bl = bi & 63;
-      const double sb = readlane_d(best_s, bl), gr = readlane_d(best_gr, bl);
-      double w2 = 1 - MT::div(gr, dg * sb);
-      w2 = w2 * w2;
-      scale = w1 * w2;
-    }
-  }
+  if (sqn(F) >= C.zf_gt && !(ablate & 1)) scale = sc;  // norm(F) > 1e-5
 }
 
 }  // namespace pmaf

@@ -177,3 +177,21 @@ def config_scene(name, scene_id=0, dynamic=False):
     c = CONFIGS[name]
     cid = {"C2": 2, "C3": 3, "C5": 5}[name]
     return synthetic_scene(c["n_agents"], c["horizon"], c["n_field"], cid, scene_id, dynamic)
+
+
+def scene_from_record(rec, name="task", seed=0xC0FFEE00 + 9 * 256, horizon=None):
+    """scene dict from a plain record (tests/golden/task_scenes.json: the
+    reference's shipped task files reduced to planner inputs)"""
+    obs = np.asarray(rec["obstacles"], dtype=np.float64)
+    n = int(rec["n_agents"])
+    s = dict(name=name, n_agents=n,
+             max_prediction_steps=(horizon + 1) if horizon else int(rec["max_prediction_steps"]),
+             dt=rec["dt"], velocity_max=rec["velocity_max"], approach_dist=rec["approach_dist"],
+             detect_shell_rad=rec["detect_shell_rad"], agent_mass=1.0, radius=0.05,
+             k_attr=rec["k_attr"], k_circ=rec["k_circ"], k_repel=rec["k_repel"], k_damp=rec["k_damp"],
+             cost_gains=np.asarray(rec["cost_gains"], dtype=np.float64),
+             ws_limits=np.asarray(rec["ws_limits"], dtype=np.float64),
+             start=np.asarray(rec["start"], dtype=np.float64), goal=np.asarray(rec["goal"], dtype=np.float64),
+             obstacles=obs)
+    s["random_vecs"] = random_unit_vectors(SplitMix64(seed), n, obs.shape[0])
+    return s

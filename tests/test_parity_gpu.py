@@ -596,3 +596,29 @@ def test_hip_path_reproduces_the_survey_probe_record(pmaf, scenes):
     final = np.asarray(gold["probe2"]["final_real_position"])
     assert np.abs(pos[-1] - final).max() < 1e-3
     hip.close()
+
+
+def _task_records():
+    import json
+    import os
+    return json.load(open(os.path.join(os.path.dirname(__file__), "golden", "task_scenes.json")))
+
+
+@pytest.mark.parametrize("task", sorted(_task_records()))
+def test_shipped_task_scenes_closed_loop(pmaf, oracle, scenes, task):
+    """every task scene the reference ships (tests/golden/task_scenes.json),
+    as shipped: 10 agents, max_prediction_steps 1500 / 1200, obstacle stream
+    advancing like dynamic_obstacle_node, planned until getDistFromGoal() < 0.01
+    (or 900 ticks); the whole set-point sequence bit-exact against the oracle"""
+    sc = scenes.scene_from_record(_task_records()[task], task)
+    hip, ora = make_pair(pmaf, oracle, sc)
+    bh, ph = drive(hip, sc, 900, True, scenes.advance_live_obstacles, until_reached=True)
+    bo, po = drive(ora, sc, 900, True, scenes.advance_live_obstacles, until_reached=True)
+    hip.stop()
+    assert len(bh) == len(bo)
+    np.testing.assert_array_equal(bh, bo)
+    np.testing.assert_array_equal(ph, po)
+    assert_state_equal(hip, ora)
+    print("%s: %d ticks, final goal distance %.4f, best-agent switches %d" %
+          (task, len(bh), hip.dist_from_goal(), int((np.diff(bh) != 0).sum())))
+    hip.close()

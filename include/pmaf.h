@@ -209,6 +209,16 @@ size_t pmaf_winner_record_doubles(const pmaf_planner *h);
 /* the hipStream_t the handle launches on (as void*), for stream-ordered consumers */
 void *pmaf_stream(pmaf_planner *h);
 
+/* ---- checkpoint / resume (no reference equivalent: its state lives in RAM) ---- */
+/* Serialise the complete planner state of a handle (agents' rotation vectors
+ * and known flags, paths, real agent incl. its trajectory, best-agent copy,
+ * obstacle tables, scoring parameters) into a caller buffer of at least
+ * pmaf_state_size(h) bytes, and restore it into a handle created with the same
+ * dimensions. After a restore the planner continues bit-identically. */
+size_t pmaf_state_size(const pmaf_planner *h);
+int pmaf_save_state(pmaf_planner *h, void *blob, size_t bytes);
+int pmaf_load_state(pmaf_planner *h, const void *blob, size_t bytes);
+
 /* ---- measurement ---- */
 /* enable HIP-event timing of every rollout launch */
 int pmaf_set_profiling(pmaf_planner *h, int32_t enable);

@@ -780,6 +780,7 @@ struct pmaf_planner {
   hipStream_t stream = nullptr;
   hipEvent_t ev_mgr = nullptr;
   std::vector<void *> allocs;
+  std::vector<size_t> alloc_bytes;  // size of every device buffer (state save / load)
   double *h_out = nullptr;      // pinned [P][12] mailbox written by k_manager
   // host copy of the real agent's state (getNextPosition / getNextVelocity /
   // getEEForce / getDistFromGoal must not wait for the running rollout)
@@ -808,6 +809,7 @@ struct pmaf_planner {
     void *p = nullptr;
     HIP_CHECK(hipMalloc(&p, sizeof(T) * (n ? n : 1)));
     allocs.push_back(p);
+    alloc_bytes.push_back(sizeof(T) * (n ? n : 1));
     HIP_CHECK(hipMemsetAsync(p, 0, sizeof(T) * (n ? n : 1), stream));
     return static_cast<T *>(p);
   }
@@ -1603,6 +1605,105 @@ int pmaf_write_winner_records(pmaf_planner *h, void *dst_device, size_t bytes) {
     h->use_device();
     hipLaunchKernelGGL(k_winner, dim3((unsigned)h->D.P), dim3(256), 0, h->stream, h->D, (double *)dst_device);
     HIP_CHECK(hipGetLastError());
+  });
+}
+
+// ---- checkpoint / resume ----------------------------------------------------
+// The blob holds every device buffer of the handle (agents' rotation vectors,
+// known flags, paths, real agent, best-agent copy, obstacle tables ...) plus
+// the host-side planner state (real agent's trajectory, scoring parameters).
+struct StateHeader {
+  uint64_t magic;
+  int32_t abi, P, N, n_obs, cap, n_bufs;
+  int32_t cp_valid, scores_valid, rollout_pending, pad;
+  uint64_t dev_bytes;
+};
+static const uint64_t kStateMagic = 0x504d41465f535431ull;  // "PMAF_ST1"
+
+static size_t state_bytes(const pmaf_planner *h) {
+  size_t n = sizeof(StateHeader) + sizeof(CostParams) + sizeof(PopConst);
+  for (size_t b : h->alloc_bytes) n += b;
+  n += sizeof(double) * 9 * (size_t)h->D.P;                    // host mirror of the real agent
+  for (auto &rp : h->real_path) n += sizeof(uint64_t) + sizeof(double) * rp.size();
+  return n;
+}
+
+size_t pmaf_state_size(const pmaf_planner *h) { return h ? state_bytes(h) : 0; }
+
+int pmaf_save_state(pmaf_planner *h, void *blob, size_t bytes) {
+  return guarded([&] {
+    REQUIRE(h && blob, "pmaf_save_state: NULL argument");
+    REQUIRE(bytes >= state_bytes(h), "pmaf_save_state: buffer too small (see pmaf_state_size)");
+    h->use_device();
+    sync(h);
+    char *w = static_cast<char *>(blob);
+    StateHeader hd{};
+    hd.magic = kStateMagic; hd.abi = PMAF_ABI_VERSION;
+    hd.P = h->D.P; hd.N = h->D.N; hd.n_obs = h->D.n_obs; hd.cap = h->D.cap; hd.n_bufs = (int32_t)h->allocs.size();
+    hd.cp_valid = h->cp_valid; hd.scores_valid = h->scores_valid; hd.rollout_pending = h->rollout_pending;
+    hd.dev_bytes = 0;
+    for (size_t b : h->alloc_bytes) hd.dev_bytes += b;
+    std::memcpy(w, &hd, sizeof(hd)); w += sizeof(hd);
+    std::memcpy(w, &h->cp, sizeof(CostParams)); w += sizeof(CostParams);
+    std::memcpy(w, &h->D.C, sizeof(PopConst)); w += sizeof(PopConst);
+    for (size_t i = 0; i < h->allocs.size(); i++) {
+      HIP_CHECK(hipMemcpyAsync(w, h->allocs[i], h->alloc_bytes[i], hipMemcpyDeviceToHost, h->stream));
+      w += h->alloc_bytes[i];
+    }
+    HIP_CHECK(hipStreamSynchronize(h->stream));
+    const size_t n3 = sizeof(double) * 3 * (size_t)h->D.P;
+    std::memcpy(w, h->real_pos_h.data(), n3); w += n3;
+    std::memcpy(w, h->real_vel_h.data(), n3); w += n3;
+    std::memcpy(w, h->real_force_h.data(), n3); w += n3;
+    for (auto &rp : h->real_path) {
+      uint64_t n = rp.size();
+      std::memcpy(w, &n, sizeof(n)); w += sizeof(n);
+      std::memcpy(w, rp.data(), sizeof(double) * n); w += sizeof(double) * n;
+    }
+  });
+}
+
+int pmaf_load_state(pmaf_planner *h, const void *blob, size_t bytes) {
+  return guarded([&] {
+    REQUIRE(h && blob, "pmaf_load_state: NULL argument");
+    REQUIRE(bytes >= sizeof(StateHeader) + sizeof(CostParams) + sizeof(PopConst), "pmaf_load_state: blob too small");
+    const char *r = static_cast<const char *>(blob);
+    StateHeader hd;
+    std::memcpy(&hd, r, sizeof(hd)); r += sizeof(hd);
+    uint64_t dev = 0;
+    for (size_t b : h->alloc_bytes) dev += b;
+    REQUIRE(hd.magic == kStateMagic && hd.abi == PMAF_ABI_VERSION, "pmaf_load_state: not a pmaf state blob of this ABI version");
+    REQUIRE(hd.P == h->D.P && hd.N == h->D.N && hd.n_obs == h->D.n_obs && hd.cap == h->D.cap &&
+                hd.n_bufs == (int32_t)h->allocs.size() && hd.dev_bytes == dev,
+            "pmaf_load_state: blob was saved from a handle with different dimensions");
+    REQUIRE(bytes >= sizeof(StateHeader) + sizeof(CostParams) + sizeof(PopConst) + dev + sizeof(double) * 9 * (size_t)h->D.P,
+            "pmaf_load_state: blob truncated");
+    h->use_device();
+    sync(h);
+    std::memcpy(&h->cp, r, sizeof(CostParams)); r += sizeof(CostParams);
+    std::memcpy(&h->D.C, r, sizeof(PopConst)); r += sizeof(PopConst);
+    for (size_t i = 0; i < h->allocs.size(); i++) {
+      HIP_CHECK(hipMemcpyAsync(h->allocs[i], r, h->alloc_bytes[i], hipMemcpyHostToDevice, h->stream));
+      r += h->alloc_bytes[i];
+    }
+    HIP_CHECK(hipStreamSynchronize(h->stream));
+    h->download(h->goal_h.data(), h->D.goal, (size_t)h->D.P * 3);  // host copy of the goals
+    const size_t n3 = sizeof(double) * 3 * (size_t)h->D.P;
+    std::memcpy(h->real_pos_h.data(), r, n3); r += n3;
+    std::memcpy(h->real_vel_h.data(), r, n3); r += n3;
+    std::memcpy(h->real_force_h.data(), r, n3); r += n3;
+    const char *end = static_cast<const char *>(blob) + bytes;
+    for (auto &rp : h->real_path) {
+      uint64_t n = 0;
+      REQUIRE(r + sizeof(n) <= end, "pmaf_load_state: blob truncated");
+      std::memcpy(&n, r, sizeof(n)); r += sizeof(n);
+      REQUIRE(r + sizeof(double) * n <= end, "pmaf_load_state: blob truncated");
+      rp.assign(reinterpret_cast<const double *>(r), reinterpret_cast<const double *>(r) + n);
+      r += sizeof(double) * n;
+    }
+    h->cp_valid = hd.cp_valid != 0;
+    h->scores_valid = hd.scores_valid != 0;
+    h->rollout_pending = hd.rollout_pending != 0;
   });
 }
 

@@ -70,6 +70,9 @@ SYMBOLS = {
     "pmaf_write_winner_records": (C.c_int, [_V, _V, C.c_size_t]),
     "pmaf_winner_record_doubles": (C.c_size_t, [_V]),
     "pmaf_stream": (_V, [_V]),
+    "pmaf_state_size": (C.c_size_t, [_V]),
+    "pmaf_save_state": (C.c_int, [_V, _V, C.c_size_t]),
+    "pmaf_load_state": (C.c_int, [_V, _V, C.c_size_t]),
     "pmaf_set_profiling": (C.c_int, [_V, C.c_int32]),
     "pmaf_get_kernel_stats": (C.c_int, [_V, _dp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "pmaf_reset_kernel_stats": (C.c_int, [_V]),
@@ -348,6 +351,16 @@ class PmafPlanner:
 
     def write_winner_records(self, device_ptr, nbytes):
         self._chk(self.L.pmaf_write_winner_records(self._h, C.c_void_p(device_ptr), nbytes))
+
+    def save_state(self):
+        n = int(self.L.pmaf_state_size(self._h))
+        buf = np.zeros(n, dtype=np.uint8)
+        self._chk(self.L.pmaf_save_state(self._h, buf.ctypes.data_as(C.c_void_p), n))
+        return buf
+
+    def load_state(self, blob):
+        blob = np.ascontiguousarray(blob, dtype=np.uint8)
+        self._chk(self.L.pmaf_load_state(self._h, blob.ctypes.data_as(C.c_void_p), blob.size))
 
     def stream(self):
         return self.L.pmaf_stream(self._h)

@@ -622,3 +622,50 @@ def test_shipped_task_scenes_closed_loop(pmaf, oracle, scenes, task):
     print("%s: %d ticks, final goal distance %.4f, best-agent switches %d" %
           (task, len(bh), hip.dist_from_goal(), int((np.diff(bh) != 0).sum())))
     hip.close()
+
+
+def test_checkpoint_resume_is_bit_identical(pmaf, oracle, scenes):
+    """pmaf_save_state / pmaf_load_state: a planner restored from a blob (into a
+    fresh handle) continues exactly like the original and like the oracle"""
+    sc = scenes.config_scene("C2", scene_id=2, dynamic=True)
+    hip, ora = make_pair(pmaf, oracle, sc)
+    obs = sc["obstacles"].copy()
+    for t in range(15):
+        assert hip.tick(obs, sc["dt"], sc["cost_gains"], sc["ws_limits"]) == ora.tick(obs, sc["dt"], sc["cost_gains"], sc["ws_limits"])
+        obs = scenes.advance_live_obstacles(obs)
+    blob = hip.save_state()
+    obs_at_save = obs.copy()
+    ref = []
+    for t in range(12):
+        b = hip.tick(obs, sc["dt"], sc["cost_gains"], sc["ws_limits"])
+        assert b == ora.tick(obs, sc["dt"], sc["cost_gains"], sc["ws_limits"])
+        ref.append((b, hip.real_state()[0].copy()))
+        obs = scenes.advance_live_obstacles(obs)
+    hip.stop()
+    paths_ref, n_ref = hip.paths()
+    traj_ref = hip.real_path()
+    # restore into a brand-new handle (different initial contents) and replay
+    other = dict(sc)
+    other["random_vecs"] = sc["random_vecs"][::-1].copy()
+    other["goal"] = sc["goal"] + 0.1          # everything comes from the blob, incl. goal and scalars
+    other["velocity_max"] = 0.3
+    hip2 = pmaf.PmafPlanner(other, device=0)
+    hip2.load_state(blob)
+    obs = obs_at_save
+    for t in range(12):
+        b = hip2.tick(obs, sc["dt"], sc["cost_gains"], sc["ws_limits"])
+        assert b == ref[t][0]
+        np.testing.assert_array_equal(hip2.real_state()[0], ref[t][1])
+        obs = scenes.advance_live_obstacles(obs)
+    hip2.stop()
+    p2, n2 = hip2.paths()
+    np.testing.assert_array_equal(n2, n_ref)
+    np.testing.assert_array_equal(p2, paths_ref)
+    np.testing.assert_array_equal(hip2.real_path(), traj_ref)
+    assert hip2.dist_from_goal() == ora.dist_from_goal()
+    assert_state_equal(hip2, ora)
+    # a blob from a differently sized handle is refused
+    small = pmaf.PmafPlanner(scenes.config_scene("C1"), device=0)
+    with pytest.raises(pmaf.PmafError):
+        small.load_state(blob)
+    small.close(); hip.close(); hip2.close()

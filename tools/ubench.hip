@@ -6,8 +6,9 @@
 #include <vector>
 #define N_IT 4096
 __device__ __forceinline__ unsigned long long now() { return __builtin_amdgcn_s_memtime(); }
-template <int OP>
+template <int OP, int ACTIVE = 64>
 __global__ __launch_bounds__(64) void k(double *out, unsigned long long *cyc, double seed) {
+  if ((int)threadIdx.x >= ACTIVE) return;  // EXEC keeps only the low ACTIVE lanes for the whole kernel
   double a = seed + threadIdx.x * 1e-3, b = 1.0000001 + threadIdx.x * 1e-9, c = 0.5, d = seed * 0.3, e = seed * 0.7;
   unsigned long long t0 = now();
   for (int i = 0; i < N_IT; i++) {
@@ -28,11 +29,11 @@ __global__ __launch_bounds__(64) void k(double *out, unsigned long long *cyc, do
   out[blockIdx.x * 64 + threadIdx.x] = a + c + d + e;
   if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
 }
-template <int OP> void run(const char *name, int ops) {
+template <int OP, int ACTIVE = 64> void run(const char *name, int ops) {
   double *out; unsigned long long *cyc;
   hipMalloc(&out, 64 * 64 * 8); hipMalloc(&cyc, 64 * 8);
-  hipLaunchKernelGGL(k<OP>, dim3(64), dim3(64), 0, 0, out, cyc, 1.25);
-  hipLaunchKernelGGL(k<OP>, dim3(64), dim3(64), 0, 0, out, cyc, 1.25);
+  hipLaunchKernelGGL((k<OP, ACTIVE>), dim3(64), dim3(64), 0, 0, out, cyc, 1.25);
+  hipLaunchKernelGGL((k<OP, ACTIVE>), dim3(64), dim3(64), 0, 0, out, cyc, 1.25);
   hipDeviceSynchronize();
   std::vector<unsigned long long> h(64); hipMemcpy(h.data(), cyc, 64 * 8, hipMemcpyDeviceToHost);
   double s = 0; for (auto v : h) s += v; s /= 64;
@@ -44,6 +45,10 @@ int main() {
   run<2>("dep div", 1); run<3>("3 indep div", 3); run<4>("dep sqrt+add", 1); run<5>("3 indep sqrt+add", 3);
   run<6>("readlane x2 + add", 1); run<7>("shfl_xor(bpermute) min + add", 1); run<8>("dpp x2 min + add", 1);
   run<9>("uniform branch + op", 1);
+  // does a partially filled wave issue faster? (EXEC with only the low 32 / 16 lanes set)
+  run<1, 32>("4 indep mul, 32 active lanes", 4); run<1, 16>("4 indep mul, 16 active lanes", 4);
+  run<10, 32>("dep fma, 32 active lanes", 1); run<10, 16>("dep fma, 16 active lanes", 1);
+  run<3, 32>("3 indep div, 32 active lanes", 3); run<5, 32>("3 indep sqrt+add, 32 active lanes", 3);
   int clk = 0; hipDeviceGetAttribute(&clk, hipDeviceAttributeClockRate, 0); printf("clockRate kHz %d\n", clk);
   int wc = 0; hipDeviceGetAttribute(&wc, hipDeviceAttributeWallClockRate, 0); printf("wallClockRate kHz %d\n", wc);
   return 0;

@@ -126,3 +126,89 @@ def all_gather_positions(local_pos, dist, world):
         return local.numpy()
     dist.all_gather_into_tensor(out, local)
     return out.numpy()
+
+
+class AgentRangeShard:
+    """One rank's share of ONE population split by contiguous agent range
+    (the fallback of SURVEY.md 8e for a population too large for one GPU).
+
+    Every rank owns a planner holding agents [a0, a1) of the population (their
+    types, gains and Random vectors) and a replica of the real agent. Per tick:
+      1. local costs of the finished rollouts (pmaf_evaluate on the shard);
+      2. ONE all-gather of the per-rank cost vectors (+ the local candidates'
+         type and Random vectors, needed by whoever wins);
+      3. the global selection, identical on every rank: first minimum over the
+         concatenated costs, 0.9 hysteresis against the previous global best
+         (merge_agent_ranges = CfManager::evaluateAgents :336-353);
+      4. the winner's heuristic is installed as the shard's best-agent copy
+         (pmaf_set_best) and every rank steps its replica of the real agent
+         (bit-identical inputs -> bit-identical replicas), resets and restarts
+         its agents.
+    Gains must be uniform over the agents (they are in the reference:
+    B/src/panda_bimanual_control.cpp:464-468), because the real step takes the
+    best agent's gains.
+
+    `gather(list_of_arrays_per_local_shard) -> list over ALL shards in rank
+    order` abstracts the collective: torch.distributed all_gather_object /
+    all_gather in a multi-process run, identity when one process drives all
+    shards (tests)."""
+
+    def __init__(self, planner_cls, scene, a0, a1, **planner_kw):
+        from . import scenes as _scenes
+        n = int(scene["n_agents"])
+        types = np.asarray(scene.get("agent_types", _scenes.default_agent_types(n)), dtype=np.int32)
+        sub = dict(scene)
+        sub["n_agents"] = a1 - a0
+        sub["agent_types"] = types[a0:a1].copy()
+        sub["random_vecs"] = np.ascontiguousarray(scene["random_vecs"][a0:a1])
+        for k in ("k_attr", "k_circ", "k_repel", "k_damp"):
+            g = np.broadcast_to(np.asarray(scene[k], dtype=np.float64), (n,))
+            if not np.all(g == g[0]):
+                raise ValueError("agent-range sharding needs uniform gains (%s)" % k)
+            sub[k] = float(g[0])
+        self.a0, self.a1 = a0, a1
+        self.types = sub["agent_types"]
+        self.rand = sub["random_vecs"]
+        self.scene = sub
+        self.planner = planner_cls(sub, **planner_kw)
+
+    # -- step 1 / 2: what this shard contributes to the all-gather
+    def local_costs(self, cost_gains, ws):
+        self.planner.stop()
+        self.planner.evaluate(cost_gains, ws)  # local selection result is discarded
+        return np.asarray(self.planner.costs(), dtype=np.float64)
+
+    def candidate(self, local_index):
+        """(type, random vectors) of one of this shard's agents"""
+        return int(self.types[local_index]), self.rand[local_index]
+
+    # -- step 4
+    def apply_global_best(self, best_type, best_rand, obstacles, dt):
+        p = self.planner
+        p.set_best(1, best_type, best_rand)   # id only has to be a valid local id: selection is global
+        p.move_real(obstacles, dt, 1, 0)      # uniform gains: any local agent's
+        pos, vel, _ = p.real_state()
+        p.reset_agents(pos, vel, obstacles)
+        p.start()
+        return pos
+
+
+def sharded_tick(shards, prev_best_global, obstacles, dt, cost_gains, ws, gather=None):
+    """One planner tick of a population split over `shards` (all shards of this
+    process; with one shard per rank pass gather = an all-gather of Python
+    objects across ranks). Returns (global best index, next real position)."""
+    local = [s.local_costs(cost_gains, ws) for s in shards]
+    costs = gather(local) if gather is not None else local
+    best = merge_agent_ranges(costs, prev_best_global)
+    # the owner of the winner publishes its heuristic (type + Random vectors)
+    offs = np.cumsum([0] + [len(c) for c in costs])
+    owner = int(np.searchsorted(offs, best, side="right") - 1)
+    info_local = []
+    for s in shards:
+        info_local.append(s.candidate(best - s.a0) if s.a0 <= best < s.a1 else None)
+    infos = gather(info_local) if gather is not None else info_local
+    btype, brand = infos[owner]
+    pos = None
+    for s in shards:
+        pos = s.apply_global_best(btype, brand, obstacles, dt)
+    return best, pos

@@ -213,7 +213,6 @@ class CfManager {
   std::vector<double> getPredictionTimes() {                                        // :200-206
     require();
     std::vector<double> out(n_agents_, 0.0);
-    pmaf_set_profiling(h_, 1);
     if (pmaf_get_prediction_times_ns(h_, out.data()) != PMAF_OK) out.assign(n_agents_, 0.0);
     return out;
   }

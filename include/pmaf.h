@@ -187,9 +187,10 @@ int pmaf_get_real_path(pmaf_planner *h, int32_t pop, double *out,
 int pmaf_get_dist_from_goal(pmaf_planner *h, double *out);
 /* getBestAgentType (cf_manager.h:73): type [P] (-1 = none yet), id [P] 1-based (0 = none) */
 int pmaf_get_best(pmaf_planner *h, int32_t *type, int32_t *id);
-/* getPredictionTimes (B/src/cf_manager.cpp:200-206): duration of the last
- * rollout launch in ns, from HIP events on the handle's stream, [P][N] (all
- * agents of a launch share it). Requires pmaf_set_profiling(h, 1). */
+/* getPredictionTimes (B/src/cf_manager.cpp:200-206; CfAgent::prediction_time_,
+ * B/src/cf_agent.cpp:308-331): duration of each agent's last rollout in ns,
+ * [P][N], from the device's constant-rate clock (wall_clock64) read by the
+ * agent's wave at the start and the end of its rollout. */
 int pmaf_get_prediction_times_ns(pmaf_planner *h, double *out);
 
 /* ---- state transfer / sharding support (no reference equivalent) ---- */

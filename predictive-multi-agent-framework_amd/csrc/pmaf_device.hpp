@@ -368,22 +368,23 @@ __device__ __forceinline__ int closest_other(const ObsTab &T, int n_obs, int id,
 // calculateRotationVector, B/src/cf_agent.cpp:408-412 (Goal), 428-461
 // (Obstacle), 477-518 (GoalObstacle), 539-543 (Vel), 559-566 (Random),
 // 599-611 (Had)
-// own_pos = position of obstacle `id` (the caller has it in registers; it is
-// the same value as T.pos(id)); T is only read for the closest-other search.
-__device__ __forceinline__ V3 calc_rot_vec(int type, V3 agent_pos, V3 goal_pos, const ObsTab &T,
-                                           int n_obs, int id, V3 own_pos, V3 rand_vec) {
+// own_pos = position of obstacle `id`; closest_pos = position of the field
+// obstacle nearest to it (closest_other; only read by the Obstacle and
+// GoalObstacle heuristics). The tuned kernels find it with a cooperative
+// search over the lanes' register copies, the generic kernel / k_manager scan
+// the LDS table (calc_rot_vec below).
+__device__ __forceinline__ V3 calc_rot_vec_c(int type, V3 agent_pos, V3 goal_pos, int n_obs, V3 own_pos,
+                                             V3 closest_pos, V3 rand_vec) {
   if (type == T_GOAL || type == T_VEL) return mk(0.0, 0.0, 1.0);
   if (type == T_OBST) {
     if (n_obs < 2) return mk(0.0, 0.0, 1.0);
-    int c = closest_other(T, n_obs, id, own_pos);
-    V3 obstacle_vec = T.pos(c) - own_pos;
+    V3 obstacle_vec = closest_pos - own_pos;
     V3 to_obs = normalized(own_pos - agent_pos);
     V3 cur = to_obs * dot(obstacle_vec, to_obs) - obstacle_vec;
     return normalized(cross(cur, to_obs));
   }
   if (type == T_GOALOBST) {
-    int c = closest_other(T, n_obs, id, own_pos);
-    V3 obstacle_vec = T.pos(c) - own_pos;
+    V3 obstacle_vec = closest_pos - own_pos;
     V3 to_obs = normalized(own_pos - agent_pos);
     V3 obst_cur = to_obs * dot(obstacle_vec, to_obs) - obstacle_vec;
     V3 goal_vec = goal_pos - agent_pos;
@@ -407,6 +408,13 @@ __device__ __forceinline__ V3 calc_rot_vec(int type, V3 agent_pos, V3 goal_pos, 
     return c / norm(c);
   }
   return mk(0.0, 0.0, 0.0);
+}
+
+__device__ __forceinline__ V3 calc_rot_vec(int type, V3 agent_pos, V3 goal_pos, const ObsTab &T,
+                                           int n_obs, int id, V3 own_pos, V3 rand_vec) {
+  V3 closest_pos = own_pos;
+  if ((type == T_OBST && n_obs >= 2) || type == T_GOALOBST) closest_pos = T.pos(closest_other(T, n_obs, id, own_pos));
+  return calc_rot_vec_c(type, agent_pos, goal_pos, n_obs, own_pos, closest_pos, rand_vec);
 }
 
 // ---- circForce + attractorForceScaling over the group's lanes ------------

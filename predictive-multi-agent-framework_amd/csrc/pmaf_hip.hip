@@ -71,6 +71,7 @@ struct DevView {
   double *best_rnd;          // [P][3][n_obs]
   int32_t *best_idx;         // [P] last evaluate result
   unsigned long long *step_counter;  // [1] agent-steps executed by all rollouts
+  unsigned long long *pred_ticks;    // [P][N] rollout duration in wall_clock64() ticks (CfAgent::prediction_time_)
   const double *zsent_lt;            // [P] exact squared-distance boundary of the repel range test
   int ablate;                        // timing experiments only (PMAF_ABLATE), 0 in production
 };
@@ -96,6 +97,7 @@ __global__ __launch_bounds__(64) void k_rollout(DevView D, CostParams CP) {
   const int aa = active ? a : 0;
   const int n_obs = D.n_obs;
   const PopConst C = D.C;
+  const unsigned long long t_begin = wall_clock64();
 
   ObsTab T = carve_obstab(smem, n_obs);
   int32_t *s_known = reinterpret_cast<int32_t *>(smem + 7 * n_obs);
@@ -185,6 +187,7 @@ __global__ __launch_bounds__(64) void k_rollout(DevView D, CostParams CP) {
       D.goal_dist[pa] = dgf;
       if (ran) D.reached[pa] = dgf < 0.100001;  // B/src/cf_agent.cpp:330-337
       atomicAdd(D.step_counter, (unsigned long long)(n - 1));
+      D.pred_ticks[pa] = wall_clock64() - t_begin;
     }
   }
 }
@@ -198,14 +201,11 @@ template <int TILES, int TYPE, int MATH>
 __device__ __forceinline__ void rollout_w64_body(const DevView &D, const CostParams &CP, const int lane,
                                                  const int pop, const int a) {
   extern __shared__ double smem[];
+  const unsigned long long t_begin = wall_clock64();
   const int n_obs = D.n_obs;
   const int M = n_obs - 1;
   const PopConst C = D.C;
   const size_t pa = (size_t)pop * D.N + a;
-  // only the "closest other obstacle" search of these two heuristics reads the table
-  constexpr bool need_table = (TYPE == T_OBST) || (TYPE == T_GOALOBST);
-
-  ObsTab T = carve_obstab(smem, n_obs);
   const double *src = D.obs_start + (size_t)pop * 7 * n_obs;
   const int32_t *ks = D.known_start + (size_t)pop * n_obs;
   double *rot_g = D.rot + pa * 3 * n_obs;
@@ -225,13 +225,11 @@ __device__ __forceinline__ void rollout_w64_body(const DevView &D, const CostPar
     if (TYPE == T_RANDOM) { O.qx[t] = rnd_g[ii]; O.qy[t] = rnd_g[n_obs + ii]; O.qz[t] = rnd_g[2 * n_obs + ii]; }
     else { O.qx[t] = 0.0; O.qy[t] = 0.0; O.qz[t] = 0.0; }
     if (valid && ks[ii]) known_bits |= (1u << t);
-    if (need_table && valid) { T.px[i] = O.p[t].x; T.py[i] = O.p[t].y; T.pz[i] = O.p[t].z; }
   }
   // trailing repulsive obstacle, wave-uniform
   V3 sent_p = mk(src[M], src[n_obs + M], src[2 * n_obs + M]);
   const V3 sent_v = mk(src[3 * n_obs + M], src[4 * n_obs + M], src[5 * n_obs + M]);
   const double sent_r = src[6 * n_obs + M];
-  if (need_table) wave_lds_fence();
 
   const V3 goal = mk(D.goal[pop * 3], D.goal[pop * 3 + 1], D.goal[pop * 3 + 2]);
   const V3 init_pos = mk(D.agent_init_pos[pop * 3], D.agent_init_pos[pop * 3 + 1], D.agent_init_pos[pop * 3 + 2]);
@@ -269,7 +267,7 @@ __device__ __forceinline__ void rollout_w64_body(const DevView &D, const CostPar
     V3 F = mk(0.0, 0.0, 0.0);
     double scale = 1.0;
     if (gate && !(D.ablate & 8))
-      circ_and_scale_w64<TILES, TYPE, MATH>(lane, p, v, zv, goal, g, dg, C, k_circ, T, n_obs, rot_g, known_bits, O,
+      circ_and_scale_w64<TILES, TYPE, MATH>(lane, p, v, zv, goal, g, dg, C, k_circ, n_obs, rot_g, known_bits, O,
                                       clist, lane_min, F, scale, D.ablate);
     V3 new_pos;
     finish_step_w64<MATH>(p, v, verr, F, scale, C, k_attr, k_repel, k_damp, sent_p, sent_r, zsent_lt, new_pos);
@@ -287,13 +285,8 @@ __device__ __forceinline__ void rollout_w64_body(const DevView &D, const CostPar
     ran = true;
     // predictObstacles, B/src/cf_agent.cpp:270-276, in registers
 #pragma unroll
-    for (int t = 0; t < TILES; t++) {
-      O.p[t] = O.p[t] + O.v[t] * C.dt;
-      int i = t * 64 + lane;
-      if (need_table && i < M) { T.px[i] = O.p[t].x; T.py[i] = O.p[t].y; T.pz[i] = O.p[t].z; }
-    }
+    for (int t = 0; t < TILES; t++) O.p[t] = O.p[t] + O.v[t] * C.dt;
     sent_p = sent_p + sent_v * C.dt;
-    if (need_table) wave_lds_fence();
   }
 
   const double min_obs = wave_min64(lane_min);
@@ -313,6 +306,7 @@ __device__ __forceinline__ void rollout_w64_body(const DevView &D, const CostPar
     D.goal_dist[pa] = dg;
     if (ran) D.reached[pa] = dg < 0.100001;  // B/src/cf_agent.cpp:330-337
     atomicAdd(D.step_counter, (unsigned long long)(n - 1));
+    D.pred_ticks[pa] = wall_clock64() - t_begin;
   }
 }
 
@@ -339,6 +333,7 @@ template <int LPA, int TILES, int MATH>
 __global__ __launch_bounds__(64) void k_rollout_grp(DevView D, CostParams CP) {
   extern __shared__ double smem[];
   constexpr int APW = 64 / LPA;
+  const unsigned long long t_begin = wall_clock64();
   const int lane = threadIdx.x;
   const int pop = blockIdx.y;
   const int sub = lane % LPA;
@@ -351,19 +346,11 @@ __global__ __launch_bounds__(64) void k_rollout_grp(DevView D, CostParams CP) {
   const PopConst C = D.C;
   const size_t pa = (size_t)pop * D.N + aa;
   const int type = D.types[aa];
-  // the "closest other obstacle" search of Obstacle / GoalObstacle agents reads the LDS table
-  const bool wave_needs_table = __any(active && (type == T_OBST || type == T_GOALOBST));
-
-  ObsTab T = carve_obstab(smem, n_obs);
   const double *src = D.obs_start + (size_t)pop * 7 * n_obs;
   const int32_t *ks = D.known_start + (size_t)pop * n_obs;
   double *rot_g = D.rot + pa * 3 * n_obs;
   const double *rnd_g = D.rnd + pa * 3 * n_obs;
 
-  // LDS table of obstacle positions, maintained by lanes l = obstacle index (mod 64)
-  if (wave_needs_table) {
-    for (int i = lane; i < 3 * n_obs; i += 64) smem[i] = src[i];
-  }
   LaneObstacles<TILES> O;
   unsigned known_bits = 0u;
 #pragma unroll
@@ -417,7 +404,7 @@ __global__ __launch_bounds__(64) void k_rollout_grp(DevView D, CostParams CP) {
     V3 F = mk(0.0, 0.0, 0.0);
     double scale = 1.0;
     if (__any(run && gate))
-      circ_and_scale_grp<LPA, TILES, MATH>(run && gate, sub, grp, type, p, v, zv, goal, g, dg, C, k_circ, T, n_obs, rot_g,
+      circ_and_scale_grp<LPA, TILES, MATH>(run && gate, sub, grp, type, p, v, zv, goal, g, dg, C, k_circ, n_obs, rot_g,
                                      known_bits, O, clist, lane_min, F, scale);
     V3 new_pos;
     V3 nv = v;
@@ -436,19 +423,10 @@ __global__ __launch_bounds__(64) void k_rollout_grp(DevView D, CostParams CP) {
       n++;
       ran = true;
     }
-    // predictObstacles, B/src/cf_agent.cpp:270-276, in registers (+ the LDS table when a latch may search it)
+    // predictObstacles, B/src/cf_agent.cpp:270-276, in registers
 #pragma unroll
     for (int t = 0; t < TILES; t++) O.p[t] = O.p[t] + O.v[t] * C.dt;
     sent_p = sent_p + sent_v * C.dt;
-    if (wave_needs_table) {
-      // table entry i is advanced by lane i (mod 64) with the same arithmetic
-      for (int i = lane; i < M; i += 64) {
-        T.px[i] = T.px[i] + src[3 * n_obs + i] * C.dt;
-        T.py[i] = T.py[i] + src[4 * n_obs + i] * C.dt;
-        T.pz[i] = T.pz[i] + src[5 * n_obs + i] * C.dt;
-      }
-      wave_lds_fence();
-    }
   }
 
   const double min_obs = group_min_dpp<LPA>(lane_min);
@@ -469,6 +447,7 @@ __global__ __launch_bounds__(64) void k_rollout_grp(DevView D, CostParams CP) {
       D.goal_dist[pa] = dg;
       if (ran) D.reached[pa] = dg < 0.100001;  // B/src/cf_agent.cpp:330-337
       atomicAdd(D.step_counter, (unsigned long long)(n - 1));
+      D.pred_ticks[pa] = wall_clock64() - t_begin;
     }
   }
 }
@@ -1142,6 +1121,7 @@ int pmaf_create(const pmaf_params *prm, pmaf_planner **out) {
     D.best_rnd = h->dalloc<double>((size_t)P * 3 * n_obs);
     D.best_idx = h->dalloc<int32_t>(P);
     D.step_counter = h->dalloc<unsigned long long>(1);
+    D.pred_ticks = h->dalloc<unsigned long long>(PN);
     double *zsent = h->dalloc<double>(P);
     D.zsent_lt = zsent;
     h->d_reset_in = h->dalloc<double>(P * 6);
@@ -1566,8 +1546,13 @@ int pmaf_get_prediction_times_ns(pmaf_planner *h, double *out) {
   return guarded([&] {
     GETTER_PROLOGUE("pmaf_get_prediction_times_ns")
     REQUIRE(out, "NULL out");
-    if (!h->profiling) fail(PMAF_ERR_STATE, "pmaf_get_prediction_times_ns: enable pmaf_set_profiling first");
-    for (size_t i = 0; i < PN; i++) out[i] = h->last_rollout_ms * 1e6;
+    // per-agent device clock (wall_clock64: constant-rate counter, rate in kHz)
+    int khz = 0;
+    HIP_CHECK(hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, h->device));
+    if (khz <= 0) khz = 100000;
+    std::vector<unsigned long long> t(PN);
+    h->download(t.data(), D.pred_ticks, PN);
+    for (size_t i = 0; i < PN; i++) out[i] = (double)t[i] * (1e6 / (double)khz);
   });
 }
 

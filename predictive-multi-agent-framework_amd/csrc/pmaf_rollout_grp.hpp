@@ -47,6 +47,55 @@ __device__ __forceinline__ int group_min_dpp_i(int v) {
   return v;
 }
 
+__device__ __forceinline__ V3 shfl_v3(V3 a, int src) {
+  return mk(__shfl(a.x, src), __shfl(a.y, src), __shfl(a.z, src));
+}
+
+// closest_other_w64 (pmaf_rollout_w64.hpp) for groups of LPA lanes: every
+// iteration serves the first latching lane of EACH group (the groups are
+// different agents, so their searches are independent); the group's lanes scan
+// their register copies of the obstacles, group argmin with lowest-index ties.
+template <int LPA, int TILES, int MATH>
+__device__ __forceinline__ V3 closest_other_grp(bool srch, int t, int sub, int grp, int M,
+                                                const LaneObstacles<TILES> &O) {
+  const int lane = grp * LPA + sub;
+  const unsigned long long gmask = ((1ull << LPA) - 1ull) << (grp * LPA);
+  V3 cpos = mk(0.0, 0.0, 0.0);
+  unsigned long long pend = __ballot(srch);
+  while (pend) {
+    const unsigned long long gp = pend & gmask;
+    const bool has = gp != 0ull;
+    const int L = has ? (__ffsll((long long)gp) - 1) : lane;  // lane (in the wave) served in this group
+    const int id = t * LPA + (L - grp * LPA);
+    V3 own = mk(0.0, 0.0, 0.0);
+#pragma unroll
+    for (int u = 0; u < TILES; u++)
+      if (u == t) own = shfl_v3(O.p[u], L);
+    double bd = 100.0;
+    int bj = 0x7fffffff;
+#pragma unroll
+    for (int u = 0; u < TILES; u++) {
+      const int j = u * LPA + sub;
+      const double d = Mth<MATH>::norm(own - O.p[u]);
+      if (has && j < M && j != id && d < bd) { bd = d; bj = j; }
+    }
+    const double md = group_min_dpp<LPA>(bd);
+    const int mj = group_min_dpp_i<LPA>((bj != 0x7fffffff && bd == md) ? bj : 0x7fffffff);
+    const int c = (mj == 0x7fffffff) ? 0 : mj;
+    const int csrc = grp * LPA + (c & (LPA - 1));
+    V3 cp = mk(0.0, 0.0, 0.0);
+#pragma unroll
+    for (int u = 0; u < TILES; u++) {
+      const V3 q = shfl_v3(O.p[u], csrc);
+      if ((c / LPA) == u) cp = q;
+    }
+    const bool served = has && (lane == L);
+    if (served) cpos = cp;
+    pend &= ~__ballot(served);
+  }
+  return cpos;
+}
+
 // circForce + attractorForceScaling for the agents of one wave. `act`: the
 // lane's agent takes a step and its gate is open (uniform within the group).
 // clist: this GROUP's list in LDS (LPA*TILES entries of 4 doubles + one
@@ -54,7 +103,7 @@ __device__ __forceinline__ int group_min_dpp_i(int v) {
 template <int LPA, int TILES, int MATH>
 __device__ __forceinline__ void circ_and_scale_grp(bool act, int sub, int grp, int type, V3 p, V3 v, double zv,
                                                    V3 goal, V3 g, double dg, const PopConst &C, double k_circ,
-                                                   const ObsTab &T, int n_obs, double *rot_g, unsigned &known_bits,
+                                                   int n_obs, double *rot_g, unsigned &known_bits,
                                                    LaneObstacles<TILES> &O, double *clist, double &lane_min, V3 &F,
                                                    double &scale) {
   typedef Mth<MATH> MT;
@@ -86,8 +135,11 @@ __device__ __forceinline__ void circ_and_scale_grp(bool act, int sub, int grp, i
     if (__any(in_shell)) {
       const bool need_latch = in_shell && !((known_bits >> t) & 1u);
       if (__any(need_latch)) {
+        V3 cpos = op;
+        const bool srch = need_latch && (type == T_OBST || type == T_GOALOBST);
+        if (__any(srch)) cpos = closest_other_grp<LPA, TILES, MATH>(srch, t, sub, grp, M, O);
         if (need_latch) {
-          V3 rot = calc_rot_vec(type, p, goal, T, n_obs, i, op, mk(O.qx[t], O.qy[t], O.qz[t]));
+          V3 rot = calc_rot_vec_c(type, p, goal, n_obs, op, cpos, mk(O.qx[t], O.qy[t], O.qz[t]));
           rot_g[i] = rot.x; rot_g[n_obs + i] = rot.y; rot_g[2 * n_obs + i] = rot.z;
           O.rx[t] = rot.x; O.ry[t] = rot.y; O.rz[t] = rot.z;
           known_bits |= (1u << t);

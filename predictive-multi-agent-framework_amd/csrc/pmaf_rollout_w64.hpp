@@ -107,12 +107,57 @@ __device__ __forceinline__ int lane_rank(unsigned long long m) {
   return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
 }
 
+__device__ __forceinline__ V3 readlane_v3(V3 a, int lane) {
+  return mk(readlane_d(a.x, lane), readlane_d(a.y, lane), readlane_d(a.z, lane));
+}
+
+// "nearest other field obstacle" of the Obstacle / GoalObstacle heuristics
+// (B/src/cf_agent.cpp:434-446 / :480-492: ascending scan, `min_dist > d` with
+// min_dist = 100 initially, so the lowest index among the exact minima wins and
+// index 0 is the answer when nothing is closer than 100), for every lane that
+// latches its slot-`t` obstacle this step: the reference's O(M) scan is done
+// by the whole wave on the lanes' register copies of the obstacles (one sqrt
+// chain + one DPP argmin per latching lane instead of M dependent sqrt chains).
+// Returns, in the latching lanes, the position of that closest obstacle.
+template <int TILES, int MATH>
+__device__ __forceinline__ V3 closest_other_w64(bool need_latch, int t, int lane, int M,
+                                                const LaneObstacles<TILES> &O) {
+  V3 cpos = mk(0.0, 0.0, 0.0);
+  unsigned long long pend = __ballot(need_latch);
+  while (pend) {
+    const int L = __ffsll((long long)pend) - 1;  // wave-uniform
+    pend &= pend - 1;
+    const int id = t * 64 + L;
+    V3 own = mk(0.0, 0.0, 0.0);
+#pragma unroll
+    for (int u = 0; u < TILES; u++)
+      if (u == t) own = readlane_v3(O.p[u], L);
+    double bd = 100.0;
+    int bj = 0x7fffffff;
+#pragma unroll
+    for (int u = 0; u < TILES; u++) {
+      const int j = u * 64 + lane;
+      const double d = Mth<MATH>::norm(own - O.p[u]);
+      if (j < M && j != id && d < bd) { bd = d; bj = j; }
+    }
+    const double md = wave_min64(bd);
+    const int mj = wave_min64_i((bj != 0x7fffffff && bd == md) ? bj : 0x7fffffff);
+    const int c = (mj == 0x7fffffff) ? 0 : mj;
+    V3 cp = mk(0.0, 0.0, 0.0);
+#pragma unroll
+    for (int u = 0; u < TILES; u++)
+      if ((c >> 6) == u) cp = readlane_v3(O.p[u], c & 63);
+    if (lane == L) cpos = cp;
+  }
+  return cpos;
+}
+
 // circForce (B/src/cf_agent.cpp:72-108) + attractorForceScaling (:195-227)
 // for one agent per wave. clist: LDS, 64*TILES entries of 4 doubles.
 // zv = squaredNorm(v), dg = norm(g) (already computed by the caller).
 template <int TILES, int TYPE, int MATH>
 __device__ __forceinline__ void circ_and_scale_w64(int lane, V3 p, V3 v, double zv, V3 goal, V3 g, double dg,
-                                                   const PopConst &C, double k_circ, const ObsTab &T,
+                                                   const PopConst &C, double k_circ,
                                                    int n_obs, double *rot_g, unsigned &known_bits,
                                                    LaneObstacles<TILES> &O, double *clist, double &lane_min,
                                                    V3 &F, double &scale, const int ablate = 0) {
@@ -189,8 +234,10 @@ __device__ __forceinline__ void circ_and_scale_w64(int lane, V3 p, V3 v, double 
     // first contact: latch the rotation vector (rare)
     const bool need_latch = in_t[t] && !((known_bits >> t) & 1u);
     if (__any(need_latch)) {
+      V3 cpos = O.p[t];
+      if (TYPE == T_OBST || TYPE == T_GOALOBST) cpos = closest_other_w64<TILES, MATH>(need_latch, t, lane, M, O);
       if (need_latch) {
-        V3 rot = calc_rot_vec(TYPE, p, goal, T, n_obs, i, O.p[t], mk(O.qx[t], O.qy[t], O.qz[t]));
+        V3 rot = calc_rot_vec_c(TYPE, p, goal, n_obs, O.p[t], cpos, mk(O.qx[t], O.qy[t], O.qz[t]));
         rot_g[i] = rot.x; rot_g[n_obs + i] = rot.y; rot_g[2 * n_obs + i] = rot.z;
         O.rx[t] = rot.x; O.ry[t] = rot.y; O.rz[t] = rot.z;
         known_bits |= (1u << t);

@@ -175,6 +175,9 @@ template <> struct Mth<MATH_FAST> {
 // table-free fdlibm e_exp.c algorithm (< 1 ulp) in plain IEEE + - * /, the
 // same function as oracle/pmaf_oracle.c:pmaf_portable_exp, so it produces
 // identical bits on the host and on gfx950.
+// Written without branches (selects only): the rollout kernels place it in one
+// straight-line region together with independent vector work so that a lone
+// wave's in-order issue can fill the latency of this dependent chain.
 template <int MATH = MATH_IEEE>
 __device__ __forceinline__ double portable_exp(double x) {
   const double ln2HI = 6.93147180369123816490e-01, ln2LO = 1.90821492927058770002e-10,
@@ -183,20 +186,24 @@ __device__ __forceinline__ double portable_exp(double x) {
                P3 = 6.61375632143793436117e-05, P4 = -1.65339022054652515390e-06,
                P5 = 4.13813679705723846039e-08;
   const double ax = fabs(x);
-  if (ax > 708.0) return (x > 0) ? __builtin_huge_val() : 0.0;  // outside the path's range
-  if (ax < 3.725290298461914e-09) return 1.0 + x;                // |x| < 2^-28
+  const bool big = ax > 708.0;                    // outside the path's range: +inf / 0
+  const bool tiny = ax < 3.725290298461914e-09;   // |x| < 2^-28: 1 + x
+  const double xs = big ? 0.0 : x;                // keeps k in range; the result is replaced below
   // k = 0 for |x| <= 0.5 ln2, else round(x / ln2); one formula for all k
   // (for k = 0: hi = x, lo = 0, and 1 - ((0 - q) - x) == 1 - (-q - x), the
   // k == 0 branch of the classic formulation, bit for bit)
-  const int k = (ax > 0.34657359027997264) ? (int)(invln2 * x + ((x < 0) ? -0.5 : 0.5)) : 0;
+  const int kr = (int)(invln2 * xs + ((xs < 0) ? -0.5 : 0.5));
+  const int k = (ax > 0.34657359027997264) ? kr : 0;
   const double t = (double)k;
-  const double hi = x - t * ln2HI;
+  const double hi = xs - t * ln2HI;
   const double lo = t * ln2LO;
   const double r = hi - lo;
   const double r2 = r * r;
   const double c = r - r2 * (P1 + r2 * (P2 + r2 * (P3 + r2 * (P4 + r2 * P5))));
   const double y = 1.0 - ((lo - Mth<MATH>::div(r * c, 2.0 - c)) - hi);
-  return y * __longlong_as_double((long long)(1023 + k) << 52);
+  const double res = y * __longlong_as_double((long long)(1023 + k) << 52);
+  const double special = big ? ((x > 0) ? __builtin_huge_val() : 0.0) : (1.0 + x);
+  return (big || tiny) ? special : res;
 }
 
 enum : int { T_REAL = 0, T_GOAL = 1, T_OBST = 2, T_GOALOBST = 3, T_VEL = 4, T_RANDOM = 5, T_HAD = 6 };
@@ -305,29 +312,41 @@ template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ int dpp_i(int v) {
   return __builtin_amdgcn_update_dpp(v, v, CTRL, ROW_MASK, 0xf, false);
 }
-// inputs are never NaN here (distances >= 1e-5), so v_min_f64 == select-min
-__device__ __forceinline__ double sel_min(double a, double b) { return __builtin_fmin(a, b); }
+// Reductions run on 32-bit unsigned keys with the DPP operand fused into the
+// min (v_min_u32_dpp: ONE VALU instruction per stage; an FP64 min needs two
+// v_mov_dpp, two canonicalising v_max and the v_min per stage, measured 49
+// cycles per stage on a lone wave). Non-negative, non-NaN doubles order like
+// their bit patterns, so min(double) = min over the high words, then min over
+// the low words of the lanes that hold the minimal high word.
+// s_nop 1: a DPP operand read needs 2 wait states after the VALU write of the
+// same VGPR (inline asm is opaque to the compiler's hazard recogniser).
+#define PMAF_DPP_MIN_U32(ctrl) "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 " ctrl "\n\t"
+#define PMAF_DPP_MIN_U32_R(ctrl) "s_nop 1\n\tv_min_u32_dpp %1, %1, %1 " ctrl "\n\t"
 
-// minimum over the 64 lanes, returned wave-uniform. Inputs must not be NaN.
+// minimum over the 64 lanes, returned wave-uniform
+__device__ __forceinline__ unsigned wave_min64_u32(unsigned v) {
+  unsigned r;
+  // volatile: a cross-lane operation must stay where the program put it (never
+  // sunk into or duplicated under control flow the compiler believes divergent)
+  asm volatile(PMAF_DPP_MIN_U32_R("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")   // lane ^ 1
+      PMAF_DPP_MIN_U32_R("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")   // lane ^ 2
+      PMAF_DPP_MIN_U32_R("row_half_mirror row_mask:0xf bank_mask:0xf")       // other quad of the 8-lane half
+      PMAF_DPP_MIN_U32_R("row_mirror row_mask:0xf bank_mask:0xf")            // other half of the 16-lane row
+      PMAF_DPP_MIN_U32_R("row_bcast:15 row_mask:0xa bank_mask:0xf")          // -> rows 1,3
+      PMAF_DPP_MIN_U32_R("row_bcast:31 row_mask:0xc bank_mask:0xf")          // -> rows 2,3; lane 63 holds the total
+      "s_nop 1\n\tv_readlane_b32 %0, %1, 63"
+      : "=s"(r), "+v"(v));
+  return r;
+}
+// v >= +0.0 and not NaN in every lane
 __device__ __forceinline__ double wave_min64(double v) {
-  v = sel_min(v, dpp_d<0xB1, 0xf>(v));   // lane ^ 1 within quads
-  v = sel_min(v, dpp_d<0x4E, 0xf>(v));   // lane ^ 2 within quads
-  v = sel_min(v, dpp_d<0x141, 0xf>(v));  // row_half_mirror: other quad of the 8-lane half
-  v = sel_min(v, dpp_d<0x140, 0xf>(v));  // row_mirror: other half of the 16-lane row
-  v = sel_min(v, dpp_d<0x142, 0xa>(v));  // row_bcast15 -> rows 1,3
-  v = sel_min(v, dpp_d<0x143, 0xc>(v));  // row_bcast31 -> rows 2,3; lane 63 holds the total
-  return readlane_d(v, 63);
+  const unsigned hi = (unsigned)__double2hiint(v), lo = (unsigned)__double2loint(v);
+  const unsigned H = wave_min64_u32(hi);
+  const unsigned L = wave_min64_u32((hi == H) ? lo : 0xffffffffu);
+  return __hiloint2double((int)H, (int)L);
 }
-__device__ __forceinline__ int wave_min64_i(int v) {
-  int o;
-  o = dpp_i<0xB1, 0xf>(v); v = o < v ? o : v;
-  o = dpp_i<0x4E, 0xf>(v); v = o < v ? o : v;
-  o = dpp_i<0x141, 0xf>(v); v = o < v ? o : v;
-  o = dpp_i<0x140, 0xf>(v); v = o < v ? o : v;
-  o = dpp_i<0x142, 0xa>(v); v = o < v ? o : v;
-  o = dpp_i<0x143, 0xc>(v); v = o < v ? o : v;
-  return __builtin_amdgcn_readlane(v, 63);
-}
+// v >= 0 in every lane
+__device__ __forceinline__ int wave_min64_i(int v) { return (int)wave_min64_u32((unsigned)v); }
 
 // ---- heuristics ----------------------------------------------------------
 // currentVector, B/src/cf_agent.cpp:389-406 (Goal), 414-426 (Obstacle),

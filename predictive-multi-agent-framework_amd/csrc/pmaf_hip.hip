@@ -251,35 +251,63 @@ __device__ __forceinline__ void rollout_w64_body(const DevView &D, const CostPar
   ws_cost_add(cost_ws, p, CP.ws, CP.k_workspace);
   if (lane == 0) { path[0] = p.x; path[1] = p.y; path[2] = p.z; }
 
-  // norms of the loop guard / gate are carried from the end of the previous
-  // step, where they share a basic block (and the FP64 pipeline) with the
-  // path-length norm
+  // Everything the next step needs from the new state -- goal distance (loop
+  // guard / gate), goal direction, squared speed, squared start distance and
+  // attractorForce's velocity error (B/src/cf_agent.cpp:188-192) -- is computed
+  // at the END of the step in one basic block with the velocity clamp and the
+  // path-length norm: five independent sqrt / divide chains that the in-order
+  // issue of a lone wave can only overlap inside one block.
+  typedef Mth<MATH> MT;
   V3 g = goal - p;
-  double dg = Mth<MATH>::norm(g);
+  double dg = MT::norm(g);
   double zv = sqn(v);
   double z_init = sqn(p - init_pos);
+  V3 gn = (dg > 0.0) ? MT::div3(g, dg) : g;  // goal_vec.normalized()
+  V3 verr = attractor_velocity_error<MATH>(v, g, C, k_attr, k_damp);
   const double zsent_lt = D.zsent_lt[pop];
+  SecTimers ST;
+#ifdef PMAF_SECTION_TIMERS
+  ST.start();
+#endif
   while ((dg > 0.1) && (n < D.cap)) {  // wave-uniform guard, B/src/cf_agent.cpp:310-311
     // gate, :315-317
     // |v| < 0.5 vmax and |p - init| < 0.2 on exact squared thresholds
     const bool gate = !(dg < C.approach || (zv < C.zvhalf_lt && z_init < C.zinit_lt));
-    const V3 verr = attractor_velocity_error<MATH>(v, g, C, k_attr, k_damp);
+    // repelForce (:159-181) depends on the step's start position only
+    const V3 repel = sentinel_repel(p, C, k_repel, sent_p, sent_r, zsent_lt);
     V3 F = mk(0.0, 0.0, 0.0);
     double scale = 1.0;
+    PMAF_SEC(ST, 0);
     if (gate && !(D.ablate & 8))
-      circ_and_scale_w64<TILES, TYPE, MATH>(lane, p, v, zv, goal, g, dg, C, k_circ, n_obs, rot_g, known_bits, O,
-                                      clist, lane_min, F, scale, D.ablate);
-    V3 new_pos;
-    finish_step_w64<MATH>(p, v, verr, F, scale, C, k_attr, k_repel, k_damp, sent_p, sent_r, zsent_lt, new_pos);
+      circ_and_scale_w64<TILES, TYPE, MATH>(lane, p, v, zv, goal, g, dg, gn, C, k_circ, n_obs, rot_g, known_bits, O,
+                                            clist, lane_min, F, scale, ST, D.ablate);
+    PMAF_SEC(ST, 5);
+    // attractorForce (:183-193), updatePositionAndVelocity (:253-268)
+    F = F + (mk(0.0, 0.0, 0.0) + repel);
+    if (k_attr != 0.0) F = F + (scale * k_damp) * verr;
+    V3 acc = F;
+    if (C.mass != 1.0) acc = F / C.mass;
+    const double az = sqn(acc);
+    if (az >= C.zacc_gt) acc = acc * (13.0 / __builtin_sqrt(az));  // norm(acc) > 13.0 (rare)
+    PMAF_SEC(ST, 6);
+    // ---- one block: integrate, clamp the speed, the next step's norms ----
+    const V3 half = ((0.5 * acc) * C.dt) * C.dt;
+    const V3 new_pos = (p + half) + (v * C.dt);
+    const V3 nv = v + acc * C.dt;
+    const double vn = MT::norm(nv);
+    const V3 cl = nv * MT::div(C.vel_max, vn);
+    v = (vn > C.vel_max) ? cl : nv;
     const V3 dp = new_pos - p;
     p = new_pos;
     g = goal - p;
-    const double seg = Mth<MATH>::norm(dp);
-    dg = Mth<MATH>::norm(g);
+    const double seg = MT::norm(dp);
+    dg = MT::norm(g);
     zv = sqn(v);
     z_init = sqn(p - init_pos);
+    const V3 gq = MT::div3(g, dg);
+    gn = (dg > 0.0) ? gq : g;
+    verr = attractor_velocity_error<MATH>(v, g, C, k_attr, k_damp);
     path_len += seg;
-    ws_cost_add(cost_ws, p, CP.ws, CP.k_workspace);
     if (lane == 0) { path[n * 3] = p.x; path[n * 3 + 1] = p.y; path[n * 3 + 2] = p.z; }
     n++;
     ran = true;
@@ -287,7 +315,15 @@ __device__ __forceinline__ void rollout_w64_body(const DevView &D, const CostPar
 #pragma unroll
     for (int t = 0; t < TILES; t++) O.p[t] = O.p[t] + O.v[t] * C.dt;
     sent_p = sent_p + sent_v * C.dt;
+    ws_cost_add(cost_ws, p, CP.ws, CP.k_workspace);
+    PMAF_SEC(ST, 7);
   }
+#ifdef PMAF_SECTION_TIMERS
+  if (lane == 0 && pop == 0 && (a == 1 || a == 5))
+    printf("agent %d type %d steps %d | verr+gate %llu sweep %llu scale %llu circ %llu sum %llu (skip) %llu finish %llu tail %llu | "
+           "in-shell steps %llu terms %llu\n", a, TYPE, n - 1, ST.acc[0], ST.acc[1], ST.acc[2], ST.acc[3], ST.acc[4],
+           ST.acc[5], ST.acc[6], ST.acc[7], ST.cnt[0], ST.cnt[1]);
+#endif
 
   const double min_obs = wave_min64(lane_min);
   int32_t *ko = D.known_out + pa * n_obs;
@@ -1078,7 +1114,8 @@ int pmaf_create(const pmaf_params *prm, pmaf_planner **out) {
       // circular-field terms: 64 * TILES entries of 4 doubles
       size_t off = 7 * (size_t)n_obs + ((size_t)n_obs + 1) / 2;
       off += off & 1;
-      h->lds_rollout = sizeof(double) * (off + 64 * 4 * 4 + 8 * 4);  // + one zero entry per group (<= 8 groups)
+      // w64: (64 * TILES + 8 padding + 64 scratch) entries; groups: 64 * TILES + one zero entry per group (<= 8)
+      h->lds_rollout = sizeof(double) * (off + (64 * 4 + 8 + 64) * 4 + 8 * 4);
     }
     h->lds_manager = sizeof(double) * 7 * n_obs;
     REQUIRE(h->lds_rollout <= 160 * 1024, "pmaf_create: obstacle table does not fit in LDS");

@@ -19,33 +19,32 @@
 
 namespace pmaf {
 
-__device__ __forceinline__ double swz16_d(double v) {  // lane ^ 16
-  int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = __builtin_amdgcn_ds_swizzle(lo, 0x401F);
-  hi = __builtin_amdgcn_ds_swizzle(hi, 0x401F);
-  return __hiloint2double(hi, lo);
-}
-
 // minimum over the LPA lanes of each group, result in every lane of the group
+// (fused-DPP u32 stages, see wave_min64_u32; lane ^ 16 by ds_swizzle)
+template <int LPA>
+__device__ __forceinline__ unsigned group_min_dpp_u32(unsigned v) {
+  asm volatile(PMAF_DPP_MIN_U32("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
+      PMAF_DPP_MIN_U32("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
+      PMAF_DPP_MIN_U32("row_half_mirror row_mask:0xf bank_mask:0xf")
+      : "+v"(v));
+  if (LPA >= 16) asm volatile(PMAF_DPP_MIN_U32("row_mirror row_mask:0xf bank_mask:0xf") : "+v"(v));
+  if (LPA >= 32) {
+    const unsigned o = (unsigned)__builtin_amdgcn_ds_swizzle((int)v, 0x401F);
+    v = o < v ? o : v;
+  }
+  return v;
+}
+// v >= +0.0 and not NaN in every lane
 template <int LPA>
 __device__ __forceinline__ double group_min_dpp(double v) {
-  v = sel_min(v, dpp_d<0xB1, 0xf>(v));
-  v = sel_min(v, dpp_d<0x4E, 0xf>(v));
-  v = sel_min(v, dpp_d<0x141, 0xf>(v));
-  if (LPA >= 16) v = sel_min(v, dpp_d<0x140, 0xf>(v));
-  if (LPA >= 32) v = sel_min(v, swz16_d(v));
-  return v;
+  const unsigned hi = (unsigned)__double2hiint(v), lo = (unsigned)__double2loint(v);
+  const unsigned H = group_min_dpp_u32<LPA>(hi);
+  const unsigned L = group_min_dpp_u32<LPA>((hi == H) ? lo : 0xffffffffu);
+  return __hiloint2double((int)H, (int)L);
 }
+// v >= 0 in every lane
 template <int LPA>
-__device__ __forceinline__ int group_min_dpp_i(int v) {
-  int o;
-  o = dpp_i<0xB1, 0xf>(v); v = o < v ? o : v;
-  o = dpp_i<0x4E, 0xf>(v); v = o < v ? o : v;
-  o = dpp_i<0x141, 0xf>(v); v = o < v ? o : v;
-  if (LPA >= 16) { o = dpp_i<0x140, 0xf>(v); v = o < v ? o : v; }
-  if (LPA >= 32) { o = __builtin_amdgcn_ds_swizzle(v, 0x401F); v = o < v ? o : v; }
-  return v;
-}
+__device__ __forceinline__ int group_min_dpp_i(int v) { return (int)group_min_dpp_u32<LPA>((unsigned)v); }
 
 __device__ __forceinline__ V3 shfl_v3(V3 a, int src) {
   return mk(__shfl(a.x, src), __shfl(a.y, src), __shfl(a.z, src));

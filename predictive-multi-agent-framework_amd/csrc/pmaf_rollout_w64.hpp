@@ -86,6 +86,26 @@ __device__ __forceinline__ void finish_step_w64(V3 p, V3 &v, V3 verr, V3 F, doub
   v = (vn > C.vel_max) ? cl : nv;
 }
 
+// repelForce (B/src/cf_agent.cpp:159-181): only the trailing obstacle repels;
+// in range iff |dist_vec|^2 < zsent_lt (host-computed exact boundary of
+// max(|dist_vec| - (rad + r), 1e-5) < shell). Rare: strict arithmetic in all
+// policies.
+__device__ __forceinline__ V3 sentinel_repel(V3 p, const PopConst &C, double k_repel, V3 sent_pos, double sent_rad,
+                                             double zsent_lt) {
+  const V3 ro = sent_pos - p;
+  const V3 dist_vec = -ro;
+  V3 repel = mk(0.0, 0.0, 0.0);
+  if (sqn(dist_vec) < zsent_lt) {
+    double d = norm(dist_vec) - (C.rad + sent_rad);
+    d = smax(d, 1e-5);
+    const V3 otr = normalized(p - sent_pos);
+    const double t = 1.0 / d - 1.0 / C.shell;
+    const double dd = d * d;
+    repel = ((k_repel * otr) * t) / dd;
+  }
+  return repel;
+}
+
 // wave-level ordering of LDS accesses: DS instructions of one wave execute in
 // order, so only the compiler has to be kept from reordering them.
 __device__ __forceinline__ void wave_lds_fence() {
@@ -93,6 +113,23 @@ __device__ __forceinline__ void wave_lds_fence() {
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
+
+// Section timers of the w64 step (debug builds with -DPMAF_SECTION_TIMERS only:
+// s_memtime deltas per section, printed by agents 1 and 5 of population 0 at
+// the end of their rollout; compiled out otherwise).
+#ifdef PMAF_SECTION_TIMERS
+struct SecTimers {
+  unsigned long long last, acc[8], cnt[4];
+  __device__ __forceinline__ void start() { for (int k = 0; k < 8; k++) acc[k] = 0; for (int k = 0; k < 4; k++) cnt[k] = 0; last = __builtin_amdgcn_s_memtime(); }
+  __device__ __forceinline__ void mark(int k) { unsigned long long now = __builtin_amdgcn_s_memtime(); acc[k] += now - last; last = now; }
+};
+#define PMAF_SEC(ST, k) (ST).mark(k)
+#define PMAF_CNT(ST, k, v) (ST).cnt[k] += (v)
+#else
+struct SecTimers {};
+#define PMAF_SEC(ST, k)
+#define PMAF_CNT(ST, k, v)
+#endif
 
 template <int TILES>
 struct LaneObstacles {
@@ -153,18 +190,29 @@ __device__ __forceinline__ V3 closest_other_w64(bool need_latch, int t, int lane
 }
 
 // circForce (B/src/cf_agent.cpp:72-108) + attractorForceScaling (:195-227)
-// for one agent per wave. clist: LDS, 64*TILES entries of 4 doubles.
-// zv = squaredNorm(v), dg = norm(g) (already computed by the caller).
+// for one agent per wave. clist: LDS, (64*TILES + 8 + 64) entries of 4 doubles
+// (the list, 8 entries of zero padding, one scratch entry per lane).
+// zv = squaredNorm(v), dg = norm(g), gn = g.normalized() (computed by the caller).
+//
+// A lone wave issues in order, so a dependent chain costs its full latency
+// unless independent instructions stand between its links IN THE SAME BASIC
+// BLOCK. After the sweep and the (rare) latches everything is therefore ONE
+// straight-line region without branches: the per-lane circular terms (two
+// sqrt + divide chains), the closest-obstacle reduction and the wave-uniform
+// attractor-scaling chain (sqrt, divide, exp, divide: evaluated speculatively,
+// applied iff |F| > 1e-5, :319), the compaction stores (every lane stores: its
+// term at its rank, or to its scratch entry) and the first batch of the
+// ordered force sum (the list is zero-padded, adding +0.0 is exact).
 template <int TILES, int TYPE, int MATH>
-__device__ __forceinline__ void circ_and_scale_w64(int lane, V3 p, V3 v, double zv, V3 goal, V3 g, double dg,
+__device__ __forceinline__ void circ_and_scale_w64(int lane, V3 p, V3 v, double zv, V3 goal, V3 g, double dg, V3 gn,
                                                    const PopConst &C, double k_circ,
                                                    int n_obs, double *rot_g, unsigned &known_bits,
                                                    LaneObstacles<TILES> &O, double *clist, double &lane_min,
-                                                   V3 &F, double &scale, const int ablate = 0) {
+                                                   V3 &F, double &scale, SecTimers &ST, const int ablate = 0) {
   typedef Mth<MATH> MT;
+  constexpr int BATCH = 8;                 // list entries summed per LDS round trip
+  constexpr int SCRATCH = 64 * TILES + BATCH;
   const int M = n_obs - 1;
-  // goal_vec.normalized(): dg == sqrt(squaredNorm(g)), the value normalized() divides by
-  const V3 gn = (dg > 0.0) ? MT::div3(g, dg) : g;
   double best_d = C.shell;
   double best_s = 0.0, best_gr = 0.0;  // |ro| and g.ro of the lane's closest obstacle
   int best_i = 0x7fffffff;
@@ -191,47 +239,14 @@ __device__ __forceinline__ void circ_and_scale_w64(int lane, V3 p, V3 v, double 
     in_t[t] = live && (d < C.shell);
     any_in = any_in || in_t[t];
   }
+  PMAF_SEC(ST, 1);
   if (!__any(any_in) || (ablate & 4)) return;  // nothing inside the shell: F stays 0, scale stays 1
+  PMAF_CNT(ST, 0, 1);
 
-  // ---- attractorForceScaling value (:212-226), evaluated SPECULATIVELY: it
-  // depends only on the sweep geometry, so its reduction / sqrt / exp chain is
-  // placed before the circular-field terms and overlaps their normalisations
-  // and the LDS round trip of the force sum instead of following them; it is
-  // applied below iff |F| > 1e-5 (:319)
-  double sc = 1.0;
-  {
-    const double m = wave_min64(best_d);
-    const bool cand = (best_i != 0x7fffffff) && (best_d == m);
-    int bi;
-    if (TILES == 1) {  // obstacle index == lane: lowest candidate lane wins
-      const unsigned long long bm = __ballot(cand);
-      bi = bm ? (__ffsll((long long)bm) - 1) : 0x7fffffff;
-    } else {
-      bi = wave_min64_i(cand ? best_i : 0x7fffffff);
-    }
-    if (bi != 0x7fffffff) {
-      if (dot(g, v) <= 0.0 && zv < C.zv09_lt && dg > 0.15) {  // norm(v) < vmax - 0.1 vmax
-        sc = 0.0;
-      } else {
-        const double w1 = 1 - portable_exp<MATH>(-MT::div(MT::sqrt(m), C.shell));
-        // |ro| and g.ro of the closest obstacle were computed by the lane that
-        // owns it (same operands, same bits as recomputing them here)
-        const int bl = bi & 63;
-        const double sb = readlane_d(best_s, bl), gr = readlane_d(best_gr, bl);
-        double w2 = 1 - MT::div(gr, dg * sb);
-        w2 = w2 * w2;
-        sc = w1 * w2;
-      }
-    }
-  }
-
-  // ---- circular-field terms (:89-106) ----
-  int count = 0;
+  // ---- first contact: latch the rotation vector (:92-96, rare) ----
 #pragma unroll
   for (int t = 0; t < TILES; t++) {
-    if (!__any(in_t[t])) continue;
     const int i = t * 64 + lane;
-    // first contact: latch the rotation vector (rare)
     const bool need_latch = in_t[t] && !((known_bits >> t) & 1u);
     if (__any(need_latch)) {
       V3 cpos = O.p[t];
@@ -243,8 +258,16 @@ __device__ __forceinline__ void circ_and_scale_w64(int lane, V3 p, V3 v, double 
         known_bits |= (1u << t);
       }
     }
-    // evaluated by every lane (lanes outside the shell compute values that are
-    // discarded by has_c)
+  }
+  PMAF_SEC(ST, 2);
+
+  // ======== straight-line region ========
+  // ---- circular-field terms (:97-106), evaluated by every lane (lanes outside
+  // the shell compute values that go to their scratch entry)
+  int count = 0;
+#pragma unroll
+  for (int t = 0; t < TILES; t++) {
+    if (TILES > 1 && !__any(in_t[t])) continue;  // no term from this slot (wave-uniform)
     const V3 rot = mk(O.rx[t], O.ry[t], O.rz[t]);
     const V3 rv = rv_t[t];
     double vn;
@@ -254,31 +277,68 @@ __device__ __forceinline__ void circ_and_scale_w64(int lane, V3 p, V3 v, double 
     const V3 cur = current_vector<MATH>(TYPE, rv, g, ron_t[t], rot);
     const V3 c = MT::div(k_circ, d_t[t] * d_t[t]) * cross(nv, cross(cur, nv));
     const bool has_c = in_t[t] && (vn != 0);
-    // compact the contributing terms, ascending obstacle index, into LDS
+    // compact the contributing terms, ascending obstacle index
     const unsigned long long m = __ballot(has_c);
-    if (has_c) {
-      double *e = clist + (size_t)(count + lane_rank(m)) * 4;
-      e[0] = c.x; e[1] = c.y; e[2] = c.z;
-    }
+    const int slot = has_c ? (count + lane_rank(m)) : (SCRATCH + lane);
+    double *e = clist + (size_t)slot * 4;
+    e[0] = c.x; e[1] = c.y; e[2] = c.z;
     count += __popcll(m);
   }
-  if (count > 0 && !(ablate & 2)) {
-    wave_lds_fence();
-    // F = ((0 + c_0) + c_1) + ... front to back; every lane reads the same
-    // address (LDS broadcast), so every lane ends with the same F
-    int k = 0;
-    for (; k + 4 <= count; k += 4) {
-      const double *e = clist + (size_t)k * 4;
-      V3 c0 = mk(e[0], e[1], e[2]), c1 = mk(e[4], e[5], e[6]), c2 = mk(e[8], e[9], e[10]), c3 = mk(e[12], e[13], e[14]);
-      F = F + c0; F = F + c1; F = F + c2; F = F + c3;
-    }
-    for (; k < count; k++) {
-      const double *e = clist + (size_t)k * 4;
-      F = F + mk(e[0], e[1], e[2]);
-    }
-    wave_lds_fence();
+  {  // zero padding behind the list (8 distinct entries, written by all lanes)
+    double *e = clist + (size_t)(count + (lane & (BATCH - 1))) * 4;
+    e[0] = 0.0; e[1] = 0.0; e[2] = 0.0;
   }
-  if (sqn(F) >= C.zf_gt && !(ablate & 1)) scale = sc;  // norm(F) > 1e-5
+  PMAF_CNT(ST, 1, count);
+
+  // ---- attractorForceScaling value (:212-226), branchless ----
+  double sc;
+  {
+    const double m = wave_min64(best_d);
+    const bool cand = (best_i != 0x7fffffff) && (best_d == m);
+    int bi;
+    if (TILES == 1) {  // obstacle index == lane: lowest candidate lane wins
+      const unsigned long long bm = __ballot(cand);
+      bi = bm ? (__ffsll((long long)bm) - 1) : 0x7fffffff;
+    } else {
+      bi = wave_min64_i(cand ? best_i : 0x7fffffff);
+    }
+    const bool stall = (dot(g, v) <= 0.0) && (zv < C.zv09_lt) && (dg > 0.15);  // norm(v) < vmax - 0.1 vmax
+    const double w1 = 1 - portable_exp<MATH>(-MT::div(MT::sqrt(m), C.shell));
+    // |ro| and g.ro of the closest obstacle were computed by the lane that
+    // owns it (same operands, same bits as recomputing them here)
+    const int bl = bi & 63;
+    const double sb = readlane_d(best_s, bl), gr = readlane_d(best_gr, bl);
+    double w2 = 1 - MT::div(gr, dg * sb);
+    w2 = w2 * w2;
+    const double w = w1 * w2;
+    sc = (bi == 0x7fffffff) ? 1.0 : (stall ? 0.0 : w);
+  }
+
+  // ---- F = ((0 + c_0) + c_1) + ... front to back; every lane reads the same
+  // address (LDS broadcast), so every lane ends with the same F. The list is
+  // read in batches of BATCH entries (one LDS round trip each).
+  // The list is cross-lane communication through LDS: the fences order this
+  // lane's reads after (and the next step's writes behind) the other lanes'
+  // accesses for the COMPILER -- without them it may reorder or forward its own
+  // LDS accesses (observed: wrong sums); the hardware executes a wave's DS
+  // instructions in order, so no instruction is emitted for them.
+  wave_lds_fence();
+  for (int k = 0;;) {
+    double ex[BATCH], ey[BATCH], ez[BATCH];
+#pragma unroll
+    for (int j = 0; j < BATCH; j++) {
+      const double *e = clist + (size_t)(k + j) * 4;
+      ex[j] = e[0]; ey[j] = e[1]; ez[j] = e[2];
+    }
+#pragma unroll
+    for (int j = 0; j < BATCH; j++) { F.x = F.x + ex[j]; F.y = F.y + ey[j]; F.z = F.z + ez[j]; }
+    k += BATCH;
+    if (k >= count) break;
+  }
+  wave_lds_fence();
+  PMAF_SEC(ST, 3);
+  scale = (sqn(F) >= C.zf_gt) ? sc : scale;  // norm(F) > 1e-5
+  PMAF_SEC(ST, 4);
 }
 
 }  // namespace pmaf

@@ -12,7 +12,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libpmaf_hip.so")
+# PMAF_LIB_PATH: load an alternative build of the same library (debug / timer builds)
+LIB_PATH = os.environ.get("PMAF_LIB_PATH") or os.path.join(_HERE, "lib", "libpmaf_hip.so")
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int32)

@@ -356,15 +356,21 @@ __device__ __forceinline__ int wave_min64_i(int v) { return (int)wave_min64_u32(
 template <int MATH = MATH_IEEE>
 __device__ __forceinline__ V3 current_vector(int type, V3 agent_vel, V3 goal_vec, V3 to_obs, V3 rot) {
   typedef Mth<MATH> M;
-  if (type == T_GOAL) {
-    V3 cur = goal_vec - to_obs * dot(to_obs, goal_vec);
-    if (M::norm(cur) < 1e-10) cur = mk(0.0, 0.0, 1.0);
-    return M::normalized(cur);
-  } else if (type == T_VEL) {
-    V3 nvel = M::normalized(agent_vel);
-    V3 cur = nvel - to_obs * dot(nvel, to_obs);
-    if (M::norm(cur) < 1e-10) cur = mk(0.0, 0.0, 1.0);
-    return M::normalized(cur);
+  if (type == T_GOAL || type == T_VEL) {
+    V3 cur;
+    if (type == T_GOAL) {
+      cur = goal_vec - to_obs * dot(to_obs, goal_vec);
+    } else {
+      V3 nvel = M::normalized(agent_vel);
+      cur = nvel - to_obs * dot(nvel, to_obs);
+    }
+    // `if (cur.norm() < 1e-10) cur = (0,0,1); return cur.normalized()` with ONE
+    // square root: (0,0,1).normalized() is (0,0,1) exactly, and otherwise
+    // normalized() divides by the same sqrt(squaredNorm(cur)) the test compared
+    double s;
+    V3 u;
+    M::norm_unit(cur, s, u);
+    return (s < 1e-10) ? mk(0.0, 0.0, 1.0) : u;
   } else if (type == T_OBST || type == T_GOALOBST || type == T_RANDOM || type == T_HAD) {
     return M::normalized(cross(to_obs, rot));
   }

@@ -521,18 +521,49 @@ struct ManagerArgs {
   double dt_real;
   const int32_t *agent_id; // [P] gains index for the real step; NULL = best_idx of this launch
   const double *reset_in;  // [P][6] pos, vel
-  double *out;             // [P][12] host-visible: best_idx, next_pos[3], next_vel[3], dist_from_goal, force[3]
+  double *out;             // [P][12] host-visible: best_idx, next_pos[3], next_vel[3], dist_from_goal, force[3], seq
+  double seq;              // written to out[11] after the other entries are visible to the host (0: not written)
 };
 
+// Latency matters here (the set-point reaches the host when this kernel is
+// done): everything that does not depend on the selection is loaded up front
+// (per-agent results, the real agent's state, the live obstacles), the values
+// that lanes exchange (costs, known flags, the obstacle table) go through LDS,
+// not global memory, and the host-visible outputs are written before the
+// agents' reset stores. The dependent global round trips on the critical path
+// are: results -> (selected agent's type and gains) -> rotation vectors of the
+// obstacles inside the real agent's shell.
 __global__ __launch_bounds__(64) void k_manager(DevView D, CostParams CP, ManagerArgs A) {
   extern __shared__ double smem[];
   const int lane = threadIdx.x;
   const int pop = blockIdx.x;
   const int n_obs = D.n_obs;
   const int N = D.N;
+  const int M = n_obs - 1;
   const PopConst C = D.C;
+  // LDS: live obstacle table [7][n_obs] | known flags [n_obs] i32 | costs [N]
+  ObsTab T = carve_obstab(smem, n_obs);
+  int32_t *s_known = reinterpret_cast<int32_t *>(smem + 7 * n_obs);
+  double *s_cost = smem + 7 * n_obs + (n_obs + 1) / 2;
+
+  // ---- loads that depend on nothing ----
   const V3 goal = mk(D.goal[pop * 3], D.goal[pop * 3 + 1], D.goal[pop * 3 + 2]);
   int best = D.best_idx[pop];
+  const int had_best = D.has_best[pop];
+  const int old_best_id = D.best_id[pop];
+  int htype = D.best_type[pop];
+  V3 rp = mk(D.real_pos[pop * 3], D.real_pos[pop * 3 + 1], D.real_pos[pop * 3 + 2]);
+  V3 rv = mk(D.real_vel[pop * 3], D.real_vel[pop * 3 + 1], D.real_vel[pop * 3 + 2]);
+  V3 rf = mk(D.real_force[pop * 3], D.real_force[pop * 3 + 1], D.real_force[pop * 3 + 2]);
+  const V3 init_pos = mk(D.real_init_pos[pop * 3], D.real_init_pos[pop * 3 + 1], D.real_init_pos[pop * 3 + 2]);
+  int32_t *rk = D.real_known + (size_t)pop * n_obs;
+  const double *live = D.obs_live + (size_t)pop * 7 * n_obs;
+  if (A.do_move || A.do_reset) {
+    for (int i = lane; i < 7 * n_obs; i += 64) smem[i] = live[i];
+    for (int i = lane; i < n_obs; i += 64) s_known[i] = rk[i];
+  }
+  // random vectors the real agent's heuristic uses (best_agent_'s copy)
+  const double *rand_g = D.best_rnd + (size_t)pop * 3 * n_obs;
 
   if (A.do_select) {
     // cost assembly + argmin, B/src/cf_manager.cpp:325-343
@@ -548,60 +579,50 @@ __global__ __launch_bounds__(64) void k_manager(DevView D, CostParams CP, Manage
       cost += CP.k_safe_dist / mo;
       if (mo < 2e-5) cost += 10000.0;
       D.costs[pa] = cost;
+      s_cost[a] = cost;
       if (cost < lmin) { lmin = cost; lidx = a; }
     }
     group_argmin<64>(lmin, lidx);
     int min_idx = (lidx == 0x7fffffff) ? 0 : lidx;
-    __syncthreads();  // costs visible to the whole wave
+    wave_lds_fence();  // costs visible to the whole wave
     // hysteresis, :344-353
     bool take;
-    if (D.has_best[pop]) {
-      int bi = D.best_id[pop] - 1;
-      double cb = D.costs[(size_t)pop * N + bi];
-      double cm = D.costs[(size_t)pop * N + min_idx];
+    if (had_best) {
+      int bi = old_best_id - 1;
+      double cb = s_cost[bi];
+      double cm = s_cost[min_idx];
       if (cm < 0.9 * cb) take = true;
       else { take = false; min_idx = bi; }
     } else {
       take = true;
     }
-    __syncthreads();
     if (take) {  // best_agent_ = makeCopy()
       const double *src = D.rnd + ((size_t)pop * N + min_idx) * 3 * n_obs;
       double *dst = D.best_rnd + (size_t)pop * 3 * n_obs;
       for (int i = lane; i < 3 * n_obs; i += 64) dst[i] = src[i];
+      rand_g = src;  // same values; the copy need not have landed
+      htype = D.types[min_idx];
       if (lane == 0) {
         D.has_best[pop] = 1;
         D.best_id[pop] = min_idx + 1;
-        D.best_type[pop] = D.types[min_idx];
+        D.best_type[pop] = htype;
       }
     }
     best = min_idx;
     if (lane == 0) D.best_idx[pop] = best;
-    __syncthreads();
   }
-
-  V3 rp = mk(D.real_pos[pop * 3], D.real_pos[pop * 3 + 1], D.real_pos[pop * 3 + 2]);
-  V3 rv = mk(D.real_vel[pop * 3], D.real_vel[pop * 3 + 1], D.real_vel[pop * 3 + 2]);
-  V3 rf = mk(D.real_force[pop * 3], D.real_force[pop * 3 + 1], D.real_force[pop * 3 + 2]);
 
   if (A.do_move) {
     // RealCfAgent::cfPlanner one step, B/src/cf_agent.cpp:343-366
-    ObsTab T = carve_obstab(smem, n_obs);
-    const double *src = D.obs_live + (size_t)pop * 7 * n_obs;
-    for (int i = lane; i < 7 * n_obs; i += 64) smem[i] = src[i];
-    __syncthreads();
     int gid = A.agent_id ? A.agent_id[pop] : best;
     size_t pg = (size_t)pop * N + gid;
     double k_attr = D.k_attr[pg], k_circ = D.k_circ[pg], k_repel = D.k_repel[pg], k_damp = D.k_damp[pg];
-    int htype = D.best_type[pop];
-    V3 init_pos = mk(D.real_init_pos[pop * 3], D.real_init_pos[pop * 3 + 1], D.real_init_pos[pop * 3 + 2]);
-    int32_t *rk = D.real_known + (size_t)pop * n_obs;
-    const int M = n_obs - 1;
+    wave_lds_fence();  // obstacle table + known flags in LDS
     const int ntiles = (M + 63) / 64;
     unsigned long long kb = 0ull;
     for (int t = 0; t < ntiles; t++) {
       int i = t * 64 + lane;
-      if (i < M && rk[i]) kb |= (1ull << t);
+      if (i < M && s_known[i]) kb |= (1ull << t);
     }
     V3 g = goal - rp;
     double dg = norm(g);
@@ -609,22 +630,38 @@ __global__ __launch_bounds__(64) void k_manager(DevView D, CostParams CP, Manage
     V3 F = mk(0.0, 0.0, 0.0);
     double scale = 1.0, dummy_min = C.shell;
     circ_and_scale<64, true>(gate, lane, 0, htype, rp, rv, goal, g, C, k_circ, T, n_obs,
-                             D.real_rot + (size_t)pop * 3 * n_obs, D.best_rnd + (size_t)pop * 3 * n_obs, kb,
-                             dummy_min, F, scale);
+                             D.real_rot + (size_t)pop * 3 * n_obs, rand_g, kb, dummy_min, F, scale);
     V3 new_pos;
     finish_step(rp, rv, g, F, scale, C, k_attr, k_repel, k_damp, A.dt_real, T.pos(n_obs - 1), T.r[n_obs - 1], new_pos);
     rp = new_pos;
     rf = F;
     for (int t = 0; t < ntiles; t++) {
       int i = t * 64 + lane;
-      if (i < M) rk[i] = (int32_t)((kb >> t) & 1ull);
+      if (i < M) {
+        const int32_t f = (int32_t)((kb >> t) & 1ull);
+        rk[i] = f;
+        s_known[i] = f;
+      }
     }
     if (lane == 0) {
       D.real_pos[pop * 3] = rp.x; D.real_pos[pop * 3 + 1] = rp.y; D.real_pos[pop * 3 + 2] = rp.z;
       D.real_vel[pop * 3] = rv.x; D.real_vel[pop * 3 + 1] = rv.y; D.real_vel[pop * 3 + 2] = rv.z;
       D.real_force[pop * 3] = F.x; D.real_force[pop * 3 + 1] = F.y; D.real_force[pop * 3 + 2] = F.z;
     }
-    __syncthreads();
+  }
+
+  // host-visible outputs first: the caller waits for these only
+  if (lane == 0 && A.out) {
+    double *o = A.out + pop * 12;
+    o[0] = (double)best;
+    o[1] = rp.x; o[2] = rp.y; o[3] = rp.z;
+    o[4] = rv.x; o[5] = rv.y; o[6] = rv.z;
+    o[7] = norm(goal - rp);
+    o[8] = rf.x; o[9] = rf.y; o[10] = rf.z;
+    if (A.seq != 0.0) {
+      __threadfence_system();  // entries 0..10 visible to the host before the sequence number
+      *reinterpret_cast<volatile double *>(o + 11) = A.seq;
+    }
   }
 
   if (A.do_reset) {
@@ -639,14 +676,13 @@ __global__ __launch_bounds__(64) void k_manager(DevView D, CostParams CP, Manage
     // setVelocity clamp, B/src/cf_agent.cpp:54-61
     double vn = norm(sv);
     if (vn > C.vel_max) sv = (C.vel_max / vn) * sv;
+    wave_lds_fence();  // table / known flags (written above by other lanes)
     // setObstacles, :63-70: position and velocity from the live obstacles,
     // radius keeps its init value; known flags from the real agent
-    const double *live = D.obs_live + (size_t)pop * 7 * n_obs;
     double *st = D.obs_start + (size_t)pop * 7 * n_obs;
-    for (int i = lane; i < 6 * n_obs; i += 64) st[i] = live[i];
-    const int32_t *rk = D.real_known + (size_t)pop * n_obs;
+    for (int i = lane; i < 6 * n_obs; i += 64) st[i] = smem[i];
     int32_t *ks = D.known_start + (size_t)pop * n_obs;
-    for (int i = lane; i < n_obs; i += 64) ks[i] = rk[i];
+    for (int i = lane; i < n_obs; i += 64) ks[i] = s_known[i];
     for (int a = lane; a < N; a += 64) {
       size_t pa = (size_t)pop * N + a;
       double *path = D.paths + pa * (size_t)D.cap * 3;
@@ -659,21 +695,12 @@ __global__ __launch_bounds__(64) void k_manager(DevView D, CostParams CP, Manage
     // one coalesced sweep over [N][n_obs] instead of a per-agent loop
     {
       int32_t *ko = D.known_out + (size_t)pop * N * n_obs;
-      for (int k = lane; k < N * n_obs; k += 64) ko[k] = rk[k % n_obs];
+      for (int k = lane; k < N * n_obs; k += 64) ko[k] = s_known[k % n_obs];
     }
     if (lane == 0) {
       D.start_pos[pop * 3] = sp.x; D.start_pos[pop * 3 + 1] = sp.y; D.start_pos[pop * 3 + 2] = sp.z;
       D.start_vel[pop * 3] = sv.x; D.start_vel[pop * 3 + 1] = sv.y; D.start_vel[pop * 3 + 2] = sv.z;
     }
-  }
-
-  if (lane == 0 && A.out) {
-    double *o = A.out + pop * 12;
-    o[0] = (double)best;
-    o[1] = rp.x; o[2] = rp.y; o[3] = rp.z;
-    o[4] = rv.x; o[5] = rv.y; o[6] = rv.z;
-    o[7] = norm(goal - rp);
-    o[8] = rf.x; o[9] = rf.y; o[10] = rf.z;
   }
 }
 
@@ -794,6 +821,7 @@ struct pmaf_planner {
   size_t lds_rollout = 0, lds_manager = 0;
   hipStream_t stream = nullptr;
   hipEvent_t ev_mgr = nullptr;
+  uint64_t mailbox_seq = 0;     // sequence number of the last pmaf_tick (mailbox entry 11)
   std::vector<void *> allocs;
   std::vector<size_t> alloc_bytes;  // size of every device buffer (state save / load)
   double *h_out = nullptr;      // pinned [P][12] mailbox written by k_manager
@@ -1025,6 +1053,26 @@ static void refresh_real_cache(pmaf_planner *h) {
   }
 }
 
+// Spin until k_manager has published sequence number `seq` for every
+// population. The stream is queried now and then so that a failed or finished
+// launch cannot leave the host spinning.
+static void wait_mailbox(pmaf_planner *h, double seq) {
+  for (int p = 0; p < h->D.P; p++) {
+    const volatile double *s = h->h_out + p * 12 + 11;
+    unsigned spins = 0;
+    while (*s != seq) {
+      __builtin_ia32_pause();
+      if ((++spins & 0x3fffu) == 0) {
+        hipError_t e = hipStreamQuery(h->stream);
+        if (e == hipErrorNotReady) continue;
+        if (e != hipSuccess) throw HipError{e, "hipStreamQuery (mailbox wait)", __LINE__};
+        if (*s != seq) fail(PMAF_ERR_DEVICE, "pmaf_tick: manager kernel finished without publishing its result");
+      }
+    }
+  }
+  __atomic_thread_fence(__ATOMIC_ACQUIRE);
+}
+
 static void append_real_path(pmaf_planner *h) {
   for (int p = 0; p < h->D.P; p++) {
     const double *o = h->h_out + p * 12;
@@ -1117,7 +1165,7 @@ int pmaf_create(const pmaf_params *prm, pmaf_planner **out) {
       // w64: (64 * TILES + 8 padding + 64 scratch) entries; groups: 64 * TILES + one zero entry per group (<= 8)
       h->lds_rollout = sizeof(double) * (off + (64 * 4 + 8 + 64) * 4 + 8 * 4);
     }
-    h->lds_manager = sizeof(double) * 7 * n_obs;
+    h->lds_manager = sizeof(double) * (7 * (size_t)n_obs + ((size_t)n_obs + 1) / 2 + (size_t)N);
     REQUIRE(h->lds_rollout <= 160 * 1024, "pmaf_create: obstacle table does not fit in LDS");
 
     size_t PN = (size_t)P * N;
@@ -1411,12 +1459,13 @@ int pmaf_tick(pmaf_planner *h, const double *obstacles, double dt, const double 
     A.do_select = 1; A.do_move = 1; A.do_reset = 1; A.reset_from_real = 1;
     A.dt_real = dt;
     A.out = h->d_out;
+    A.seq = (double)(++h->mailbox_seq);
     launch_manager(h, A);
-    HIP_CHECK(hipEventRecord(h->ev_mgr, h->stream));
     h->rollout_pending = true;
     launch_rollout(h);
-    // outputs of k_manager land in mapped pinned memory; wait for it only
-    HIP_CHECK(hipEventSynchronize(h->ev_mgr));
+    // outputs of k_manager land in mapped pinned memory; wait for them only
+    // (no event between the two launches: the host polls the sequence number)
+    wait_mailbox(h, A.seq);
     refresh_real_cache(h);
     append_real_path(h);
     for (int p = 0; p < h->D.P; p++) {

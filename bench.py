@@ -117,7 +117,15 @@ def main():
     if os.environ.get("PMAF_BENCH_SINGLE_DEVICE") == "1":
         local_rank = 0
     red_dev = "cuda" if backend == "nccl" else "cpu"
-    if world > 1:
+    # PMAF_BENCH_FORCE_DIST=1: initialise torch.distributed (RCCL) even for one rank
+    # -- exercises RCCL and this library's HIP runtime in one process on a 1-GPU box
+    force_dist = os.environ.get("PMAF_BENCH_FORCE_DIST") == "1"
+    if force_dist and world == 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+    if world > 1 or force_dist:
         import torch
         import torch.distributed as dist
         if backend == "nccl":
@@ -184,6 +192,16 @@ def main():
         elapsed = float(t.item())
     kernel_ms, launches, agent_steps = planner.kernel_stats()
     cfg = planner.launch_config()
+    # set-point latency of a tick issued on an idle stream (the previous rollout
+    # has finished, as in a 100 Hz control loop): host call -> best index and
+    # next set-point on the host. Outside the timed region.
+    idle = np.zeros(100)
+    for k in range(idle.size):
+        planner.stop()
+        ta = time.perf_counter()
+        one_tick(obs)
+        idle[k] = time.perf_counter() - ta
+    planner.stop()
     planner.close()
 
     if rank == 0:
@@ -228,7 +246,11 @@ def main():
                                      "the CPU oracle)"},
             "agent_steps_per_s": agent_steps / max(launches, 1) * world * args.steps / elapsed,
             "h_eff": steps_per_launch / (N * P),
-            "tick_latency_us": {"median": float(np.median(lat) * 1e6), "p99": float(np.percentile(lat, 99) * 1e6)},
+            "tick_latency_us": {"median": float(np.median(lat) * 1e6), "p99": float(np.percentile(lat, 99) * 1e6),
+                                "note": "back-to-back ticks: each call waits for the previous rollout"},
+            "setpoint_latency_us": {"median": float(np.median(idle) * 1e6), "p99": float(np.percentile(idle, 99) * 1e6),
+                                    "note": "tick issued on an idle stream: host call -> best index + next set-point "
+                                            "on the host (the new rollout then runs asynchronously)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": kernel_name,
@@ -244,10 +266,19 @@ def main():
             out["cpu_baseline"] = cpu_baseline(pkg, sc, args.cpu_seconds, max(1, min(N, os.cpu_count() or 1)))
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out))
+        line = json.dumps(out)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # the JSON line is the last thing written (RCCL may print a banner at its first collective)
+        sys.stdout.flush()
+        try:  # ... including what C libraries still hold in their stdio buffers
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
+        print(line, flush=True)
 
 
 if __name__ == "__main__":

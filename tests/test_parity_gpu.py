@@ -705,3 +705,66 @@ def test_agent_range_sharding_equals_single_population(pmaf, oracle, scenes, cut
         np.testing.assert_array_equal(nh, no[s.a0:s.a1])
         np.testing.assert_array_equal(ph, po[s.a0:s.a1])
         s.planner.close()
+
+
+@pytest.mark.parametrize("lpa,force_generic", [(0, False), (16, False), (8, False), (0, True)])
+def test_closest_other_ties_and_far_obstacles(pmaf, oracle, scenes, monkeypatch, lpa, force_generic):
+    """the Obstacle / GoalObstacle heuristics latch against the nearest OTHER
+    obstacle (cf_agent.cpp:434-446, :480-492: ascending scan, strict `>`, 100 m
+    initial minimum). The tuned kernels do that scan cooperatively over the
+    lanes, so pin its corner cases against the oracle's sequential scan:
+    exact distance ties (lowest index wins, across lanes and across slots of one
+    lane), a neighbour exactly 100 m away (not accepted) and obstacles with no
+    neighbour inside 100 m (index 0, which may be the obstacle itself)."""
+    if force_generic:
+        monkeypatch.setenv("PMAF_FORCE_GENERIC", "1")
+    types = np.array([2, 3, 2, 3, 5, 6, 1, 4], dtype=np.int32)
+    # field obstacles on the agents' way, symmetric about the centre one: |o1-o0| == |o1-o2| etc.
+    near = [[0.00, 0.02, 0.70], [0.10, 0.02, 0.70], [-0.10, 0.02, 0.70], [0.00, 0.12, 0.70], [0.00, -0.08, 0.70],
+            [0.00, 0.02, 0.80], [0.00, 0.02, 0.60]]
+    m = 70  # two slots per lane in the w64 mapping, five in the 16-lane one
+    sc = scenes.synthetic_scene(8, 150, m, 9, 5, agent_types=types)
+    obs = sc["obstacles"]
+    for k in range(m):
+        obs[k, :3] = near[k] if k < len(near) else [150.0 + 7.0 * k, 40.0, 0.7]  # off the path
+        obs[k, 3:6] = 0.0
+        obs[k, 6] = 0.03
+    # a pair exactly 100 m apart and one obstacle alone in its neighbourhood (> 100 m from everything)
+    obs[m - 3, :3] = [0.3, 0.0, 0.7]
+    obs[m - 2, :3] = [0.3, 100.0, 0.7]
+    obs[m - 1, :3] = [-0.3, -0.05, 0.72]
+    hip, _ = run_both(pmaf, oracle, scenes, sc, 4, lanes_per_agent=lpa)
+    assert hip.known().any()  # latches happened
+    hip.close()
+    # a sparse scene: every field obstacle is > 100 m from every other one except those on the path
+    sc = scenes.synthetic_scene(4, 150, 3, 9, 6, agent_types=types[:4])
+    sc["obstacles"][0] = [0.0, 250.0, 0.7, 0, 0, 0, 0.03]
+    sc["obstacles"][1] = [0.05, 0.03125, 0.7, 0, 0, 0, 0.03]
+    sc["obstacles"][2] = [0.05, -99.96875, 0.7, 0, 0, 0, 0.03]   # exactly 100 m from obstacle 1: `100 > d` is false
+    hip, _ = run_both(pmaf, oracle, scenes, sc, 3, lanes_per_agent=lpa)
+    hip.close()
+
+
+def test_prediction_times_are_per_agent(pmaf, scenes):
+    """getPredictionTimes (cf_manager.cpp:200-206): one duration per agent from
+    the device clock; agents that stop at the goal after a few steps report
+    shorter rollouts than agents that run the whole horizon"""
+    sc = scenes.config_scene("C2")
+    hip = pmaf.PmafPlanner(sc, device=0, mgr_init_pos=sc["start"])
+    hip.set_initial_position(sc["start"])
+    hip.tick(None, sc["dt"], sc["cost_gains"], sc["ws_limits"])
+    hip.stop()
+    t = np.asarray(hip.prediction_times_ns()).reshape(-1)
+    assert t.shape == (sc["n_agents"],)
+    assert (t > 2e4).all() and (t < 2e7).all()       # 200 steps: tens of us .. well under 20 ms
+    assert np.unique(t).size > 8                      # per agent, not one launch time
+    hip.close()
+    near = dict(sc)
+    near["start"] = sc["goal"] + np.array([-0.12, 0.0, 0.0])   # guard ends after a few steps
+    hip = pmaf.PmafPlanner(near, device=0, mgr_init_pos=near["start"])
+    hip.set_initial_position(near["start"])
+    hip.tick(None, sc["dt"], sc["cost_gains"], sc["ws_limits"])
+    hip.stop()
+    assert (np.asarray(hip.n_points()) < 60).all()
+    assert np.asarray(hip.prediction_times_ns()).max() < 0.5 * t.min()
+    hip.close()

@@ -1,0 +1,28 @@
+"""C5: distribution of the per-agent (= per group of lanes) rollout durations and of
+the per-WAVE duration (max over the wave's agents) in the group kernel."""
+import os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import __graft_entry__ as g
+pm = g.load_package()
+P = 8
+lpa = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+scs = [pm.scenes.config_scene("C5", scene_id=i) for i in range(P)]
+starts = np.stack([s["start"] for s in scs]); sc = scs[0]
+h = pm.PmafPlanner(scs, device=0, mgr_init_pos=starts, lanes_per_agent=lpa); h.set_initial_position(starts)
+cfg = h.launch_config()
+acc = []
+for k in range(12):
+    h.tick(None, sc["dt"], sc["cost_gains"], sc["ws_limits"]); h.stop()
+    if k >= 4: acc.append(np.asarray(h.prediction_times_ns()).reshape(P, -1))
+t = np.mean(acc, axis=0) / 1e3
+apw = 64 // cfg["lanes_per_agent"]
+w = t.reshape(P, -1, apw).max(axis=2)
+print("cfg", cfg)
+print("agent us: min %.0f p50 %.0f p90 %.0f p99 %.0f max %.0f" % (t.min(), np.median(t), np.percentile(t, 90), np.percentile(t, 99), t.max()))
+print("wave  us: min %.0f p50 %.0f p90 %.0f p99 %.0f max %.0f  mean %.0f" % (w.min(), np.median(w), np.percentile(w, 90), np.percentile(w, 99), w.max(), w.mean()))
+types = pm.scenes.default_agent_types(sc["n_agents"])
+for ty in sorted(set(types.tolist())):
+    sel = t[:, types == ty]
+    print("  type %d n=%d mean %.0f max %.0f" % (ty, sel.size, sel.mean(), sel.max()))
+h.close()

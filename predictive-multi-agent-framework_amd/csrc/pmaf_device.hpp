@@ -318,25 +318,27 @@ __device__ __forceinline__ int dpp_i(int v) {
 // cycles per stage on a lone wave). Non-negative, non-NaN doubles order like
 // their bit patterns, so min(double) = min over the high words, then min over
 // the low words of the lanes that hold the minimal high word.
-// s_nop 1: a DPP operand read needs 2 wait states after the VALU write of the
-// same VGPR (inline asm is opaque to the compiler's hazard recogniser).
-#define PMAF_DPP_MIN_U32(ctrl) "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 " ctrl "\n\t"
-#define PMAF_DPP_MIN_U32_R(ctrl) "s_nop 1\n\tv_min_u32_dpp %1, %1, %1 " ctrl "\n\t"
+// `old` = UINT_MAX (the identity of umin) lets the compiler's DPP combiner fold
+// the v_mov_dpp into the v_min_u32 -- and, unlike inline asm, keeps the
+// instructions visible to its hazard recogniser (DPP after a VALU write needs
+// 2 wait states; a lane select read from an SGPR that a v_readlane just wrote
+// needs 4: an inline-asm version of this reduction produced wrong lanes under
+// some schedules).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned dpp_min_u32(unsigned v) {
+  const unsigned o = (unsigned)__builtin_amdgcn_update_dpp((int)0xffffffffu, (int)v, CTRL, ROW_MASK, 0xf, false);
+  return o < v ? o : v;
+}
 
 // minimum over the 64 lanes, returned wave-uniform
 __device__ __forceinline__ unsigned wave_min64_u32(unsigned v) {
-  unsigned r;
-  // volatile: a cross-lane operation must stay where the program put it (never
-  // sunk into or duplicated under control flow the compiler believes divergent)
-  asm volatile(PMAF_DPP_MIN_U32_R("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")   // lane ^ 1
-      PMAF_DPP_MIN_U32_R("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")   // lane ^ 2
-      PMAF_DPP_MIN_U32_R("row_half_mirror row_mask:0xf bank_mask:0xf")       // other quad of the 8-lane half
-      PMAF_DPP_MIN_U32_R("row_mirror row_mask:0xf bank_mask:0xf")            // other half of the 16-lane row
-      PMAF_DPP_MIN_U32_R("row_bcast:15 row_mask:0xa bank_mask:0xf")          // -> rows 1,3
-      PMAF_DPP_MIN_U32_R("row_bcast:31 row_mask:0xc bank_mask:0xf")          // -> rows 2,3; lane 63 holds the total
-      "s_nop 1\n\tv_readlane_b32 %0, %1, 63"
-      : "=s"(r), "+v"(v));
-  return r;
+  v = dpp_min_u32<0xB1, 0xf>(v);   // lane ^ 1 within quads
+  v = dpp_min_u32<0x4E, 0xf>(v);   // lane ^ 2 within quads
+  v = dpp_min_u32<0x141, 0xf>(v);  // row_half_mirror: other quad of the 8-lane half
+  v = dpp_min_u32<0x140, 0xf>(v);  // row_mirror: other half of the 16-lane row
+  v = dpp_min_u32<0x142, 0xa>(v);  // row_bcast15 -> rows 1,3
+  v = dpp_min_u32<0x143, 0xc>(v);  // row_bcast31 -> rows 2,3; lane 63 holds the total
+  return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
 // v >= +0.0 and not NaN in every lane
 __device__ __forceinline__ double wave_min64(double v) {

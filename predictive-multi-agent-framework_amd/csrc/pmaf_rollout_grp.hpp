@@ -20,14 +20,13 @@
 namespace pmaf {
 
 // minimum over the LPA lanes of each group, result in every lane of the group
-// (fused-DPP u32 stages, see wave_min64_u32; lane ^ 16 by ds_swizzle)
+// (fused-DPP u32 stages, see dpp_min_u32; lane ^ 16 by ds_swizzle)
 template <int LPA>
 __device__ __forceinline__ unsigned group_min_dpp_u32(unsigned v) {
-  asm volatile(PMAF_DPP_MIN_U32("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
-      PMAF_DPP_MIN_U32("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
-      PMAF_DPP_MIN_U32("row_half_mirror row_mask:0xf bank_mask:0xf")
-      : "+v"(v));
-  if (LPA >= 16) asm volatile(PMAF_DPP_MIN_U32("row_mirror row_mask:0xf bank_mask:0xf") : "+v"(v));
+  v = dpp_min_u32<0xB1, 0xf>(v);
+  v = dpp_min_u32<0x4E, 0xf>(v);
+  v = dpp_min_u32<0x141, 0xf>(v);
+  if (LPA >= 16) v = dpp_min_u32<0x140, 0xf>(v);
   if (LPA >= 32) {
     const unsigned o = (unsigned)__builtin_amdgcn_ds_swizzle((int)v, 0x401F);
     v = o < v ? o : v;

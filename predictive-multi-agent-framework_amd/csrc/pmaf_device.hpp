@@ -87,11 +87,13 @@ template <> struct Mth<MATH_IEEE> {
   static __device__ __forceinline__ V3 div3(V3 a, double s) { return a / s; }
   static __device__ __forceinline__ double norm(V3 a) { return __builtin_sqrt(sqn(a)); }
   // s = |a|, u = a.normalized()
+  template <bool TP = false>
   static __device__ __forceinline__ void norm_unit(V3 a, double &s, V3 &u) {
     double z = sqn(a);
     s = __builtin_sqrt(z);
     u = (z > 0.0) ? (a / s) : a;
   }
+  template <bool TP = false>
   static __device__ __forceinline__ V3 normalized(V3 a) { return pmaf::normalized(a); }
 };
 template <> struct Mth<MATH_XACT> {
@@ -129,13 +131,25 @@ template <> struct Mth<MATH_XACT> {
     return mk(div_r(a.x, s, r), div_r(a.y, s, r), div_r(a.z, s, r));
   }
   static __device__ __forceinline__ double norm(V3 a) { return sqrt(sqn(a)); }
+  // normalized() returns the vector itself unless squaredNorm > 0: dividing by
+  // 1.0 instead does that exactly (x / 1.0 == x for every x, zeros keep their
+  // sign, NaNs stay NaN) with one 64-bit select instead of three
+  // TP (throughput shape, the group kernel): the select sits on the divisor (2
+  // instructions instead of 6). The wave-per-agent kernel keeps it behind the
+  // division, off the sqrt -> reciprocal chain its latency depends on.
+  template <bool TP = false>
   static __device__ __forceinline__ void norm_unit(V3 a, double &s, V3 &u) {
     double z = sqn(a);
     s = sqrt(z);
-    V3 q = div3(a, s);
-    u = (z > 0.0) ? q : a;
+    if (TP) {
+      u = div3(a, (z > 0.0) ? s : 1.0);
+    } else {
+      V3 q = div3(a, s);
+      u = (z > 0.0) ? q : a;
+    }
   }
-  static __device__ __forceinline__ V3 normalized(V3 a) { double s; V3 u; norm_unit(a, s, u); return u; }
+  template <bool TP = false>
+  static __device__ __forceinline__ V3 normalized(V3 a) { double s; V3 u; norm_unit<TP>(a, s, u); return u; }
 };
 template <> struct Mth<MATH_FAST> {
   static __device__ __forceinline__ double rcp(double b) {
@@ -162,11 +176,13 @@ template <> struct Mth<MATH_FAST> {
   static __device__ __forceinline__ double div(double a, double b) { return a * rcp(b); }
   static __device__ __forceinline__ V3 div3(V3 a, double s) { double r = rcp(s); return a * r; }
   static __device__ __forceinline__ double norm(V3 a) { return sqrt(sqn(a)); }
+  template <bool TP = false>
   static __device__ __forceinline__ void norm_unit(V3 a, double &s, V3 &u) {
     double y;
     sqrt_rsqrt(sqn(a), s, y);
     u = a * y;
   }
+  template <bool TP = false>
   static __device__ __forceinline__ V3 normalized(V3 a) { double s; V3 u; norm_unit(a, s, u); return u; }
 };
 
@@ -355,7 +371,7 @@ __device__ __forceinline__ int wave_min64_i(int v) { return (int)wave_min64_u32(
 // 463-475 (GoalObstacle), 520-537 (Vel), 545-557 (Random), 585-597 (Had).
 // to_obs = normalized(obstacle - agent_pos), identical to the value the
 // reference recomputes inside each currentVector.
-template <int MATH = MATH_IEEE>
+template <int MATH = MATH_IEEE, bool TP = false>
 __device__ __forceinline__ V3 current_vector(int type, V3 agent_vel, V3 goal_vec, V3 to_obs, V3 rot) {
   typedef Mth<MATH> M;
   if (type == T_GOAL || type == T_VEL) {
@@ -363,7 +379,7 @@ __device__ __forceinline__ V3 current_vector(int type, V3 agent_vel, V3 goal_vec
     if (type == T_GOAL) {
       cur = goal_vec - to_obs * dot(to_obs, goal_vec);
     } else {
-      V3 nvel = M::normalized(agent_vel);
+      V3 nvel = M::template normalized<TP>(agent_vel);
       cur = nvel - to_obs * dot(nvel, to_obs);
     }
     // `if (cur.norm() < 1e-10) cur = (0,0,1); return cur.normalized()` with ONE
@@ -371,10 +387,10 @@ __device__ __forceinline__ V3 current_vector(int type, V3 agent_vel, V3 goal_vec
     // normalized() divides by the same sqrt(squaredNorm(cur)) the test compared
     double s;
     V3 u;
-    M::norm_unit(cur, s, u);
+    M::template norm_unit<TP>(cur, s, u);
     return (s < 1e-10) ? mk(0.0, 0.0, 1.0) : u;
   } else if (type == T_OBST || type == T_GOALOBST || type == T_RANDOM || type == T_HAD) {
-    return M::normalized(cross(to_obs, rot));
+    return M::template normalized<TP>(cross(to_obs, rot));
   }
   return mk(0.0, 0.0, 0.0);
 }

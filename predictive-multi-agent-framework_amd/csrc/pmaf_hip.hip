@@ -305,7 +305,7 @@ __device__ __forceinline__ void rollout_w64_body(const DevView &D, const CostPar
     zv = sqn(v);
     z_init = sqn(p - init_pos);
     const V3 gq = MT::div3(g, dg);
-    gn = (dg > 0.0) ? gq : g;
+    gn = (dg > 0.0) ? gq : g;  // goal_vec.normalized()
     verr = attractor_velocity_error<MATH>(v, g, C, k_attr, k_damp);
     path_len += seg;
     if (lane == 0) { path[n * 3] = p.x; path[n * 3 + 1] = p.y; path[n * 3 + 2] = p.z; }

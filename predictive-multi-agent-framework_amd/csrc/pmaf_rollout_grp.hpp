@@ -106,7 +106,7 @@ __device__ __forceinline__ void circ_and_scale_grp(bool act, int sub, int grp, i
                                                    double &scale) {
   typedef Mth<MATH> MT;
   const int M = n_obs - 1;
-  const V3 gn = (dg > 0.0) ? MT::div3(g, dg) : g;
+  const V3 gn = MT::div3(g, (dg > 0.0) ? dg : 1.0);  // goal_vec.normalized(): x / 1.0 == x
   double best_d = C.shell;
   double best_s = 0.0, best_gr = 0.0;
   int best_i = 0x7fffffff;
@@ -122,7 +122,7 @@ __device__ __forceinline__ void circ_and_scale_grp(bool act, int sub, int grp, i
     const V3 rv = v - O.v[t];
     double s;
     V3 ron;
-    MT::norm_unit(ro, s, ron);
+    MT::template norm_unit<true>(ro, s, ron);
     const bool skip = (dot(ron, gn) < -0.01) && (dot(ro, rv) < -0.01);
     double d = s - (C.rad + O.r[t]);
     d = smax(d, 1e-5);
@@ -146,7 +146,7 @@ __device__ __forceinline__ void circ_and_scale_grp(bool act, int sub, int grp, i
       const V3 rot = mk(O.rx[t], O.ry[t], O.rz[t]);
       const double vn = MT::norm(rv);
       const V3 nv = MT::div3(rv, vn);
-      const V3 cur = current_vector<MATH>(type, rv, g, ron, rot);
+      const V3 cur = current_vector<MATH, true>(type, rv, g, ron, rot);
       const V3 c = MT::div(k_circ, d * d) * cross(nv, cross(cur, nv));
       const bool has_c = in_shell && (vn != 0);
       const unsigned long long m = __ballot(has_c);

@@ -233,7 +233,12 @@ __device__ __forceinline__ void circ_and_scale_w64(int lane, V3 p, V3 v, double 
     double d = s - (C.rad + O.r[t]);
     d = smax(d, 1e-5);
     d_t[t] = d;
-    if (valid && d < best_d) { best_d = d; best_i = i; best_s = s; best_gr = dot(g, ro); }
+    if (TILES == 1) {  // one slot per lane: its |ro| and g.ro are only read from the winning lane
+      if (valid && d < best_d) { best_d = d; best_i = i; }
+      best_s = s; best_gr = dot(g, ro);
+    } else {
+      if (valid && d < best_d) { best_d = d; best_i = i; best_s = s; best_gr = dot(g, ro); }
+    }
     const bool live = valid && !skip;
     if (live && d < lane_min) lane_min = d;
     in_t[t] = live && (d < C.shell);

@@ -244,11 +244,8 @@ __device__ __forceinline__ void rollout_w64_body(const DevView &D, const CostPar
   double *clist = smem + clist_off;
 
   double lane_min = C.shell;  // per-lane running min_obs_dist_, reduced once after the loop
-  double cost_ws = 0.0;
-  double path_len = 0.0;
   int n = 1;
   bool ran = false;
-  ws_cost_add(cost_ws, p, CP.ws, CP.k_workspace);
   if (lane == 0) { path[0] = p.x; path[1] = p.y; path[2] = p.z; }
 
   // Everything the next step needs from the new state -- goal distance (loop
@@ -265,6 +262,7 @@ __device__ __forceinline__ void rollout_w64_body(const DevView &D, const CostPar
   V3 gn = (dg > 0.0) ? MT::div3(g, dg) : g;  // goal_vec.normalized()
   V3 verr = attractor_velocity_error<MATH>(v, g, C, k_attr, k_damp);
   const double zsent_lt = D.zsent_lt[pop];
+  const bool sent_reachable = sentinel_reachable(p, sent_p, sent_v, zsent_lt, C, D.cap);
   SecTimers ST;
 #ifdef PMAF_SECTION_TIMERS
   ST.start();
@@ -274,7 +272,8 @@ __device__ __forceinline__ void rollout_w64_body(const DevView &D, const CostPar
     // |v| < 0.5 vmax and |p - init| < 0.2 on exact squared thresholds
     const bool gate = !(dg < C.approach || (zv < C.zvhalf_lt && z_init < C.zinit_lt));
     // repelForce (:159-181) depends on the step's start position only
-    const V3 repel = sentinel_repel(p, C, k_repel, sent_p, sent_r, zsent_lt);
+    V3 repel = mk(0.0, 0.0, 0.0);
+    if (sent_reachable) repel = sentinel_repel(p, C, k_repel, sent_p, sent_r, zsent_lt);
     V3 F = mk(0.0, 0.0, 0.0);
     double scale = 1.0;
     PMAF_SEC(ST, 0);
@@ -283,7 +282,7 @@ __device__ __forceinline__ void rollout_w64_body(const DevView &D, const CostPar
                                             clist, lane_min, F, scale, ST, D.ablate);
     PMAF_SEC(ST, 5);
     // attractorForce (:183-193), updatePositionAndVelocity (:253-268)
-    F = F + (mk(0.0, 0.0, 0.0) + repel);
+    if (sent_reachable) F = F + (mk(0.0, 0.0, 0.0) + repel);  // else + 0.0: F is a sum that started from +0.0, never -0.0
     if (k_attr != 0.0) F = F + (scale * k_damp) * verr;
     V3 acc = F;
     if (C.mass != 1.0) acc = F / C.mass;
@@ -297,25 +296,21 @@ __device__ __forceinline__ void rollout_w64_body(const DevView &D, const CostPar
     const double vn = MT::norm(nv);
     const V3 cl = nv * MT::div(C.vel_max, vn);
     v = (vn > C.vel_max) ? cl : nv;
-    const V3 dp = new_pos - p;
     p = new_pos;
     g = goal - p;
-    const double seg = MT::norm(dp);
     dg = MT::norm(g);
     zv = sqn(v);
     z_init = sqn(p - init_pos);
     const V3 gq = MT::div3(g, dg);
     gn = (dg > 0.0) ? gq : g;  // goal_vec.normalized()
     verr = attractor_velocity_error<MATH>(v, g, C, k_attr, k_damp);
-    path_len += seg;
     if (lane == 0) { path[n * 3] = p.x; path[n * 3 + 1] = p.y; path[n * 3 + 2] = p.z; }
     n++;
     ran = true;
     // predictObstacles, B/src/cf_agent.cpp:270-276, in registers
 #pragma unroll
     for (int t = 0; t < TILES; t++) O.p[t] = O.p[t] + O.v[t] * C.dt;
-    sent_p = sent_p + sent_v * C.dt;
-    ws_cost_add(cost_ws, p, CP.ws, CP.k_workspace);
+    if (sent_reachable) sent_p = sent_p + sent_v * C.dt;
     PMAF_SEC(ST, 7);
   }
 #ifdef PMAF_SECTION_TIMERS
@@ -324,6 +319,9 @@ __device__ __forceinline__ void rollout_w64_body(const DevView &D, const CostPar
            "in-shell steps %llu terms %llu\n", a, TYPE, n - 1, ST.acc[0], ST.acc[1], ST.acc[2], ST.acc[3], ST.acc[4],
            ST.acc[5], ST.acc[6], ST.acc[7], ST.cnt[0], ST.cnt[1]);
 #endif
+
+  double cost_ws, path_len;
+  path_cost_terms_w64<MATH>(lane, path, n, CP.ws, CP.k_workspace, clist, cost_ws, path_len);
 
   const double min_obs = wave_min64(lane_min);
   int32_t *ko = D.known_out + pa * n_obs;
@@ -413,6 +411,7 @@ __global__ __launch_bounds__(64) void k_rollout_grp(DevView D, CostParams CP) {
   const double k_attr = D.k_attr[pa], k_circ = D.k_circ[pa], k_repel = D.k_repel[pa], k_damp = D.k_damp[pa];
   double *path = D.paths + pa * (size_t)D.cap * 3;
   const double zsent_lt = D.zsent_lt[pop];
+  const bool sent_reachable = __any(sentinel_reachable(p, sent_p, sent_v, zsent_lt, C, D.cap));  // wave-uniform
 
   int clist_off = 7 * n_obs + (n_obs + 1) / 2;
   clist_off += clist_off & 1;
@@ -444,7 +443,8 @@ __global__ __launch_bounds__(64) void k_rollout_grp(DevView D, CostParams CP) {
                                      known_bits, O, clist, lane_min, F, scale);
     V3 new_pos;
     V3 nv = v;
-    finish_step_w64<MATH>(p, nv, verr, F, scale, C, k_attr, k_repel, k_damp, sent_p, sent_r, zsent_lt, new_pos);
+    finish_step_w64<MATH>(p, nv, verr, F, scale, C, k_attr, k_repel, k_damp, sent_p, sent_r, zsent_lt, new_pos,
+                          sent_reachable);
     if (run) {
       const V3 dp = new_pos - p;
       p = new_pos;
@@ -462,7 +462,7 @@ __global__ __launch_bounds__(64) void k_rollout_grp(DevView D, CostParams CP) {
     // predictObstacles, B/src/cf_agent.cpp:270-276, in registers
 #pragma unroll
     for (int t = 0; t < TILES; t++) O.p[t] = O.p[t] + O.v[t] * C.dt;
-    sent_p = sent_p + sent_v * C.dt;
+    if (sent_reachable) sent_p = sent_p + sent_v * C.dt;
   }
 
   const double min_obs = group_min_dpp<LPA>(lane_min);

@@ -55,8 +55,9 @@ __device__ __forceinline__ V3 attractor_velocity_error(V3 v, V3 goal_vec, const 
 template <int MATH>
 __device__ __forceinline__ void finish_step_w64(V3 p, V3 &v, V3 verr, V3 F, double scale, const PopConst &C,
                                                 double k_attr, double k_repel, double k_damp, V3 sent_pos,
-                                                double sent_rad, double zsent_lt, V3 &new_pos) {
-  {
+                                                double sent_rad, double zsent_lt, V3 &new_pos,
+                                                const bool sent_reachable = true) {
+  if (sent_reachable) {
     V3 ro = sent_pos - p;
     V3 dist_vec = -ro;
     V3 repel = mk(0.0, 0.0, 0.0);
@@ -84,6 +85,23 @@ __device__ __forceinline__ void finish_step_w64(V3 p, V3 &v, V3 verr, V3 F, doub
   const double f = Mth<MATH>::div(C.vel_max, vn);
   const V3 cl = nv * f;
   v = (vn > C.vel_max) ? cl : nv;
+}
+
+// Can the repulsive obstacle come into range at all during this rollout? Per
+// step the agent moves at most |a| dt^2 / 2 + |v| dt with |a| <= 13 and
+// |v| <= vel_max (both clamped, updatePositionAndVelocity :253-268) and the
+// obstacle |v_s| dt, so with the distance at the rollout's start and `steps`
+// steps to go the range test of repelForce is decided for the whole rollout
+// (margins cover the rounding of the clamps and of this bound). In the shipped
+// scenes the obstacle sits 170 m away: the per-step test is skipped.
+__device__ __forceinline__ bool sentinel_reachable(V3 p, V3 sent_pos, V3 sent_vel, double zsent_lt, const PopConst &C,
+                                                   int steps) {
+  const double adt = fabs(C.dt);
+  const double per_step = (6.5 * adt * adt + C.vel_max * adt) + norm(sent_vel) * adt;
+  const double reach = (double)steps * per_step * 1.001 + 1e-9;
+  const double range = __builtin_sqrt(zsent_lt) * 1.001;
+  const double d0 = norm(p - sent_pos);
+  return !(d0 > range + reach);  // NaN anywhere: keep testing
 }
 
 // repelForce (B/src/cf_agent.cpp:159-181): only the trailing obstacle repels;
@@ -344,6 +362,51 @@ __device__ __forceinline__ void circ_and_scale_w64(int lane, V3 p, V3 v, double 
   PMAF_SEC(ST, 3);
   scale = (sqn(F) >= C.zf_gt) ? sc : scale;  // norm(F) > 1e-5
   PMAF_SEC(ST, 4);
+}
+
+// evaluateAgents' path terms (B/src/cf_manager.cpp:302-324 workspace-box
+// penalties, :329 / getPathLength cf_agent.cpp:26-32) from the path the rollout
+// has just stored. Inside the step loop they cost a dependent sqrt chain and a
+// dozen compares per step on a lone wave; here the whole wave works on 64 path
+// points at a time: segment norms in parallel, their sum in path order through
+// an LDS list (the reference adds them front to back; adding the +0.0 of the
+// lanes past the end is exact), the penalties of the (rare) points outside the
+// box in path order by lane. Same operands and operations as the in-loop
+// evaluation, so the bits are the same.
+// The points were written by lane 0: the agent-scope fence + agent-scope loads
+// make them visible to the other lanes (not served from a stale L1 line).
+__device__ __forceinline__ double ld_agent(const double *p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <int MATH>
+__device__ __forceinline__ void path_cost_terms_w64(int lane, const double *path, int n, const double *ws,
+                                                    double k_workspace, double *list, double &cost_ws,
+                                                    double &path_len) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  cost_ws = 0.0;
+  path_len = 0.0;
+  for (int base = 0; base < n; base += 64) {
+    const int k = base + lane;
+    const bool valid = k < n;
+    const bool has_seg = valid && (k > 0);
+    const int kk = valid ? k : 0, kp = has_seg ? (k - 1) : 0;
+    const V3 q = mk(ld_agent(path + kk * 3), ld_agent(path + kk * 3 + 1), ld_agent(path + kk * 3 + 2));
+    const V3 qp = mk(ld_agent(path + kp * 3), ld_agent(path + kp * 3 + 1), ld_agent(path + kp * 3 + 2));
+    const double seg = Mth<MATH>::norm(q - qp);
+    list[lane] = has_seg ? seg : 0.0;
+    wave_lds_fence();
+#pragma unroll 8
+    for (int j = 0; j < 64; j++) path_len += list[j];
+    wave_lds_fence();
+    const bool out = valid && ((q.x > ws[0]) | (q.x < ws[1]) | (q.y > ws[2]) | (q.y < ws[3]) | (q.z > ws[4]) | (q.z < ws[5]));
+    unsigned long long m = __ballot(out);
+    while (m) {  // rare
+      const int L = __ffsll((long long)m) - 1;
+      m &= m - 1;
+      ws_cost_add(cost_ws, readlane_v3(q, L), ws, k_workspace);
+    }
+  }
 }
 
 }  // namespace pmaf

@@ -420,11 +420,8 @@ __global__ __launch_bounds__(64) void k_rollout_grp(DevView D, CostParams CP) {
   wave_lds_fence();
 
   double lane_min = C.shell;
-  double cost_ws = 0.0;
-  double path_len = 0.0;
   int n = 1;
   bool ran = false;
-  ws_cost_add(cost_ws, p, CP.ws, CP.k_workspace);
   if (active && sub == 0) { path[0] = p.x; path[1] = p.y; path[2] = p.z; }
 
   V3 g = goal - p;
@@ -446,15 +443,12 @@ __global__ __launch_bounds__(64) void k_rollout_grp(DevView D, CostParams CP) {
     finish_step_w64<MATH>(p, nv, verr, F, scale, C, k_attr, k_repel, k_damp, sent_p, sent_r, zsent_lt, new_pos,
                           sent_reachable);
     if (run) {
-      const V3 dp = new_pos - p;
       p = new_pos;
       v = nv;
       g = goal - p;
-      path_len += Mth<MATH>::norm(dp);
       dg = Mth<MATH>::norm(g);
       zv = sqn(v);
       z_init = sqn(p - init_pos);
-      ws_cost_add(cost_ws, p, CP.ws, CP.k_workspace);
       if (sub == 0) { path[n * 3] = p.x; path[n * 3 + 1] = p.y; path[n * 3 + 2] = p.z; }
       n++;
       ran = true;
@@ -464,6 +458,9 @@ __global__ __launch_bounds__(64) void k_rollout_grp(DevView D, CostParams CP) {
     for (int t = 0; t < TILES; t++) O.p[t] = O.p[t] + O.v[t] * C.dt;
     if (sent_reachable) sent_p = sent_p + sent_v * C.dt;
   }
+
+  double cost_ws, path_len;
+  path_cost_terms_grp<LPA, MATH>(sub, grp, active, path, n, CP.ws, CP.k_workspace, clist, cost_ws, path_len);
 
   const double min_obs = group_min_dpp<LPA>(lane_min);
   if (active) {

@@ -198,4 +198,40 @@ __device__ __forceinline__ void circ_and_scale_grp(bool act, int sub, int grp, i
   }
 }
 
+// path_cost_terms_w64 (pmaf_rollout_w64.hpp) for groups of LPA lanes: every
+// group works on LPA points of ITS agent's path at a time; list = the group's
+// LDS list (at least LPA doubles).
+template <int LPA, int MATH>
+__device__ __forceinline__ void path_cost_terms_grp(int sub, int grp, bool active, const double *path, int n,
+                                                    const double *ws, double k_workspace, double *list,
+                                                    double &cost_ws, double &path_len) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  cost_ws = 0.0;
+  path_len = 0.0;
+  const unsigned long long gmask = ((1ull << LPA) - 1ull) << (grp * LPA);
+  for (int base = 0; __any(active && base < n); base += LPA) {
+    const int k = base + sub;
+    const bool valid = active && (k < n);
+    const bool has_seg = valid && (k > 0);
+    const int kk = valid ? k : 0, kp = has_seg ? (k - 1) : 0;
+    const V3 q = mk(ld_agent(path + kk * 3), ld_agent(path + kk * 3 + 1), ld_agent(path + kk * 3 + 2));
+    const V3 qp = mk(ld_agent(path + kp * 3), ld_agent(path + kp * 3 + 1), ld_agent(path + kp * 3 + 2));
+    const double seg = Mth<MATH>::norm(q - qp);
+    list[sub] = has_seg ? seg : 0.0;
+    wave_lds_fence();
+#pragma unroll
+    for (int j = 0; j < LPA; j++) path_len += list[j];
+    wave_lds_fence();
+    const bool out = valid && ((q.x > ws[0]) | (q.x < ws[1]) | (q.y > ws[2]) | (q.y < ws[3]) | (q.z > ws[4]) | (q.z < ws[5]));
+    unsigned long long gm = __ballot(out) & gmask;  // this group's points outside the box, in path order
+    while (__any(gm != 0ull)) {  // rare
+      const int L = gm ? (__ffsll((long long)gm) - 1) : (grp * LPA + sub);
+      const V3 ql = shfl_v3(q, L);
+      if (gm) ws_cost_add(cost_ws, ql, ws, k_workspace);
+      gm &= gm - 1ull;
+    }
+  }
+}
+
 }  // namespace pmaf

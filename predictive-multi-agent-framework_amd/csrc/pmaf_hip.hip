@@ -263,6 +263,11 @@ __device__ __forceinline__ void rollout_w64_body(const DevView &D, const CostPar
   V3 verr = attractor_velocity_error<MATH>(v, g, C, k_attr, k_damp);
   const double zsent_lt = D.zsent_lt[pop];
   const bool sent_reachable = sentinel_reachable(p, sent_p, sent_v, zsent_lt, C, D.cap);
+  bool moving = false;  // any field obstacle with a non-zero (or NaN) velocity component
+#pragma unroll
+  for (int t = 0; t < TILES; t++) moving = moving || !(O.v[t].x == 0.0 && O.v[t].y == 0.0 && O.v[t].z == 0.0);
+  moving = __any(moving);
+  bool advance = true;
   SecTimers ST;
 #ifdef PMAF_SECTION_TIMERS
   ST.start();
@@ -295,7 +300,7 @@ __device__ __forceinline__ void rollout_w64_body(const DevView &D, const CostPar
     const V3 nv = v + acc * C.dt;
     const double vn = MT::norm(nv);
     const V3 cl = nv * MT::div(C.vel_max, vn);
-    v = (vn > C.vel_max) ? cl : nv;
+    v = (vn > C.vel_max) ? cl : nv;  // a select, not a branch: the block is not split (a branch measured 5 % slower)
     p = new_pos;
     g = goal - p;
     dg = MT::norm(g);
@@ -307,9 +312,14 @@ __device__ __forceinline__ void rollout_w64_body(const DevView &D, const CostPar
     if (lane == 0) { path[n * 3] = p.x; path[n * 3 + 1] = p.y; path[n * 3 + 2] = p.z; }
     n++;
     ran = true;
-    // predictObstacles, B/src/cf_agent.cpp:270-276, in registers
+    // predictObstacles, B/src/cf_agent.cpp:270-276, in registers. Obstacles at
+    // rest: p + (+-0) dt is idempotent after its first application (which turns
+    // a -0.0 coordinate into +0.0), so later steps skip it.
+    if (advance) {
 #pragma unroll
-    for (int t = 0; t < TILES; t++) O.p[t] = O.p[t] + O.v[t] * C.dt;
+      for (int t = 0; t < TILES; t++) O.p[t] = O.p[t] + O.v[t] * C.dt;
+      advance = moving;
+    }
     if (sent_reachable) sent_p = sent_p + sent_v * C.dt;
     PMAF_SEC(ST, 7);
   }
@@ -412,6 +422,11 @@ __global__ __launch_bounds__(64) void k_rollout_grp(DevView D, CostParams CP) {
   double *path = D.paths + pa * (size_t)D.cap * 3;
   const double zsent_lt = D.zsent_lt[pop];
   const bool sent_reachable = __any(sentinel_reachable(p, sent_p, sent_v, zsent_lt, C, D.cap));  // wave-uniform
+  bool moving = false;
+#pragma unroll
+  for (int t = 0; t < TILES; t++) moving = moving || !(O.v[t].x == 0.0 && O.v[t].y == 0.0 && O.v[t].z == 0.0);
+  moving = __any(moving);
+  bool advance = true;
 
   int clist_off = 7 * n_obs + (n_obs + 1) / 2;
   clist_off += clist_off & 1;
@@ -453,9 +468,12 @@ __global__ __launch_bounds__(64) void k_rollout_grp(DevView D, CostParams CP) {
       n++;
       ran = true;
     }
-    // predictObstacles, B/src/cf_agent.cpp:270-276, in registers
+    // predictObstacles, B/src/cf_agent.cpp:270-276, in registers (obstacles at rest: once, see the w64 kernel)
+    if (advance) {
 #pragma unroll
-    for (int t = 0; t < TILES; t++) O.p[t] = O.p[t] + O.v[t] * C.dt;
+      for (int t = 0; t < TILES; t++) O.p[t] = O.p[t] + O.v[t] * C.dt;
+      advance = moving;
+    }
     if (sent_reachable) sent_p = sent_p + sent_v * C.dt;
   }
 

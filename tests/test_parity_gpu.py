@@ -768,3 +768,33 @@ def test_prediction_times_are_per_agent(pmaf, scenes):
     assert (np.asarray(hip.n_points()) < 60).all()
     assert np.asarray(hip.prediction_times_ns()).max() < 0.5 * t.min()
     hip.close()
+
+
+@pytest.mark.parametrize("lpa", [0, 16])
+def test_signed_zero_coordinates_of_obstacles_at_rest(pmaf, oracle, scenes, lpa):
+    """obstacles at rest are advanced once per rollout by the tuned kernels
+    (p + (+-0) dt is idempotent after the first application): -0.0 coordinates
+    and -0.0 velocity components must still behave like the reference's
+    `pos += vel * dt` in every step (a -0.0 coordinate turns into +0.0 after the
+    first step unless its velocity component is -0.0 too)"""
+    sc = scenes.synthetic_scene(12, 150, 6, 9, 7)
+    obs = sc["obstacles"]
+    obs[0, :3] = [0.0, -0.0, 0.7]      # on the start-goal line (y = z-offset 0): zeros everywhere
+    obs[1, :3] = [-0.0, 0.05, 0.7]
+    obs[1, 3:6] = [-0.0, 0.0, -0.0]
+    obs[2, :3] = [0.2, -0.0, 0.7]
+    obs[2, 3:6] = [0.0, -0.0, 0.0]
+    hip, _ = run_both(pmaf, oracle, scenes, sc, 4, lanes_per_agent=lpa)
+    hip.close()
+
+
+def test_repulsive_obstacle_moving_into_range(pmaf, oracle, scenes):
+    """the repulsive (last) obstacle starts out of range and flies towards the
+    agents: the once-per-rollout reachability bound must keep the per-step range
+    test alive (repelForce, cf_agent.cpp:159-181), on every kernel mapping"""
+    for lpa in (0, 16):
+        sc = scenes.synthetic_scene(8, 200, 5, 9, 8, dynamic=True)
+        # 2 m away, 1.2 m/s towards the path: its surface comes within 0.27 m of the predicted paths (shell 0.35 m)
+        sc["obstacles"][-1] = [0.0, 2.0, 0.7, 0.0, -1.2, 0.0, 0.1]
+        hip, ora = run_both(pmaf, oracle, scenes, sc, 3, dynamic=True, lanes_per_agent=lpa)
+        hip.close()

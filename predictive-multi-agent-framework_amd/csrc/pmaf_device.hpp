@@ -86,6 +86,10 @@ template <> struct Mth<MATH_IEEE> {
   static __device__ __forceinline__ double div(double a, double b) { return a / b; }
   static __device__ __forceinline__ V3 div3(V3 a, double s) { return a / s; }
   static __device__ __forceinline__ double norm(V3 a) { return __builtin_sqrt(sqn(a)); }
+  // s = |a| and the policy's helper value for dividing by s (unused here)
+  static __device__ __forceinline__ void norm_rcp(V3 a, double &s, double &rs) { s = __builtin_sqrt(sqn(a)); rs = 0.0; }
+  static __device__ __forceinline__ double div_n(double x, double s, double) { return x / s; }
+  static __device__ __forceinline__ V3 div3_n(V3 a, double s, double) { return a / s; }
   // s = |a|, u = a.normalized()
   template <bool TP = false>
   static __device__ __forceinline__ void norm_unit(V3 a, double &s, V3 &u) {
@@ -109,6 +113,26 @@ template <> struct Mth<MATH_XACT> {
     g = __builtin_fma(d, h, g);
     return (z == 0.0 || z == __builtin_huge_val()) ? z : g;  // sqrt(+-0) = +-0, sqrt(inf) = inf
   }
+  // s = sqrt(z) as above, and r = 1/s refined to division quality WITHOUT a
+  // v_rcp_f64 (a quarter-rate instruction): the Goldschmidt iteration already
+  // carries h ~ 1/(2 sqrt(z)) to ~2^-51, one Newton step against the rounded s
+  // brings 2h to the accuracy rcp_refined() reaches (checked bit for bit
+  // against IEEE a / sqrt(z): pmaf_debug_math op 9, test_xact_sequences_match_ieee).
+  static __device__ __forceinline__ void sqrt_rcp(double z, double &s, double &rs) {
+    double y = __builtin_amdgcn_rsq(z);
+    double g = z * y, h = 0.5 * y;
+    double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    h = __builtin_fma(h, r, h);
+    double d = __builtin_fma(-g, g, z);
+    g = __builtin_fma(d, h, g);
+    d = __builtin_fma(-g, g, z);
+    g = __builtin_fma(d, h, g);
+    s = (z == 0.0 || z == __builtin_huge_val()) ? z : g;
+    double r0 = h + h;
+    double e = __builtin_fma(-s, r0, 1.0);
+    rs = __builtin_fma(r0, e, r0);
+  }
   static __device__ __forceinline__ double rcp_refined(double b) {
     double r = __builtin_amdgcn_rcp(b);
     double e = __builtin_fma(-b, r, 1.0);
@@ -131,20 +155,27 @@ template <> struct Mth<MATH_XACT> {
     return mk(div_r(a.x, s, r), div_r(a.y, s, r), div_r(a.z, s, r));
   }
   static __device__ __forceinline__ double norm(V3 a) { return sqrt(sqn(a)); }
-  // normalized() returns the vector itself unless squaredNorm > 0: dividing by
-  // 1.0 instead does that exactly (x / 1.0 == x for every x, zeros keep their
-  // sign, NaNs stay NaN) with one 64-bit select instead of three
-  // TP (throughput shape, the group kernel): the select sits on the divisor (2
-  // instructions instead of 6). The wave-per-agent kernel keeps it behind the
-  // division, off the sqrt -> reciprocal chain its latency depends on.
+  // s = |a| and the refined reciprocal of s that falls out of the sqrt iteration
+  static __device__ __forceinline__ void norm_rcp(V3 a, double &s, double &rs) { sqrt_rcp(sqn(a), s, rs); }
+  static __device__ __forceinline__ double div_n(double x, double s, double rs) { return div_r(x, s, rs); }
+  static __device__ __forceinline__ V3 div3_n(V3 a, double s, double rs) {
+    return mk(div_r(a.x, s, rs), div_r(a.y, s, rs), div_r(a.z, s, rs));
+  }
+  // normalized() returns the vector itself unless squaredNorm > 0. TP
+  // (throughput shape, the group kernel): dividing by 1.0 instead does that
+  // exactly (x / 1.0 == x for every x, zeros keep their sign, NaNs stay NaN)
+  // with selects on the divisor and its reciprocal (4 instructions instead of
+  // 6). The wave-per-agent kernel keeps the select behind the division, off
+  // the sqrt -> divide chain its latency depends on.
   template <bool TP = false>
   static __device__ __forceinline__ void norm_unit(V3 a, double &s, V3 &u) {
-    double z = sqn(a);
-    s = sqrt(z);
+    double z = sqn(a), rs;
+    sqrt_rcp(z, s, rs);
     if (TP) {
-      u = div3(a, (z > 0.0) ? s : 1.0);
+      const bool pos = z > 0.0;
+      u = div3_n(a, pos ? s : 1.0, pos ? rs : 1.0);
     } else {
-      V3 q = div3(a, s);
+      V3 q = div3_n(a, s, rs);
       u = (z > 0.0) ? q : a;
     }
   }
@@ -176,6 +207,9 @@ template <> struct Mth<MATH_FAST> {
   static __device__ __forceinline__ double div(double a, double b) { return a * rcp(b); }
   static __device__ __forceinline__ V3 div3(V3 a, double s) { double r = rcp(s); return a * r; }
   static __device__ __forceinline__ double norm(V3 a) { return sqrt(sqn(a)); }
+  static __device__ __forceinline__ void norm_rcp(V3 a, double &s, double &rs) { sqrt_rsqrt(sqn(a), s, rs); }
+  static __device__ __forceinline__ double div_n(double x, double, double rs) { return x * rs; }
+  static __device__ __forceinline__ V3 div3_n(V3 a, double, double rs) { return a * rs; }
   template <bool TP = false>
   static __device__ __forceinline__ void norm_unit(V3 a, double &s, V3 &u) {
     double y;

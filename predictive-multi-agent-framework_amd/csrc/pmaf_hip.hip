@@ -298,15 +298,17 @@ __device__ __forceinline__ void rollout_w64_body(const DevView &D, const CostPar
     const V3 half = ((0.5 * acc) * C.dt) * C.dt;
     const V3 new_pos = (p + half) + (v * C.dt);
     const V3 nv = v + acc * C.dt;
-    const double vn = MT::norm(nv);
-    const V3 cl = nv * MT::div(C.vel_max, vn);
+    double vn, rvn;
+    MT::norm_rcp(nv, vn, rvn);
+    const V3 cl = nv * MT::div_n(C.vel_max, vn, rvn);
     v = (vn > C.vel_max) ? cl : nv;  // a select, not a branch: the block is not split (a branch measured 5 % slower)
     p = new_pos;
     g = goal - p;
-    dg = MT::norm(g);
+    double rdg;
+    MT::norm_rcp(g, dg, rdg);
     zv = sqn(v);
     z_init = sqn(p - init_pos);
-    const V3 gq = MT::div3(g, dg);
+    const V3 gq = MT::div3_n(g, dg, rdg);
     gn = (dg > 0.0) ? gq : g;  // goal_vec.normalized()
     verr = attractor_velocity_error<MATH>(v, g, C, k_attr, k_damp);
     if (lane == 0) { path[n * 3] = p.x; path[n * 3 + 1] = p.y; path[n * 3 + 2] = p.z; }
@@ -770,6 +772,8 @@ __global__ void k_debug_math(int op, int n, const double *a, const double *b, do
     case 6: r = Mth<MATH_XACT>::div(a[i], b[i]); break;
     case 7: { V3 q = Mth<MATH_XACT>::div3(mk(a[i], b[i], a[i] * 0.5), b[i] + a[i]); r = (q.x + q.y) + q.z; } break;
     case 8: { V3 q = mk(a[i], b[i], a[i] * 0.5) / (b[i] + a[i]); r = (q.x + q.y) + q.z; } break;
+    case 9: { double sq, rs; Mth<MATH_XACT>::sqrt_rcp(b[i], sq, rs); r = Mth<MATH_XACT>::div_r(a[i], sq, rs); } break;  // a / sqrt(b)
+    case 10: r = a[i] / __builtin_sqrt(b[i]); break;
   }
   out[i] = r;
 }
@@ -1829,7 +1833,7 @@ int pmaf_reset_kernel_stats(pmaf_planner *h) {
 }
 int pmaf_debug_math(int32_t op, int32_t n, const double *a, const double *b, double *out) {
   return guarded([&] {
-    REQUIRE(a && b && out && n > 0 && op >= 0 && op <= 8, "pmaf_debug_math: bad argument");
+    REQUIRE(a && b && out && n > 0 && op >= 0 && op <= 10, "pmaf_debug_math: bad argument");
     double *da = nullptr, *db = nullptr, *dout = nullptr;
     HIP_CHECK(hipMalloc((void **)&da, sizeof(double) * n));
     HIP_CHECK(hipMalloc((void **)&db, sizeof(double) * n));

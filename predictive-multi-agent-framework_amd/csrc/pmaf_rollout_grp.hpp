@@ -144,8 +144,9 @@ __device__ __forceinline__ void circ_and_scale_grp(bool act, int sub, int grp, i
         }
       }
       const V3 rot = mk(O.rx[t], O.ry[t], O.rz[t]);
-      const double vn = MT::norm(rv);
-      const V3 nv = MT::div3(rv, vn);
+      double vn, rvn;
+      MT::norm_rcp(rv, vn, rvn);
+      const V3 nv = MT::div3_n(rv, vn, rvn);
       const V3 cur = current_vector<MATH, true>(type, rv, g, ron, rot);
       const V3 c = MT::div(k_circ, d * d) * cross(nv, cross(cur, nv));
       const bool has_c = in_shell && (vn != 0);

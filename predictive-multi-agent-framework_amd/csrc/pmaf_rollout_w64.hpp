@@ -42,7 +42,9 @@ template <int MATH>
 __device__ __forceinline__ V3 attractor_velocity_error(V3 v, V3 goal_vec, const PopConst &C, double k_attr,
                                                        double k_damp) {
   V3 vel_des = (k_attr / k_damp) * goal_vec;
-  double scale_lim = smin(1.0, Mth<MATH>::div(C.vel_max, Mth<MATH>::norm(vel_des)));
+  double nd, rnd;
+  Mth<MATH>::norm_rcp(vel_des, nd, rnd);
+  double scale_lim = smin(1.0, Mth<MATH>::div_n(C.vel_max, nd, rnd));
   vel_des = vel_des * scale_lim;
   return vel_des - v;
 }
@@ -81,8 +83,9 @@ __device__ __forceinline__ void finish_step_w64(V3 p, V3 &v, V3 verr, V3 F, doub
   V3 half = ((0.5 * acc) * C.dt) * C.dt;
   new_pos = (p + half) + (v * C.dt);
   V3 nv = v + acc * C.dt;
-  const double vn = Mth<MATH>::norm(nv);
-  const double f = Mth<MATH>::div(C.vel_max, vn);
+  double vn, rvn;
+  Mth<MATH>::norm_rcp(nv, vn, rvn);
+  const double f = Mth<MATH>::div_n(C.vel_max, vn, rvn);
   const V3 cl = nv * f;
   v = (vn > C.vel_max) ? cl : nv;
 }
@@ -293,10 +296,9 @@ __device__ __forceinline__ void circ_and_scale_w64(int lane, V3 p, V3 v, double 
     if (TILES > 1 && !__any(in_t[t])) continue;  // no term from this slot (wave-uniform)
     const V3 rot = mk(O.rx[t], O.ry[t], O.rz[t]);
     const V3 rv = rv_t[t];
-    double vn;
-    V3 nv;
-    if (MATH == MATH_FAST) { MT::norm_unit(rv, vn, nv); }
-    else { vn = MT::norm(rv); nv = MT::div3(rv, vn); }
+    double vn, rvn;
+    MT::norm_rcp(rv, vn, rvn);
+    const V3 nv = MT::div3_n(rv, vn, rvn);
     const V3 cur = current_vector<MATH>(TYPE, rv, g, ron_t[t], rot);
     const V3 c = MT::div(k_circ, d_t[t] * d_t[t]) * cross(nv, cross(cur, nv));
     const bool has_c = in_t[t] && (vn != 0);

@@ -521,9 +521,15 @@ def test_xact_sequences_match_ieee(pmaf):
         wb = np.ldexp(rng.uniform(1.0, 2.0, n), rng.integers(-250, 250, n)) * rng.choice([-1.0, 1.0], n)
         assert (pmaf.debug_math(5, np.abs(wa)) == np.sqrt(np.abs(wa))).all()
         assert (pmaf.debug_math(6, wa, wb) == wa / wb).all()
+        # a / sqrt(b) with the reciprocal of the norm taken from the sqrt iteration (op 9)
+        assert (pmaf.debug_math(9, a, np.abs(b)) == a / np.sqrt(np.abs(b))).all()
+        assert (pmaf.debug_math(9, wa, np.abs(wb)) == wa / np.sqrt(np.abs(wb))).all()
+        v = rng.uniform(-1.5, 1.5, (n, 3))
+        z = (v[:, 0] * v[:, 0] + v[:, 1] * v[:, 1]) + v[:, 2] * v[:, 2]
+        assert (pmaf.debug_math(9, v[:, 1], z) == v[:, 1] / np.sqrt(z)).all()
         special = np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 1.0, -1.0, 3.0, 2.0 ** -250, 2.0 ** 250, -7.5])
         A, B = [x.ravel() for x in np.meshgrid(special, special)]
-        for op, ref in ((5, np.sqrt(A)), (6, A / B)):
+        for op, ref in ((5, np.sqrt(A)), (6, A / B), (9, A / np.sqrt(B))):
             got = pmaf.debug_math(op, A, B)
             same = (got == ref) | (np.isnan(got) & np.isnan(ref))
             assert same.all(), (op, A[~same], B[~same], got[~same], ref[~same])

@@ -227,8 +227,9 @@ def main():
         traffic = None
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-            if args.config == "C2" and P == 1 and kernel_name in tj:
-                traffic = tj[kernel_name]["traffic_bytes_per_launch"]
+            key = "%s%s:%s" % (args.config, "" if P == 1 else "x%d" % P, kernel_name)
+            if key in tj and not args.dynamic:
+                traffic = tj[key]["traffic_bytes_per_launch"]
         except (OSError, ValueError, KeyError):
             traffic = None
         out = {

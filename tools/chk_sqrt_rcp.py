@@ -6,7 +6,7 @@ import __graft_entry__ as g
 pm = g.load_package()
 rng = np.random.default_rng(11)
 bad = 0; tot = 0
-for rnd in range(12):
+for rnd in range(int(sys.argv[1]) if len(sys.argv) > 1 else 12):
     n = 4_000_000
     if rnd % 3 == 0:
         a = rng.uniform(1e-12, 50.0, n) * rng.choice([-1.0, 1.0], n); b = rng.uniform(1e-12, 50.0, n)

@@ -9,7 +9,8 @@ export TMPDIR=/tmp
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp
-timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/trace -o t -- python $R/bench.py --steps 200 --warmup 20 --cpu-seconds 0 "$@" > $OUT/trace.log 2>&1 < /dev/null
+# same command as the bench line it documents (default --steps / --warmup), minus the CPU baseline
+timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/trace -o t -- python $R/bench.py --cpu-seconds 0 "$@" > $OUT/trace.log 2>&1 < /dev/null
 python $R/tools/prof_summary.py $OUT/trace $OUT/trace_summary.txt < /dev/null
 i=0
 for PMC in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES" \

@@ -268,17 +268,23 @@ def main():
         else:
             out["cpu_baseline"] = None
         line = json.dumps(out)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
-    if rank == 0:
-        # the JSON line is the last thing written (RCCL may print a banner at its first collective)
+
+    def flush_all():
         sys.stdout.flush()
-        try:  # ... including what C libraries still hold in their stdio buffers
+        try:  # ... including what C libraries (RCCL's banner) still hold in their stdio buffers
             import ctypes
             ctypes.CDLL(None).fflush(None)
         except OSError:
             pass
+
+    # the JSON line is the last thing written by the job: every rank empties its
+    # buffers before the final barrier, rank 0 prints after it
+    flush_all()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        flush_all()
         print(line, flush=True)
 
 

@@ -532,9 +532,75 @@ __global__ void k_score(DevView D, CostParams CP) {
 // ---------------------------------------------------------------------------
 // k_manager: evaluate / real step / reset, one wave per population
 // ---------------------------------------------------------------------------
+// RealCfAgent::cfPlanner, ONE step (B/src/cf_agent.cpp:343-366), with the tuned
+// wave-per-agent step functions: the live obstacles, the real agent's rotation
+// vectors and known flags sit in this wave's registers exactly as an agent's do
+// in k_rollout_w64 (the generic LDS-table path took 7 us per call, this one
+// is the same code the rollout spends ~2 us per step in). No min_obs_dist_
+// tracking (RealCfAgent::circForce :110-144), heuristic = the stored best agent's.
+template <int TILES>
+__device__ __forceinline__ void real_step_w64(const DevView &D, const double dt_real, const int pop, const int lane,
+                                              const int htype, const double *live, const int32_t *s_known,
+                                              double *rot_g, const double *rand_g, double *clist, const double k_attr,
+                                              const double k_circ, const double k_repel, const double k_damp,
+                                              const V3 goal, const V3 init_pos, V3 &rp, V3 &rv, V3 &F_total,
+                                              unsigned &known_bits) {
+  typedef Mth<MATH_XACT> MT;
+  PopConst C = D.C;
+  C.dt = dt_real;
+  const int n_obs = D.n_obs, M = n_obs - 1;
+  LaneObstacles<TILES> O;
+  known_bits = 0u;
+#pragma unroll
+  for (int t = 0; t < TILES; t++) {
+    const int i = t * 64 + lane;
+    const bool valid = i < M;
+    const int ii = valid ? i : 0;
+    O.p[t] = mk(live[ii], live[n_obs + ii], live[2 * n_obs + ii]);
+    O.v[t] = mk(live[3 * n_obs + ii], live[4 * n_obs + ii], live[5 * n_obs + ii]);
+    O.r[t] = live[6 * n_obs + ii];
+    O.rx[t] = rot_g[ii]; O.ry[t] = rot_g[n_obs + ii]; O.rz[t] = rot_g[2 * n_obs + ii];
+    O.qx[t] = rand_g[ii]; O.qy[t] = rand_g[n_obs + ii]; O.qz[t] = rand_g[2 * n_obs + ii];
+    if (valid && s_known[ii]) known_bits |= (1u << t);
+  }
+  const V3 sent_p = mk(live[M], live[n_obs + M], live[2 * n_obs + M]);
+  const double sent_r = live[6 * n_obs + M];
+  const V3 g = goal - rp;
+  const double dg = MT::norm(g);
+  const double zv = sqn(rv);
+  const double z_init = sqn(rp - init_pos);
+  const bool gate = !(dg < C.approach || (zv < C.zvhalf_lt && z_init < C.zinit_lt));  // :347-349
+  const V3 gn = (dg > 0.0) ? MT::div3(g, dg) : g;
+  const V3 verr = attractor_velocity_error<MATH_XACT>(rv, g, C, k_attr, k_damp);
+  const V3 repel = sentinel_repel(rp, C, k_repel, sent_p, sent_r, D.zsent_lt[pop]);
+  V3 F = mk(0.0, 0.0, 0.0);
+  double scale = 1.0, no_min = C.shell;
+  SecTimers ST;
+  if (gate)
+    circ_and_scale_w64<TILES, T_REAL, MATH_XACT>(lane, rp, rv, zv, goal, g, dg, gn, C, k_circ, n_obs, rot_g, known_bits,
+                                                 O, clist, no_min, F, scale, ST, 0, htype);
+  F = F + (mk(0.0, 0.0, 0.0) + repel);
+  if (k_attr != 0.0) F = F + (scale * k_damp) * verr;
+  F_total = F;
+  V3 acc = F;
+  if (C.mass != 1.0) acc = F / C.mass;
+  const double az = sqn(acc);
+  if (az >= C.zacc_gt) acc = acc * (13.0 / __builtin_sqrt(az));
+  const V3 half = ((0.5 * acc) * C.dt) * C.dt;
+  const V3 new_pos = (rp + half) + (rv * C.dt);
+  const V3 nv = rv + acc * C.dt;
+  double vn, rvn;
+  MT::norm_rcp(nv, vn, rvn);
+  const V3 cl = nv * MT::div_n(C.vel_max, vn, rvn);
+  rv = (vn > C.vel_max) ? cl : nv;
+  rp = new_pos;
+}
+
 struct ManagerArgs {
   int do_select, do_move, do_reset;
   int reset_from_real;     // 1: reset to the real agent's state, 0: reset_in
+  int rollout_follows;     // 1: the rollout kernel is launched right behind this one (pmaf_tick)
+  int tuned_real_step;     // 1: real_step_w64 (default arithmetic policy, M <= 256), 0: generic LDS-table path
   double dt_real;
   const int32_t *agent_id; // [P] gains index for the real step; NULL = best_idx of this launch
   const double *reset_in;  // [P][6] pos, vel
@@ -637,20 +703,36 @@ __global__ __launch_bounds__(64) void k_manager(DevView D, CostParams CP, Manage
     wave_lds_fence();  // obstacle table + known flags in LDS
     const int ntiles = (M + 63) / 64;
     unsigned long long kb = 0ull;
-    for (int t = 0; t < ntiles; t++) {
-      int i = t * 64 + lane;
-      if (i < M && s_known[i]) kb |= (1ull << t);
-    }
-    V3 g = goal - rp;
-    double dg = norm(g);
-    bool gate = !(dg < C.approach || (norm(rv) < 0.5 * C.vel_max && norm(rp - init_pos) < 0.2));
     V3 F = mk(0.0, 0.0, 0.0);
-    double scale = 1.0, dummy_min = C.shell;
-    circ_and_scale<64, true>(gate, lane, 0, htype, rp, rv, goal, g, C, k_circ, T, n_obs,
-                             D.real_rot + (size_t)pop * 3 * n_obs, rand_g, kb, dummy_min, F, scale);
-    V3 new_pos;
-    finish_step(rp, rv, g, F, scale, C, k_attr, k_repel, k_damp, A.dt_real, T.pos(n_obs - 1), T.r[n_obs - 1], new_pos);
-    rp = new_pos;
+    if (A.tuned_real_step && ntiles <= 4) {
+      double *rrot = D.real_rot + (size_t)pop * 3 * n_obs;
+      double *clist = s_cost + N + (N & 1);
+      unsigned kb32 = 0u;
+      if (ntiles <= 1)
+        real_step_w64<1>(D, A.dt_real, pop, lane, htype, smem, s_known, rrot, rand_g, clist, k_attr, k_circ, k_repel,
+                         k_damp, goal, init_pos, rp, rv, F, kb32);
+      else if (ntiles == 2)
+        real_step_w64<2>(D, A.dt_real, pop, lane, htype, smem, s_known, rrot, rand_g, clist, k_attr, k_circ, k_repel,
+                         k_damp, goal, init_pos, rp, rv, F, kb32);
+      else
+        real_step_w64<4>(D, A.dt_real, pop, lane, htype, smem, s_known, rrot, rand_g, clist, k_attr, k_circ, k_repel,
+                         k_damp, goal, init_pos, rp, rv, F, kb32);
+      kb = kb32;
+    } else {
+      for (int t = 0; t < ntiles; t++) {
+        int i = t * 64 + lane;
+        if (i < M && s_known[i]) kb |= (1ull << t);
+      }
+      V3 g = goal - rp;
+      double dg = norm(g);
+      bool gate = !(dg < C.approach || (norm(rv) < 0.5 * C.vel_max && norm(rp - init_pos) < 0.2));
+      double scale = 1.0, dummy_min = C.shell;
+      circ_and_scale<64, true>(gate, lane, 0, htype, rp, rv, goal, g, C, k_circ, T, n_obs,
+                               D.real_rot + (size_t)pop * 3 * n_obs, rand_g, kb, dummy_min, F, scale);
+      V3 new_pos;
+      finish_step(rp, rv, g, F, scale, C, k_attr, k_repel, k_damp, A.dt_real, T.pos(n_obs - 1), T.r[n_obs - 1], new_pos);
+      rp = new_pos;
+    }
     rf = F;
     for (int t = 0; t < ntiles; t++) {
       int i = t * 64 + lane;
@@ -700,17 +782,20 @@ __global__ __launch_bounds__(64) void k_manager(DevView D, CostParams CP, Manage
     for (int i = lane; i < 6 * n_obs; i += 64) st[i] = smem[i];
     int32_t *ks = D.known_start + (size_t)pop * n_obs;
     for (int i = lane; i < n_obs; i += 64) ks[i] = s_known[i];
-    for (int a = lane; a < N; a += 64) {
-      size_t pa = (size_t)pop * N + a;
-      double *path = D.paths + pa * (size_t)D.cap * 3;
-      path[0] = sp.x; path[1] = sp.y; path[2] = sp.z;
-      D.n_points[pa] = 1;
-      D.agent_vel[pa * 3] = sv.x; D.agent_vel[pa * 3 + 1] = sv.y; D.agent_vel[pa * 3 + 2] = sv.z;
-      D.min_obs[pa] = C.shell;
-    }
-    // known_obstacles_ of every agent <- the real agent's flags (setObstacles, cf_agent.cpp:68):
-    // one coalesced sweep over [N][n_obs] instead of a per-agent loop
-    {
+    // The agents' own copies (path start, point count, velocity, min_obs_dist_, known_obstacles_) are what
+    // getters see between a reset and the next rollout. When the rollout is launched right behind this
+    // kernel (pmaf_tick) it rewrites every one of them, so the stores are skipped.
+    if (!A.rollout_follows) {
+      for (int a = lane; a < N; a += 64) {
+        size_t pa = (size_t)pop * N + a;
+        double *path = D.paths + pa * (size_t)D.cap * 3;
+        path[0] = sp.x; path[1] = sp.y; path[2] = sp.z;
+        D.n_points[pa] = 1;
+        D.agent_vel[pa * 3] = sv.x; D.agent_vel[pa * 3 + 1] = sv.y; D.agent_vel[pa * 3 + 2] = sv.z;
+        D.min_obs[pa] = C.shell;
+      }
+      // known_obstacles_ of every agent <- the real agent's flags (setObstacles, cf_agent.cpp:68):
+      // one coalesced sweep over [N][n_obs] instead of a per-agent loop
       int32_t *ko = D.known_out + (size_t)pop * N * n_obs;
       for (int k = lane; k < N * n_obs; k += 64) ko[k] = s_known[k % n_obs];
     }
@@ -1054,7 +1139,9 @@ static void upload_live_obstacles(pmaf_planner *h, const double *obstacles) {
   HIP_CHECK(hipEventRecord(h->ev_stage[s], h->stream));
 }
 
-static void launch_manager(pmaf_planner *h, const ManagerArgs &A) {
+static void launch_manager(pmaf_planner *h, const ManagerArgs &A0) {
+  ManagerArgs A = A0;
+  A.tuned_real_step = (h->math == MATH_XACT && !h->force_generic) ? 1 : 0;
   hipLaunchKernelGGL(k_manager, dim3((unsigned)h->D.P), dim3(64), h->lds_manager, h->stream, h->D, h->cp, A);
   HIP_CHECK(hipGetLastError());
 }
@@ -1184,7 +1271,8 @@ int pmaf_create(const pmaf_params *prm, pmaf_planner **out) {
       // w64: (64 * TILES + 8 padding + 64 scratch) entries; groups: 64 * TILES + one zero entry per group (<= 8)
       h->lds_rollout = sizeof(double) * (off + (64 * 4 + 8 + 64) * 4 + 8 * 4);
     }
-    h->lds_manager = sizeof(double) * (7 * (size_t)n_obs + ((size_t)n_obs + 1) / 2 + (size_t)N);
+    // table | known flags | costs | the tuned real step's list (64 * 4 + 8 + 64 entries of 4 doubles)
+    h->lds_manager = sizeof(double) * (7 * (size_t)n_obs + ((size_t)n_obs + 1) / 2 + (size_t)N + 1 + (64 * 4 + 8 + 64) * 4);
     REQUIRE(h->lds_rollout <= 160 * 1024, "pmaf_create: obstacle table does not fit in LDS");
 
     size_t PN = (size_t)P * N;
@@ -1476,6 +1564,7 @@ int pmaf_tick(pmaf_planner *h, const double *obstacles, double dt, const double 
     ensure_scores(h);
     ManagerArgs A{};
     A.do_select = 1; A.do_move = 1; A.do_reset = 1; A.reset_from_real = 1;
+    A.rollout_follows = 1;
     A.dt_real = dt;
     A.out = h->d_out;
     A.seq = (double)(++h->mailbox_seq);

@@ -229,8 +229,12 @@ __device__ __forceinline__ void circ_and_scale_w64(int lane, V3 p, V3 v, double 
                                                    const PopConst &C, double k_circ,
                                                    int n_obs, double *rot_g, unsigned &known_bits,
                                                    LaneObstacles<TILES> &O, double *clist, double &lane_min,
-                                                   V3 &F, double &scale, SecTimers &ST, const int ablate = 0) {
+                                                   V3 &F, double &scale, SecTimers &ST, const int ablate = 0,
+                                                   const int rtype = 0) {
   typedef Mth<MATH> MT;
+  // TYPE == T_REAL: the heuristic is a run-time value (the real agent's step in
+  // k_manager dispatches to the stored best agent's type, cf_agent.cpp:368-387)
+  const int type = (TYPE == T_REAL) ? rtype : TYPE;
   constexpr int BATCH = 8;                 // list entries summed per LDS round trip
   constexpr int SCRATCH = 64 * TILES + BATCH;
   const int M = n_obs - 1;
@@ -276,9 +280,9 @@ __device__ __forceinline__ void circ_and_scale_w64(int lane, V3 p, V3 v, double 
     const bool need_latch = in_t[t] && !((known_bits >> t) & 1u);
     if (__any(need_latch)) {
       V3 cpos = O.p[t];
-      if (TYPE == T_OBST || TYPE == T_GOALOBST) cpos = closest_other_w64<TILES, MATH>(need_latch, t, lane, M, O);
+      if (type == T_OBST || type == T_GOALOBST) cpos = closest_other_w64<TILES, MATH>(need_latch, t, lane, M, O);
       if (need_latch) {
-        V3 rot = calc_rot_vec_c(TYPE, p, goal, n_obs, O.p[t], cpos, mk(O.qx[t], O.qy[t], O.qz[t]));
+        V3 rot = calc_rot_vec_c(type, p, goal, n_obs, O.p[t], cpos, mk(O.qx[t], O.qy[t], O.qz[t]));
         rot_g[i] = rot.x; rot_g[n_obs + i] = rot.y; rot_g[2 * n_obs + i] = rot.z;
         O.rx[t] = rot.x; O.ry[t] = rot.y; O.rz[t] = rot.z;
         known_bits |= (1u << t);
@@ -299,7 +303,7 @@ __device__ __forceinline__ void circ_and_scale_w64(int lane, V3 p, V3 v, double 
     double vn, rvn;
     MT::norm_rcp(rv, vn, rvn);
     const V3 nv = MT::div3_n(rv, vn, rvn);
-    const V3 cur = current_vector<MATH>(TYPE, rv, g, ron_t[t], rot);
+    const V3 cur = current_vector<MATH>(type, rv, g, ron_t[t], rot);
     const V3 c = MT::div(k_circ, d_t[t] * d_t[t]) * cross(nv, cross(cur, nv));
     const bool has_c = in_t[t] && (vn != 0);
     // compact the contributing terms, ascending obstacle index

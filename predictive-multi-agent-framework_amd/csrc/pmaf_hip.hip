@@ -326,7 +326,7 @@ __device__ __forceinline__ void rollout_w64_body(const DevView &D, const CostPar
     PMAF_SEC(ST, 7);
   }
 #ifdef PMAF_SECTION_TIMERS
-  if (lane == 0 && pop == 0 && (a == 1 || a == 5))
+  if (lane == 0 && pop == 0 && a < 7)
     printf("agent %d type %d steps %d | verr+gate %llu sweep %llu scale %llu circ %llu sum %llu (skip) %llu finish %llu tail %llu | "
            "in-shell steps %llu terms %llu\n", a, TYPE, n - 1, ST.acc[0], ST.acc[1], ST.acc[2], ST.acc[3], ST.acc[4],
            ST.acc[5], ST.acc[6], ST.acc[7], ST.cnt[0], ST.cnt[1]);

@@ -235,7 +235,7 @@ __device__ __forceinline__ void circ_and_scale_w64(int lane, V3 p, V3 v, double 
   // TYPE == T_REAL: the heuristic is a run-time value (the real agent's step in
   // k_manager dispatches to the stored best agent's type, cf_agent.cpp:368-387)
   const int type = (TYPE == T_REAL) ? rtype : TYPE;
-  constexpr int BATCH = 8;                 // list entries summed per LDS round trip
+  constexpr int BATCH = 8;                 // list entries summed per LDS round trip (10, 12, 16 measured: no gain)
   constexpr int SCRATCH = 64 * TILES + BATCH;
   const int M = n_obs - 1;
   double best_d = C.shell;
@@ -314,7 +314,7 @@ __device__ __forceinline__ void circ_and_scale_w64(int lane, V3 p, V3 v, double 
     count += __popcll(m);
   }
   {  // zero padding behind the list (8 distinct entries, written by all lanes)
-    double *e = clist + (size_t)(count + (lane & (BATCH - 1))) * 4;
+    double *e = clist + (size_t)(count + (lane % BATCH)) * 4;
     e[0] = 0.0; e[1] = 0.0; e[2] = 0.0;
   }
   PMAF_CNT(ST, 1, count);

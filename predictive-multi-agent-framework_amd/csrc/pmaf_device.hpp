@@ -450,39 +450,44 @@ __device__ __forceinline__ int closest_other(const ObsTab &T, int n_obs, int id,
 // GoalObstacle heuristics). The tuned kernels find it with a cooperative
 // search over the lanes' register copies, the generic kernel / k_manager scan
 // the LDS table (calc_rot_vec below).
+template <int MATH = MATH_IEEE>
 __device__ __forceinline__ V3 calc_rot_vec_c(int type, V3 agent_pos, V3 goal_pos, int n_obs, V3 own_pos,
                                              V3 closest_pos, V3 rand_vec) {
+  typedef Mth<MATH> M;
   if (type == T_GOAL || type == T_VEL) return mk(0.0, 0.0, 1.0);
   if (type == T_OBST) {
     if (n_obs < 2) return mk(0.0, 0.0, 1.0);
     V3 obstacle_vec = closest_pos - own_pos;
-    V3 to_obs = normalized(own_pos - agent_pos);
+    V3 to_obs = M::normalized(own_pos - agent_pos);
     V3 cur = to_obs * dot(obstacle_vec, to_obs) - obstacle_vec;
-    return normalized(cross(cur, to_obs));
+    return M::normalized(cross(cur, to_obs));
   }
   if (type == T_GOALOBST) {
     V3 obstacle_vec = closest_pos - own_pos;
-    V3 to_obs = normalized(own_pos - agent_pos);
+    V3 to_obs = M::normalized(own_pos - agent_pos);
     V3 obst_cur = to_obs * dot(obstacle_vec, to_obs) - obstacle_vec;
     V3 goal_vec = goal_pos - agent_pos;
     V3 goal_cur = goal_vec - to_obs * dot(to_obs, goal_vec);
-    V3 cur = normalized(goal_cur) + normalized(obst_cur);
-    if (norm(cur) < 1e-10) cur = mk(0.0, 0.0, 1.0);
-    cur = normalized(cur);
-    return normalized(cross(cur, to_obs));
+    V3 cur = M::normalized(goal_cur) + M::normalized(obst_cur);
+    // `if (cur.norm() < 1e-10) cur = (0,0,1); cur.normalize()` with one square root (see current_vector)
+    double s;
+    V3 u;
+    M::norm_unit(cur, s, u);
+    cur = (s < 1e-10) ? mk(0.0, 0.0, 1.0) : u;
+    return M::normalized(cross(cur, to_obs));
   }
   if (type == T_RANDOM) {
-    V3 goal_vec = normalized(goal_pos - agent_pos);
+    V3 goal_vec = M::normalized(goal_pos - agent_pos);
     return cross(goal_vec, rand_vec);
   }
   if (type == T_HAD) {
     V3 obs_pos = own_pos;
     V3 goal_vec = goal_pos - agent_pos;
     V3 rob_obs = obs_pos - agent_pos;
-    double gn = norm(goal_vec);
-    V3 d = (agent_pos + goal_vec * (dot(rob_obs, goal_vec) / (gn * gn))) - obs_pos;
+    double gn = M::norm(goal_vec);
+    V3 d = (agent_pos + goal_vec * M::div(dot(rob_obs, goal_vec), gn * gn)) - obs_pos;
     V3 c = cross(d, goal_vec);
-    return c / norm(c);
+    return M::div3(c, M::norm(c));
   }
   return mk(0.0, 0.0, 0.0);
 }

@@ -68,3 +68,30 @@ def test_product_sources_do_not_reference_the_oracle():
                     for line in txt.splitlines():
                         if re.search(r"^\s*(from|import)\s+oracle|#include\s+\"[^\"]*oracle|libpmaf_oracle|orc_[a-z_]+\(", line):
                             raise AssertionError("%s references the oracle: %s" % (f, line.strip()))
+
+
+def test_throughput_kernels_keep_two_waves_per_simd(pmaf):
+    """k_rollout_grp hides its latencies with a second wave on the SIMD, i.e. it
+    must stay within 256 VGPRs (it sits just below; csrc/build.sh records every
+    kernel's resources). A variant that tips over runs at half the rate."""
+    rec = os.path.join(os.path.dirname(pmaf.LIB_PATH), "resource_usage.txt")
+    if not os.path.exists(rec):
+        pytest.skip("no resource record next to the library (built by another recipe)")
+    kernels = {}
+    name = None
+    for line in open(rec):
+        line = line.strip()
+        if line.startswith("Function Name:"):
+            name = line.split(":", 1)[1].strip()
+            kernels[name] = {}
+        elif name and ":" in line:
+            k, v = line.rsplit(":", 1)
+            kernels[name][k.strip()] = v.strip()
+    grp = [k for k in kernels if re.match(r"_Z13k_rollout_grpILi(8|16|32)ELi[12]ELi2EE", k)]
+    assert len(grp) == 6, sorted(kernels)
+    for k in grp:
+        assert int(kernels[k]["Occupancy [waves/SIMD]"]) >= 2, (k, kernels[k])
+        assert int(kernels[k]["ScratchSize [bytes/lane]"]) == 0, (k, kernels[k])
+    for k in kernels:
+        if re.match(r"_Z13k_rollout_w64ILi[12]ELi2EE", k):
+            assert int(kernels[k]["ScratchSize [bytes/lane]"]) == 0, (k, kernels[k])

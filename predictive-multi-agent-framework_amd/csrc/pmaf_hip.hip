@@ -308,8 +308,7 @@ __device__ __forceinline__ void rollout_w64_body(const DevView &D, const CostPar
     MT::norm_rcp(g, dg, rdg);
     zv = sqn(v);
     z_init = sqn(p - init_pos);
-    const V3 gq = MT::div3_n(g, dg, rdg);
-    gn = (dg > 0.0) ? gq : g;  // goal_vec.normalized()
+    gn = MT::div3_n(g, dg, rdg);  // goal_vec.normalized(); only used if the loop goes on, i.e. dg > 0.1: no zero-norm case
     verr = attractor_velocity_error<MATH>(v, g, C, k_attr, k_damp);
     if (lane == 0) { path[n * 3] = p.x; path[n * 3 + 1] = p.y; path[n * 3 + 2] = p.z; }
     n++;

@@ -804,3 +804,38 @@ def test_repulsive_obstacle_moving_into_range(pmaf, oracle, scenes):
         sc["obstacles"][-1] = [0.0, 2.0, 0.7, 0.0, -1.2, 0.0, 0.1]
         hip, ora = run_both(pmaf, oracle, scenes, sc, 3, dynamic=True, lanes_per_agent=lpa)
         hip.close()
+
+
+def test_handle_lifecycle_does_not_leak_device_memory(pmaf, scenes):
+    """create / tick / destroy in a loop: device memory returns to where it was
+    (CfManager's destructor joins its threads and frees everything,
+    cf_manager.h:51), and two live handles do not disturb each other"""
+    import torch
+    sc = scenes.config_scene("C1")
+
+    def one():
+        h = pmaf.PmafPlanner(sc, device=0, mgr_init_pos=sc["start"])
+        h.set_initial_position(sc["start"])
+        for _ in range(3):
+            h.tick(sc["obstacles"], sc["dt"], sc["cost_gains"], sc["ws_limits"])
+        h.stop()
+        out = np.asarray(h.real_state()[0]).copy()
+        h.close()
+        return out
+
+    ref = one()
+    free0 = torch.cuda.mem_get_info(0)[0]
+    for _ in range(25):
+        np.testing.assert_array_equal(one(), ref)
+    free1 = torch.cuda.mem_get_info(0)[0]
+    assert free0 - free1 < 8 << 20, (free0, free1)   # allocator slack only
+    a = pmaf.PmafPlanner(sc, device=0, mgr_init_pos=sc["start"])
+    b = pmaf.PmafPlanner(sc, device=0, mgr_init_pos=sc["start"])
+    a.set_initial_position(sc["start"]); b.set_initial_position(sc["start"])
+    for _ in range(3):
+        a.tick(sc["obstacles"], sc["dt"], sc["cost_gains"], sc["ws_limits"])
+        b.tick(sc["obstacles"], sc["dt"], sc["cost_gains"], sc["ws_limits"])
+    a.stop(); b.stop()
+    np.testing.assert_array_equal(a.real_state()[0], ref)
+    np.testing.assert_array_equal(b.real_state()[0], ref)
+    a.close(); b.close()

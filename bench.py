@@ -12,7 +12,8 @@ issued back to back, each returning best index + next set-point to the host
 (the real per-tick API, not a batched open-loop shortcut).
 
 N > 1 (launched by torch.distributed.run, one rank per GPU): every rank plans
-its own independent population (scene id = rank) -- the path shards by
+its own independent population (the same scene on every GPU, so the per-GPU
+work is fixed; --distinct-scenes gives rank r scene r) -- the path shards by
 population with no data-path collective (weak scaling). torch.distributed is
 used only for the barrier and the max-over-ranks timing.
 
@@ -102,6 +103,9 @@ def main():
     ap.add_argument("--lanes-per-agent", type=int, default=0)
     ap.add_argument("--dynamic", action="store_true", help="moving obstacles, re-uploaded every tick")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline time budget (0 = skip)")
+    ap.add_argument("--distinct-scenes", action="store_true",
+                    help="N > 1: rank r plans scene(s) r*P .. r*P+P-1 (a goal/obstacle sweep) instead of every rank "
+                         "planning the same scene(s)")
     ap.add_argument("--episode", type=int, default=256,
                     help="ticks per episode: the real agent is put back at the start every EPISODE ticks so every "
                          "timed rollout runs its full horizon (stationary workload; 0 = never)")
@@ -136,7 +140,10 @@ def main():
 
     pkg = graft.load_package()
     pkg.load_library()
-    scenes = [pkg.scenes.config_scene(args.config, scene_id=rank * args.populations + i, dynamic=args.dynamic)
+    # weak scaling = the SAME work on every GPU: all ranks plan the same scene(s) unless --distinct-scenes
+    # (the seeded scenes differ by +-3 % in tick time, which would read as a scaling loss of the slowest one)
+    first = rank * args.populations if args.distinct_scenes else 0
+    scenes = [pkg.scenes.config_scene(args.config, scene_id=first + i, dynamic=args.dynamic)
               for i in range(args.populations)]
     sc = scenes[0]
     N, H, n_obs = sc["n_agents"], sc["max_prediction_steps"] - 1, sc["obstacles"].shape[0]
@@ -241,7 +248,8 @@ def main():
                                    "%d population(s) per GPU, %s obstacles, one pmaf_tick per step"
                                    % (args.config, N, H, n_obs - 1, P, "moving" if args.dynamic else "static"),
                        "agents": N, "horizon": H, "obstacles": n_obs - 1, "populations_per_gpu": P,
-                       "parallelism": "population-per-gpu x%d" % world,
+                       "parallelism": "population-per-gpu x%d (%s)" % (world, "distinct scenes" if args.distinct_scenes
+                                                                      else "same scene on every GPU"),
                        "lanes_per_agent": cfg["lanes_per_agent"], "rollout_blocks": cfg["n_blocks"],
                        "arithmetic": "f64, hand-expanded IEEE div/sqrt sequences (default policy; bit-identical to "
                                      "the CPU oracle)"},

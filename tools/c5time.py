@@ -1,3 +1,5 @@
+"""C5 (P populations x 1024 agents in one handle): tick and rollout-kernel time per lanes-per-agent mapping.
+usage: python tools/c5time.py [P] [lpa,lpa,...]"""
 import sys, time, numpy as np
 sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 import __graft_entry__ as g

@@ -1,3 +1,5 @@
+"""tick / rollout-kernel time of a BASELINE config per lanes-per-agent mapping (FAST=1: opt-in fast arithmetic).
+usage: python tools/quicktime.py C2:64,32 C3:64 ..."""
 import sys, time, numpy as np
 sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 import __graft_entry__ as g

@@ -228,13 +228,26 @@ template <> struct Mth<MATH_FAST> {
 // Written without branches (selects only): the rollout kernels place it in one
 // straight-line region together with independent vector work so that a lone
 // wave's in-order issue can fill the latency of this dependent chain.
+// The constants come in a struct so that a kernel can hold them in VGPRs
+// across its step loop (exp_consts_in_vgprs): as literals they are scalar
+// values the compiler keeps in -- and spills from -- the SGPR file.
+struct ExpK {
+  double ln2HI, ln2LO, invln2, P1, P2, P3, P4, P5;
+};
+__device__ __forceinline__ ExpK exp_consts() {
+  ExpK K;
+  K.ln2HI = 6.93147180369123816490e-01; K.ln2LO = 1.90821492927058770002e-10; K.invln2 = 1.44269504088896338700e+00;
+  K.P1 = 1.66666666666666019037e-01; K.P2 = -2.77777777770155933842e-03; K.P3 = 6.61375632143793436117e-05;
+  K.P4 = -1.65339022054652515390e-06; K.P5 = 4.13813679705723846039e-08;
+  return K;
+}
+__device__ __forceinline__ ExpK exp_consts_in_vgprs() {
+  ExpK K = exp_consts();
+  asm volatile("" : "+v"(K.ln2HI), "+v"(K.ln2LO), "+v"(K.invln2), "+v"(K.P1), "+v"(K.P2), "+v"(K.P3), "+v"(K.P4), "+v"(K.P5));
+  return K;
+}
 template <int MATH = MATH_IEEE>
-__device__ __forceinline__ double portable_exp(double x) {
-  const double ln2HI = 6.93147180369123816490e-01, ln2LO = 1.90821492927058770002e-10,
-               invln2 = 1.44269504088896338700e+00,
-               P1 = 1.66666666666666019037e-01, P2 = -2.77777777770155933842e-03,
-               P3 = 6.61375632143793436117e-05, P4 = -1.65339022054652515390e-06,
-               P5 = 4.13813679705723846039e-08;
+__device__ __forceinline__ double portable_exp(double x, const ExpK &K) {
   const double ax = fabs(x);
   const bool big = ax > 708.0;                    // outside the path's range: +inf / 0
   const bool tiny = ax < 3.725290298461914e-09;   // |x| < 2^-28: 1 + x
@@ -242,19 +255,21 @@ __device__ __forceinline__ double portable_exp(double x) {
   // k = 0 for |x| <= 0.5 ln2, else round(x / ln2); one formula for all k
   // (for k = 0: hi = x, lo = 0, and 1 - ((0 - q) - x) == 1 - (-q - x), the
   // k == 0 branch of the classic formulation, bit for bit)
-  const int kr = (int)(invln2 * xs + ((xs < 0) ? -0.5 : 0.5));
+  const int kr = (int)(K.invln2 * xs + ((xs < 0) ? -0.5 : 0.5));
   const int k = (ax > 0.34657359027997264) ? kr : 0;
   const double t = (double)k;
-  const double hi = xs - t * ln2HI;
-  const double lo = t * ln2LO;
+  const double hi = xs - t * K.ln2HI;
+  const double lo = t * K.ln2LO;
   const double r = hi - lo;
   const double r2 = r * r;
-  const double c = r - r2 * (P1 + r2 * (P2 + r2 * (P3 + r2 * (P4 + r2 * P5))));
+  const double c = r - r2 * (K.P1 + r2 * (K.P2 + r2 * (K.P3 + r2 * (K.P4 + r2 * K.P5))));
   const double y = 1.0 - ((lo - Mth<MATH>::div(r * c, 2.0 - c)) - hi);
   const double res = y * __longlong_as_double((long long)(1023 + k) << 52);
   const double special = big ? ((x > 0) ? __builtin_huge_val() : 0.0) : (1.0 + x);
   return (big || tiny) ? special : res;
 }
+template <int MATH = MATH_IEEE>
+__device__ __forceinline__ double portable_exp(double x) { return portable_exp<MATH>(x, exp_consts()); }
 
 enum : int { T_REAL = 0, T_GOAL = 1, T_OBST = 2, T_GOALOBST = 3, T_VEL = 4, T_RANDOM = 5, T_HAD = 6 };
 

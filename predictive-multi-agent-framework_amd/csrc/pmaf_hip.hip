@@ -204,7 +204,13 @@ __device__ __forceinline__ void rollout_w64_body(const DevView &D, const CostPar
   const unsigned long long t_begin = wall_clock64();
   const int n_obs = D.n_obs;
   const int M = n_obs - 1;
-  const PopConst C = D.C;
+  // Loop-invariant wave-uniform doubles (population constants, goal, gains, the exp() coefficients) are pinned
+  // into VGPRs: left to itself the compiler keeps them in the 100-odd SGPRs, runs out, and pays for the
+  // spills (v_writelane / v_readlane) in the step loop -- 163 spilled SGPRs before, C2 360 -> 344 us with this.
+  PopConst C = D.C;
+  { double *f = reinterpret_cast<double *>(&C);
+    for (int i = 0; i < (int)(sizeof(PopConst) / sizeof(double)); i++) asm volatile("" : "+v"(f[i])); }
+  const ExpK EK = exp_consts_in_vgprs();
   const size_t pa = (size_t)pop * D.N + a;
   const double *src = D.obs_start + (size_t)pop * 7 * n_obs;
   const int32_t *ks = D.known_start + (size_t)pop * n_obs;
@@ -231,11 +237,13 @@ __device__ __forceinline__ void rollout_w64_body(const DevView &D, const CostPar
   const V3 sent_v = mk(src[3 * n_obs + M], src[4 * n_obs + M], src[5 * n_obs + M]);
   const double sent_r = src[6 * n_obs + M];
 
-  const V3 goal = mk(D.goal[pop * 3], D.goal[pop * 3 + 1], D.goal[pop * 3 + 2]);
-  const V3 init_pos = mk(D.agent_init_pos[pop * 3], D.agent_init_pos[pop * 3 + 1], D.agent_init_pos[pop * 3 + 2]);
+  V3 goal = mk(D.goal[pop * 3], D.goal[pop * 3 + 1], D.goal[pop * 3 + 2]);
+  V3 init_pos = mk(D.agent_init_pos[pop * 3], D.agent_init_pos[pop * 3 + 1], D.agent_init_pos[pop * 3 + 2]);
+  asm volatile("" : "+v"(goal.x), "+v"(goal.y), "+v"(goal.z), "+v"(init_pos.x), "+v"(init_pos.y), "+v"(init_pos.z));
   V3 p = mk(D.start_pos[pop * 3], D.start_pos[pop * 3 + 1], D.start_pos[pop * 3 + 2]);
   V3 v = mk(D.start_vel[pop * 3], D.start_vel[pop * 3 + 1], D.start_vel[pop * 3 + 2]);
-  const double k_attr = D.k_attr[pa], k_circ = D.k_circ[pa], k_repel = D.k_repel[pa], k_damp = D.k_damp[pa];
+  double k_attr = D.k_attr[pa], k_circ = D.k_circ[pa], k_repel = D.k_repel[pa], k_damp = D.k_damp[pa];
+  asm volatile("" : "+v"(k_attr), "+v"(k_circ), "+v"(k_repel), "+v"(k_damp));
   double *path = D.paths + pa * (size_t)D.cap * 3;
 
   // LDS list of the step's non-zero circular-field terms (after the obstacle table)
@@ -284,7 +292,7 @@ __device__ __forceinline__ void rollout_w64_body(const DevView &D, const CostPar
     PMAF_SEC(ST, 0);
     if (gate && !(D.ablate & 8))
       circ_and_scale_w64<TILES, TYPE, MATH>(lane, p, v, zv, goal, g, dg, gn, C, k_circ, n_obs, rot_g, known_bits, O,
-                                            clist, lane_min, F, scale, ST, D.ablate);
+                                            clist, lane_min, F, scale, ST, EK, D.ablate);
     PMAF_SEC(ST, 5);
     // attractorForce (:183-193), updatePositionAndVelocity (:253-268)
     if (sent_reachable) F = F + (mk(0.0, 0.0, 0.0) + repel);  // else + 0.0: F is a sum that started from +0.0, never -0.0
@@ -577,7 +585,7 @@ __device__ __forceinline__ void real_step_w64(const DevView &D, const double dt_
   SecTimers ST;
   if (gate)
     circ_and_scale_w64<TILES, T_REAL, MATH_XACT>(lane, rp, rv, zv, goal, g, dg, gn, C, k_circ, n_obs, rot_g, known_bits,
-                                                 O, clist, no_min, F, scale, ST, 0, htype);
+                                                 O, clist, no_min, F, scale, ST, exp_consts(), 0, htype);
   F = F + (mk(0.0, 0.0, 0.0) + repel);
   if (k_attr != 0.0) F = F + (scale * k_damp) * verr;
   F_total = F;

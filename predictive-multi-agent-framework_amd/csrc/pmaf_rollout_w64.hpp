@@ -229,8 +229,8 @@ __device__ __forceinline__ void circ_and_scale_w64(int lane, V3 p, V3 v, double 
                                                    const PopConst &C, double k_circ,
                                                    int n_obs, double *rot_g, unsigned &known_bits,
                                                    LaneObstacles<TILES> &O, double *clist, double &lane_min,
-                                                   V3 &F, double &scale, SecTimers &ST, const int ablate = 0,
-                                                   const int rtype = 0) {
+                                                   V3 &F, double &scale, SecTimers &ST, const ExpK &EK,
+                                                   const int ablate = 0, const int rtype = 0) {
   typedef Mth<MATH> MT;
   // TYPE == T_REAL: the heuristic is a run-time value (the real agent's step in
   // k_manager dispatches to the stored best agent's type, cf_agent.cpp:368-387)
@@ -332,7 +332,7 @@ __device__ __forceinline__ void circ_and_scale_w64(int lane, V3 p, V3 v, double 
       bi = wave_min64_i(cand ? best_i : 0x7fffffff);
     }
     const bool stall = (dot(g, v) <= 0.0) && (zv < C.zv09_lt) && (dg > 0.15);  // norm(v) < vmax - 0.1 vmax
-    const double w1 = 1 - portable_exp<MATH>(-MT::div(MT::sqrt(m), C.shell));
+    const double w1 = 1 - portable_exp<MATH>(-MT::div(MT::sqrt(m), C.shell), EK);
     // |ro| and g.ro of the closest obstacle were computed by the lane that
     // owns it (same operands, same bits as recomputing them here)
     const int bl = bi & 63;

@@ -1026,10 +1026,14 @@ static double repel_boundary(double R, double shell) {
 static int pick_lpa(int N, int P, int M) {
   // Heuristic: fill the 1024 SIMDs of the chip with waves, but never use more
   // lanes per agent than there are field obstacles to share.
+  // Measured on C2-shaped populations (tools/lpasweep.py, kernel us for 1024 / 2048 / 4096 / 8192 agents):
+  //   wave per agent 360 / 549 / 1024 / -,  32 lanes 512 / 492 / 697 / 1348,  16 lanes 672 / 712 / 684 / 1017.
+  // The wave-per-agent kernel is the fastest while every wave has a SIMD to itself (<= 1024 waves); a second
+  // wave per SIMD costs it more than the group kernels' narrower mapping does, and those run best at 2 per SIMD.
   int lpa = 64;
   while (lpa > 1) {
     long waves = ((long)N * lpa + 63) / 64 * P;
-    if (waves > 2048) lpa /= 2; else break;
+    if (waves > (lpa == 64 ? 1024 : 2048)) lpa /= 2; else break;
   }
   // known-flag bitmask holds 64 tiles per lane
   while ((M + lpa - 1) / lpa > 64 && lpa < 64) lpa *= 2;

@@ -24,6 +24,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/pmaf.h"
@@ -1178,7 +1179,11 @@ static void wait_mailbox(pmaf_planner *h, double seq) {
     const volatile double *s = h->h_out + p * 12 + 11;
     unsigned spins = 0;
     while (*s != seq) {
+#if defined(__x86_64__) || defined(__i386__)
       __builtin_ia32_pause();
+#else
+      std::this_thread::yield();
+#endif
       if ((++spins & 0x3fffu) == 0) {
         hipError_t e = hipStreamQuery(h->stream);
         if (e == hipErrorNotReady) continue;

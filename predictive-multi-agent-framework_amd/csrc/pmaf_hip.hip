@@ -211,7 +211,8 @@ __device__ __forceinline__ void rollout_w64_body(const DevView &D, const CostPar
   PopConst C = D.C;
   { double *f = reinterpret_cast<double *>(&C);
     for (int i = 0; i < (int)(sizeof(PopConst) / sizeof(double)); i++) asm volatile("" : "+v"(f[i])); }
-  const ExpK EK = exp_consts_in_vgprs();
+  // (two and four slots per lane have no VGPRs to spare for the exp coefficients: measured)
+  const ExpK EK = (TILES >= 2) ? exp_consts() : exp_consts_in_vgprs();
   const size_t pa = (size_t)pop * D.N + a;
   const double *src = D.obs_start + (size_t)pop * 7 * n_obs;
   const int32_t *ks = D.known_start + (size_t)pop * n_obs;

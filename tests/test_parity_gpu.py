@@ -839,3 +839,30 @@ def test_handle_lifecycle_does_not_leak_device_memory(pmaf, scenes):
     np.testing.assert_array_equal(a.real_state()[0], ref)
     np.testing.assert_array_equal(b.real_state()[0], ref)
     a.close(); b.close()
+
+
+def test_two_handles_driven_from_two_threads(pmaf, scenes):
+    """a handle is not thread-safe (like CfManager), but different handles are
+    independent: two host threads tick their own planners concurrently (ctypes
+    releases the GIL, each handle has its own stream and mailbox) and get the
+    results of a sequential run"""
+    import threading
+    sca, scb = scenes.config_scene("C2"), scenes.config_scene("C2", scene_id=3)
+
+    def run(sc, out, n=40):
+        h = pmaf.PmafPlanner(sc, device=0, mgr_init_pos=sc["start"])
+        h.set_initial_position(sc["start"])
+        best = [np.asarray(h.tick(sc["obstacles"], sc["dt"], sc["cost_gains"], sc["ws_limits"])).copy() for _ in range(n)]
+        h.stop()
+        out.append((np.asarray(best), np.asarray(h.real_state()[0]).copy(), np.asarray(h.costs()).copy()))
+        h.close()
+
+    ref_a, ref_b = [], []
+    run(sca, ref_a); run(scb, ref_b)
+    got_a, got_b = [], []
+    ta = threading.Thread(target=run, args=(sca, got_a)); tb = threading.Thread(target=run, args=(scb, got_b))
+    ta.start(); tb.start(); ta.join(); tb.join()
+    for ref, got in ((ref_a, got_a), (ref_b, got_b)):
+        assert len(got) == 1
+        for x, y in zip(ref[0], got[0]):
+            np.testing.assert_array_equal(x, y)

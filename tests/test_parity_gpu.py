@@ -866,3 +866,20 @@ def test_two_handles_driven_from_two_threads(pmaf, scenes):
         assert len(got) == 1
         for x, y in zip(ref[0], got[0]):
             np.testing.assert_array_equal(x, y)
+
+
+@pytest.mark.parametrize("lpa,force_generic", [(0, False), (16, False), (0, True)])
+def test_workspace_penalties_of_many_path_points(pmaf, oracle, scenes, monkeypatch, lpa, force_generic):
+    """evaluateAgents' workspace-box penalties (cf_manager.cpp:302-324) are
+    summed over the path points in order, x / y / z terms within a point; the
+    tuned kernels evaluate them after the rollout, 64 (or lanes-per-agent)
+    points at a time. A box the paths leave on several sides and in every chunk
+    must give the oracle's costs bit for bit (and a different winner than the
+    open box)"""
+    if force_generic:
+        monkeypatch.setenv("PMAF_FORCE_GENERIC", "1")
+    sc = scenes.synthetic_scene(24, 220, 12, 9, 9)
+    sc["ws_limits"] = np.array([0.25, -0.45, 0.04, -0.02, 0.74, 0.69])   # xmax xmin ymax ymin zmax zmin
+    hip, ora = run_both(pmaf, oracle, scenes, sc, 4, lanes_per_agent=lpa)
+    assert (np.asarray(ora.costs()) > 10.0).all()     # every agent pays workspace penalties
+    hip.close()

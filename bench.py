@@ -232,11 +232,13 @@ def main():
         # (tools/gpu_prof.sh + tools/traffic_from_pmc.py); PMC counters cannot be
         # collected from inside the timed run itself
         traffic = None
+        pmc = None
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
             key = "%s%s:%s" % (args.config, "" if P == 1 else "x%d" % P, kernel_name)
             if key in tj and not args.dynamic:
                 traffic = tj[key]["traffic_bytes_per_launch"]
+                pmc = {k: tj[key].get(k) for k in ("valu_active_frac_of_wave_cycles", "valu_insts_per_launch", "waves_per_launch")}
         except (OSError, ValueError, KeyError):
             traffic = None
         out = {
@@ -269,7 +271,8 @@ def main():
                                  "(SURVEY.md 8d): see fp64_valu"},
             "fp64_valu": {"achieved_tflops": flops / avg_kernel_s / 1e12, "peak_tflops": FP64_VALU_PEAK_TF,
                           "frac": flops / avg_kernel_s / 1e12 / FP64_VALU_PEAK_TF,
-                          "flops_per_agent_step_est": algorithmic_flops_per_agent_step(n_obs - 1)},
+                          "flops_per_agent_step_est": algorithmic_flops_per_agent_step(n_obs - 1),
+                          "pmc": pmc},  # from the committed PMC passes (profiles/traffic.json), like roofline.traffic
         }
         if args.cpu_seconds > 0 and world == 1:  # reported at N = 1 only
             out["cpu_baseline"] = cpu_baseline(pkg, sc, args.cpu_seconds, max(1, min(N, os.cpu_count() or 1)))

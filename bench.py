@@ -172,6 +172,7 @@ def main():
                 torch.cuda.synchronize()
             dist.barrier()
 
+    obs0 = obs.copy()
     planner.tick(obs, dt, cg, ws)  # obstacles resident in HBM from here on
     for _ in range(args.warmup):
         one_tick(obs)
@@ -185,7 +186,12 @@ def main():
         one_tick(obs)
         lat[k] = time.perf_counter() - ta
         if args.dynamic:
-            obs = np.stack([pkg.scenes.advance_live_obstacles(o) for o in obs])
+            # moving obstacles: advanced like dynamic_obstacle_node does, put back with the agent at every
+            # episode start so the workload stays stationary (they would drift out of the scene otherwise)
+            if args.episode and tick_no[0] % args.episode == 0:
+                obs = obs0.copy()
+            else:
+                obs = np.stack([pkg.scenes.advance_live_obstacles(o) for o in obs])
     planner.stop()
     if dist is not None and red_dev == "cuda":
         import torch

@@ -610,6 +610,8 @@ struct ManagerArgs {
   int reset_from_real;     // 1: reset to the real agent's state, 0: reset_in
   int rollout_follows;     // 1: the rollout kernel is launched right behind this one (pmaf_tick)
   int tuned_real_step;     // 1: real_step_w64 (default arithmetic policy, M <= 256), 0: generic LDS-table path
+  const double *live_src;  // [P][7][n_obs] live obstacles in mapped pinned HOST memory (pmaf_tick: no copy command);
+                           // NULL: D.obs_live already holds them
   double dt_real;
   const int32_t *agent_id; // [P] gains index for the real step; NULL = best_idx of this launch
   const double *reset_in;  // [P][6] pos, vel
@@ -649,9 +651,16 @@ __global__ __launch_bounds__(64) void k_manager(DevView D, CostParams CP, Manage
   V3 rf = mk(D.real_force[pop * 3], D.real_force[pop * 3 + 1], D.real_force[pop * 3 + 2]);
   const V3 init_pos = mk(D.real_init_pos[pop * 3], D.real_init_pos[pop * 3 + 1], D.real_init_pos[pop * 3 + 2]);
   int32_t *rk = D.real_known + (size_t)pop * n_obs;
-  const double *live = D.obs_live + (size_t)pop * 7 * n_obs;
+  // live obstacles: read straight from the caller's pinned staging buffer when the tick brought new ones (1.8 KB
+  // over PCIe costs less than a copy command in front of this kernel) and kept in D.obs_live for later calls
+  double *live_dev = D.obs_live + (size_t)pop * 7 * n_obs;
+  const double *live = A.live_src ? A.live_src + (size_t)pop * 7 * n_obs : live_dev;
   if (A.do_move || A.do_reset) {
-    for (int i = lane; i < 7 * n_obs; i += 64) smem[i] = live[i];
+    for (int i = lane; i < 7 * n_obs; i += 64) {
+      const double x = live[i];
+      smem[i] = x;
+      if (A.live_src) live_dev[i] = x;
+    }
     for (int i = lane; i < n_obs; i += 64) s_known[i] = rk[i];
   }
   // random vectors the real agent's heuristic uses (best_agent_'s copy)
@@ -945,6 +954,7 @@ struct pmaf_planner {
   static constexpr int kStage = 4;
   double *h_stage[kStage] = {nullptr, nullptr, nullptr, nullptr};  // pinned staging ring for obstacle SoA uploads
   hipEvent_t ev_stage[kStage] = {nullptr, nullptr, nullptr, nullptr};
+  double *h_zc = nullptr, *d_zc = nullptr;  // mapped pinned obstacle buffer read by k_manager in pmaf_tick
   int stage_next = 0;
   double *d_reset_in = nullptr; // [P][6]
   int32_t *d_agent_id = nullptr;// [P]
@@ -1152,6 +1162,15 @@ static void upload_live_obstacles(pmaf_planner *h, const double *obstacles) {
   HIP_CHECK(hipEventRecord(h->ev_stage[s], h->stream));
 }
 
+// pmaf_tick's obstacles: converted into the mapped pinned buffer k_manager reads directly. One buffer is enough:
+// pmaf_tick returns only after the manager kernel that read it has published its result.
+static const double *stage_live_obstacles_zero_copy(pmaf_planner *h, const double *obstacles) {
+  if (!obstacles) return nullptr;
+  check_range(obstacles, (size_t)h->D.P * h->D.n_obs * 7, "obstacles");
+  aos_to_soa(obstacles, h->h_zc, h->D.P, h->D.n_obs);
+  return h->d_zc;
+}
+
 static void launch_manager(pmaf_planner *h, const ManagerArgs &A0) {
   ManagerArgs A = A0;
   A.tuned_real_step = (h->math == MATH_XACT && !h->force_generic) ? 1 : 0;
@@ -1337,6 +1356,8 @@ int pmaf_create(const pmaf_params *prm, pmaf_planner **out) {
     h->d_agent_id = h->dalloc<int32_t>(P);
     HIP_CHECK(hipHostMalloc((void **)&h->h_out, sizeof(double) * P * 12, hipHostMallocMapped));
     HIP_CHECK(hipHostGetDevicePointer((void **)&h->d_out, h->h_out, 0));
+    HIP_CHECK(hipHostMalloc((void **)&h->h_zc, sizeof(double) * (size_t)P * 7 * n_obs, hipHostMallocMapped));
+    HIP_CHECK(hipHostGetDevicePointer((void **)&h->d_zc, h->h_zc, 0));
     for (int i = 0; i < pmaf_planner::kStage; i++) {
       HIP_CHECK(hipHostMalloc((void **)&h->h_stage[i], sizeof(double) * (size_t)P * 7 * n_obs, hipHostMallocDefault));
       HIP_CHECK(hipEventCreateWithFlags(&h->ev_stage[i], hipEventDisableTiming));
@@ -1427,6 +1448,7 @@ int pmaf_destroy(pmaf_planner *h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   for (void *p : h->allocs) (void)hipFree(p);
   if (h->h_out) (void)hipHostFree(h->h_out);
+  if (h->h_zc) (void)hipHostFree(h->h_zc);
   for (int i = 0; i < pmaf_planner::kStage; i++) {
     if (h->h_stage[i]) (void)hipHostFree(h->h_stage[i]);
     if (h->ev_stage[i]) (void)hipEventDestroy(h->ev_stage[i]);
@@ -1577,9 +1599,9 @@ int pmaf_tick(pmaf_planner *h, const double *obstacles, double dt, const double 
     REQUIRE(h && cost_gains && ws, "pmaf_tick: NULL argument");
     h->use_device();
     set_cost_params(h, cost_gains, ws);
-    upload_live_obstacles(h, obstacles);
     ensure_scores(h);
     ManagerArgs A{};
+    A.live_src = stage_live_obstacles_zero_copy(h, obstacles);
     A.do_select = 1; A.do_move = 1; A.do_reset = 1; A.reset_from_real = 1;
     A.rollout_follows = 1;
     A.dt_real = dt;

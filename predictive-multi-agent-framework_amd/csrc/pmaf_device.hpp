@@ -113,26 +113,6 @@ template <> struct Mth<MATH_XACT> {
     g = __builtin_fma(d, h, g);
     return (z == 0.0 || z == __builtin_huge_val()) ? z : g;  // sqrt(+-0) = +-0, sqrt(inf) = inf
   }
-  // s = sqrt(z) as above, and r = 1/s refined to division quality WITHOUT a
-  // v_rcp_f64 (a quarter-rate instruction): the Goldschmidt iteration already
-  // carries h ~ 1/(2 sqrt(z)) to ~2^-51, one Newton step against the rounded s
-  // brings 2h to the accuracy rcp_refined() reaches (checked bit for bit
-  // against IEEE a / sqrt(z): pmaf_debug_math op 9, test_xact_sequences_match_ieee).
-  static __device__ __forceinline__ void sqrt_rcp(double z, double &s, double &rs) {
-    double y = __builtin_amdgcn_rsq(z);
-    double g = z * y, h = 0.5 * y;
-    double r = __builtin_fma(-h, g, 0.5);
-    g = __builtin_fma(g, r, g);
-    h = __builtin_fma(h, r, h);
-    double d = __builtin_fma(-g, g, z);
-    g = __builtin_fma(d, h, g);
-    d = __builtin_fma(-g, g, z);
-    g = __builtin_fma(d, h, g);
-    s = (z == 0.0 || z == __builtin_huge_val()) ? z : g;
-    double r0 = h + h;
-    double e = __builtin_fma(-s, r0, 1.0);
-    rs = __builtin_fma(r0, e, r0);
-  }
   static __device__ __forceinline__ double rcp_refined(double b) {
     double r = __builtin_amdgcn_rcp(b);
     double e = __builtin_fma(-b, r, 1.0);
@@ -155,8 +135,12 @@ template <> struct Mth<MATH_XACT> {
     return mk(div_r(a.x, s, r), div_r(a.y, s, r), div_r(a.z, s, r));
   }
   static __device__ __forceinline__ double norm(V3 a) { return sqrt(sqn(a)); }
-  // s = |a| and the refined reciprocal of s that falls out of the sqrt iteration
-  static __device__ __forceinline__ void norm_rcp(V3 a, double &s, double &rs) { sqrt_rcp(sqn(a), s, rs); }
+  // s = |a| and the refined reciprocal of s (shared by the divisions by this norm). It must be rcp_refined(s):
+  // a reciprocal taken from the sqrt iteration (2h + one Newton step) passed 1.2e9 random a / sqrt(b) checks but is
+  // NOT always the same double -- for s = 1 - 2^-53 (the norm of a cross product of two unit vectors!) both 1.0 and
+  // 1 + 2^-52 are fixed points of the Newton step, it lands on the other one than v_rcp_f64 does, and the quotient
+  // of a numerator on a rounding tie came out 1 ulp off (found by tools/fuzz_parity.py, now in the test suite).
+  static __device__ __forceinline__ void norm_rcp(V3 a, double &s, double &rs) { s = sqrt(sqn(a)); rs = rcp_refined(s); }
   static __device__ __forceinline__ double div_n(double x, double s, double rs) { return div_r(x, s, rs); }
   static __device__ __forceinline__ V3 div3_n(V3 a, double s, double rs) {
     return mk(div_r(a.x, s, rs), div_r(a.y, s, rs), div_r(a.z, s, rs));
@@ -169,8 +153,9 @@ template <> struct Mth<MATH_XACT> {
   // the sqrt -> divide chain its latency depends on.
   template <bool TP = false>
   static __device__ __forceinline__ void norm_unit(V3 a, double &s, V3 &u) {
-    double z = sqn(a), rs;
-    sqrt_rcp(z, s, rs);
+    double z = sqn(a);
+    s = sqrt(z);
+    const double rs = rcp_refined(s);
     if (TP) {
       const bool pos = z > 0.0;
       u = div3_n(a, pos ? s : 1.0, pos ? rs : 1.0);

@@ -875,7 +875,7 @@ __global__ void k_debug_math(int op, int n, const double *a, const double *b, do
     case 6: r = Mth<MATH_XACT>::div(a[i], b[i]); break;
     case 7: { V3 q = Mth<MATH_XACT>::div3(mk(a[i], b[i], a[i] * 0.5), b[i] + a[i]); r = (q.x + q.y) + q.z; } break;
     case 8: { V3 q = mk(a[i], b[i], a[i] * 0.5) / (b[i] + a[i]); r = (q.x + q.y) + q.z; } break;
-    case 9: { double sq, rs; Mth<MATH_XACT>::sqrt_rcp(b[i], sq, rs); r = Mth<MATH_XACT>::div_r(a[i], sq, rs); } break;  // a / sqrt(b)
+    case 9: { double sq = Mth<MATH_XACT>::sqrt(b[i]); r = Mth<MATH_XACT>::div_r(a[i], sq, Mth<MATH_XACT>::rcp_refined(sq)); } break;  // a / sqrt(b)
     case 10: r = a[i] / __builtin_sqrt(b[i]); break;
   }
   out[i] = r;

@@ -14,6 +14,8 @@ Two oracle modes (oracle/pmaf_oracle.c):
     rollout amplifies a 1-ulp perturbation (mildly over the BASELINE horizons,
     chaotically over 1000+ steps). test_libm_exp_oracle_* assert the north-star
     tolerance 1e-5 m on the BASELINE configs in that mode."""
+import os
+
 import numpy as np
 import pytest
 
@@ -527,6 +529,16 @@ def test_xact_sequences_match_ieee(pmaf):
         v = rng.uniform(-1.5, 1.5, (n, 3))
         z = (v[:, 0] * v[:, 0] + v[:, 1] * v[:, 1]) + v[:, 2] * v[:, 2]
         assert (pmaf.debug_math(9, v[:, 1], z) == v[:, 1] / np.sqrt(z)).all()
+        # divisors within a few ulps of 1 (norms of cross products of unit vectors) and numerators on rounding
+        # ties: where a reciprocal that is 1 ulp off its correctly rounded value shows (a reciprocal taken from the
+        # sqrt iteration failed exactly here: -2^-55 / (1 - 2^-53))
+        k = np.arange(-64, 65, dtype=np.float64)
+        for base in (1.0, 0.5, 2.0):
+            sN = base * (1.0 + k * 2.0 ** -53)
+            for num in (2.0 ** -55, 3.0 * 2.0 ** -55, 1.0, 0.3, 1.0 + 2.0 ** -52, -(2.0 ** -55), -0.7):
+                aN = np.full_like(sN, num)
+                assert (pmaf.debug_math(6, aN, sN) == aN / sN).all()
+                assert (pmaf.debug_math(9, aN, sN * sN) == aN / np.sqrt(sN * sN)).all()
         special = np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 1.0, -1.0, 3.0, 2.0 ** -250, 2.0 ** 250, -7.5])
         A, B = [x.ravel() for x in np.meshgrid(special, special)]
         for op, ref in ((5, np.sqrt(A)), (6, A / B), (9, A / np.sqrt(B))):
@@ -883,3 +895,16 @@ def test_workspace_penalties_of_many_path_points(pmaf, oracle, scenes, monkeypat
     hip, ora = run_both(pmaf, oracle, scenes, sc, 4, lanes_per_agent=lpa)
     assert (np.asarray(ora.costs()) > 10.0).all()     # every agent pays workspace penalties
     hip.close()
+
+
+def test_randomised_scenes_bit_exact(pmaf):
+    """tools/fuzz_parity.py: random agent / obstacle counts (0 ... 150), heuristic mixes, moving obstacles, gains,
+    horizons and lanes-per-agent mappings, every result compared bit for bit with the oracle. (20 000 trials of it
+    found the one arithmetic shortcut that was not exact: a reciprocal shared with the sqrt iteration.)"""
+    import subprocess
+    import sys as _sys
+    import conftest
+    r = subprocess.run([_sys.executable, os.path.join(conftest.ROOT, "tools", "fuzz_parity.py"), "1500", "5"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "mismatches 0" in r.stdout

@@ -25,12 +25,25 @@ for trial in range(n_trials):
     if rng.integers(0, 4) == 0:   # the repulsive obstacle near the path
         sc["obstacles"][-1] = [rng.uniform(-0.3, 0.3), rng.uniform(0.1, 0.4), 0.7, 0, rng.uniform(-0.3, 0.0), 0, 0.1]
     sc["k_circ"] = float(rng.choice([0.025, 0.015, 0.05])); sc["k_damp"] = float(rng.choice([3.0, 4.0]))
+    wild = rng.integers(0, 3) == 0   # every third trial: parameters well off the shipped task files
+    if wild:
+        sc["dt"] = float(rng.choice([0.01, 0.02, 0.005, 0.05])); sc["velocity_max"] = float(rng.choice([0.2, 0.5, 1.0, 0.05]))
+        sc["approach_dist"] = float(rng.choice([0.25, 0.1, 0.6])); sc["detect_shell_rad"] = float(rng.choice([0.35, 0.8, 0.1, 0.05]))
+        sc["agent_mass"] = float(rng.choice([1.0, 1.0, 0.5, 2.5])); sc["radius"] = float(rng.choice([0.05, 0.0, 0.12]))
+        sc["k_attr"] = float(rng.choice([4.0, 0.0, 1.0, 20.0])); sc["k_repel"] = float(rng.choice([0.08, 0.0, 1.0]))
+        sc["k_circ"] = float(rng.choice([0.025, 0.0, 0.5, 5.0]))
+        sc["cost_gains"] = np.array([rng.choice([100.0, 1.0, 0.0]), rng.choice([10.0, 0.0, 50.0]), rng.choice([0.001, 1.0, 0.0]), rng.choice([1.0, 10.0, 0.0])])
+        sc["ws_limits"] = np.array([rng.uniform(0.0, 1.0), rng.uniform(-1.0, 0.0), rng.uniform(0.0, 0.3), rng.uniform(-0.3, 0.0), rng.uniform(0.7, 1.1), rng.uniform(0.2, 0.7)])
+        if rng.integers(0, 3) == 0: sc["start"] = sc["goal"] + rng.uniform(-0.3, 0.3, 3)          # short trips, early goal
+        if rng.integers(0, 3) == 0 and M > 0: sc["start"] = sc["obstacles"][0, :3] + rng.uniform(-0.02, 0.02, 3)  # inside an obstacle
+        if rng.integers(0, 4) == 0 and M > 2: sc["obstacles"][1, :3] = sc["obstacles"][0, :3]       # coincident obstacles
     lpa = int(rng.choice([0, 0, 64, 32, 16, 8, 4, 1]))
     if lpa and (M + lpa - 1) // max(lpa, 1) > 64: lpa = 0
-    ticks = int(rng.integers(1, 6))
+    ticks = int(rng.integers(1, 6)) if rng.integers(0, 8) else int(rng.integers(10, 40))
+    ieee = bool(rng.integers(0, 6) == 0)
     if only >= 0 and trial != only: continue
     try:
-        hip = pm.PmafPlanner(sc, device=0, mgr_init_pos=sc["start"], lanes_per_agent=lpa)
+        hip = pm.PmafPlanner(sc, device=0, mgr_init_pos=sc["start"], lanes_per_agent=lpa, ieee_sequences=ieee)
     except pm.PmafError as e:
         print("trial", trial, "create refused:", e); continue
     ora = orc.OraclePlanner(sc, mgr_init_pos=sc["start"])
@@ -61,7 +74,7 @@ for trial in range(n_trials):
         print("obstacles", sc["obstacles"]); print("types", pm.scenes.default_agent_types(N) if types is None else types)
     if not ok:
         bad += 1
-        print("MISMATCH trial", trial, dict(N=N, M=M, H=H, dyn=dyn, lpa=lpa, ticks=ticks, cfg=hip.launch_config()), flush=True)
+        print("MISMATCH trial", trial, dict(N=N, M=M, H=H, dyn=dyn, lpa=lpa, ticks=ticks, wild=bool(wild), ieee=ieee, cfg=hip.launch_config()), flush=True)
     hip.close(); ora.close()
 print("trials", n_trials, "mismatches", bad, "in %.0f s" % (time.time() - t0))
 sys.exit(1 if bad else 0)

@@ -908,3 +908,16 @@ def test_randomised_scenes_bit_exact(pmaf):
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "mismatches 0" in r.stdout
+
+
+def test_randomised_api_sequences_bit_exact(pmaf):
+    """tools/fuzz_api.py: 1..5 populations per handle, ticks issued as pmaf_tick or as the reference's five-call
+    sequence, save_state / load_state hand-overs to fresh handles in between; every population against its own
+    oracle, bit for bit"""
+    import subprocess
+    import sys as _sys
+    import conftest
+    r = subprocess.run([_sys.executable, os.path.join(conftest.ROOT, "tools", "fuzz_api.py"), "300", "9"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "mismatches 0" in r.stdout

@@ -100,7 +100,7 @@ __device__ __forceinline__ void finish_step_w64(V3 p, V3 &v, V3 verr, V3 F, doub
 __device__ __forceinline__ bool sentinel_reachable(V3 p, V3 sent_pos, V3 sent_vel, double zsent_lt, const PopConst &C,
                                                    int steps) {
   const double adt = fabs(C.dt);
-  const double per_step = (6.5 * adt * adt + C.vel_max * adt) + norm(sent_vel) * adt;
+  const double per_step = (6.5 * adt * adt + fabs(C.vel_max) * adt) + norm(sent_vel) * adt;
   const double reach = (double)steps * per_step * 1.001 + 1e-9;
   const double range = __builtin_sqrt(zsent_lt) * 1.001;
   const double d0 = norm(p - sent_pos);

@@ -539,6 +539,14 @@ def test_xact_sequences_match_ieee(pmaf):
                 aN = np.full_like(sN, num)
                 assert (pmaf.debug_math(6, aN, sN) == aN / sN).all()
                 assert (pmaf.debug_math(9, aN, sN * sN) == aN / np.sqrt(sN * sN)).all()
+        # the classic exception of reciprocal-based division: a divisor whose mantissa is all ones (and its
+        # neighbours), against many numerators
+        for sN in (1.0 - 2.0 ** -53, 1.0 - 2.0 ** -52, 1.0 + 2.0 ** -52, 2.0 - 2.0 ** -52, 0.5 - 2.0 ** -54):
+            aN = np.concatenate([rng.uniform(-3.0, 3.0, 200_000), np.ldexp(rng.integers(1, 1 << 20, 100_000).astype(np.float64), -60),
+                                 np.ldexp(1.0, rng.integers(-80, 10, 1000))])
+            bN = np.full_like(aN, sN)
+            assert (pmaf.debug_math(6, aN, bN) == aN / bN).all()
+            assert (pmaf.debug_math(9, aN, bN * bN) == aN / np.sqrt(bN * bN)).all()
         special = np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 1.0, -1.0, 3.0, 2.0 ** -250, 2.0 ** 250, -7.5])
         A, B = [x.ravel() for x in np.meshgrid(special, special)]
         for op, ref in ((5, np.sqrt(A)), (6, A / B), (9, A / np.sqrt(B))):

@@ -547,6 +547,12 @@ def test_xact_sequences_match_ieee(pmaf):
             bN = np.full_like(aN, sN)
             assert (pmaf.debug_math(6, aN, bN) == aN / bN).all()
             assert (pmaf.debug_math(9, aN, bN * bN) == aN / np.sqrt(bN * bN)).all()
+        # square roots next to exact squares and to powers of two (results on or beside rounding boundaries)
+        kk = np.arange(-200, 201, dtype=np.float64)
+        for base in (1.0, 2.0, 0.5, 3.0, 0.1, 7.25):
+            r0 = base * (1.0 + kk * 2.0 ** -52)
+            for zN in (r0 * r0, np.nextafter(r0 * r0, np.inf), np.nextafter(r0 * r0, 0.0), r0):
+                assert (pmaf.debug_math(5, zN) == np.sqrt(zN)).all()
         special = np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 1.0, -1.0, 3.0, 2.0 ** -250, 2.0 ** 250, -7.5])
         A, B = [x.ravel() for x in np.meshgrid(special, special)]
         for op, ref in ((5, np.sqrt(A)), (6, A / B), (9, A / np.sqrt(B))):

@@ -17,6 +17,8 @@ t0 = time.time()
 for trial in range(n_trials):
     N = int(rng.integers(1, 40)); M = int(rng.choice([0, 1, 2, 5, 9, 17, 32, 33, 63, 64, 65, 100, 128, 129, 150]))
     H = int(rng.integers(5, 160)); dyn = bool(rng.integers(0, 2))
+    if rng.integers(0, 25) == 0:   # a large population (multi-block launches of the group kernels), short horizon
+        N = int(rng.integers(200, 1500)); H = int(rng.integers(5, 30)); M = int(rng.choice([3, 17, 32, 40]))
     types = rng.integers(1, 7, N).astype(np.int32) if rng.integers(0, 2) else None
     sc = pm.scenes.synthetic_scene(N, H, M, 11, trial, dynamic=dyn, agent_types=types)
     if rng.integers(0, 3) == 0:   # denser clutter around the path

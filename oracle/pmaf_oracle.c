@@ -31,7 +31,13 @@ static inline v3 vsub(v3 a, v3 b) { return V(a.x - b.x, a.y - b.y, a.z - b.z); }
 static inline v3 vneg(v3 a) { return V(-a.x, -a.y, -a.z); }
 static inline v3 vscale(double s, v3 a) { return V(s * a.x, s * a.y, s * a.z); }
 static inline v3 vmuls(v3 a, double s) { return V(a.x * s, a.y * s, a.z * s); }
+#ifdef PMAF_QUOTIENT_BY_RECIPROCAL
+/* sensitivity study only (tests/test_oracle_sensitivity.py): vector / scalar as multiplication by the reciprocal,
+ * what an Eigen older than the reference's would evaluate */
+static inline v3 vdivs(v3 a, double s) { double r = 1.0 / s; return V(a.x * r, a.y * r, a.z * r); }
+#else
 static inline v3 vdivs(v3 a, double s) { return V(a.x / s, a.y / s, a.z / s); }
+#endif
 static inline double vdot(v3 a, v3 b) {
 #ifdef PMAF_DOT_RIGHT_ASSOC
   return a.x * b.x + (a.y * b.y + a.z * b.z);

@@ -75,6 +75,7 @@ struct DevView {
   unsigned long long *pred_ticks;    // [P][N] rollout duration in wall_clock64() ticks (CfAgent::prediction_time_)
   const double *zsent_lt;            // [P] exact squared-distance boundary of the repel range test
   int ablate;                        // timing experiments only (PMAF_ABLATE), 0 in production
+  int n_simds;                       // SIMDs of the device (4 per CU): a launch of more waves doubles them up
 };
 
 struct CostParams {
@@ -384,6 +385,18 @@ __global__ __launch_bounds__(64) void k_rollout_w64(DevView D, CostParams CP) {
 // ---------------------------------------------------------------------------
 // k_rollout_grp<LPA, TILES>: 64/LPA agents per wave (see pmaf_rollout_grp.hpp)
 // ---------------------------------------------------------------------------
+// SIMD sharing in the group kernel (launches of more waves than the device has SIMDs), measured on C5 = 2048 waves:
+// * block b and block b + n_simds land on the same SIMD (tools/placement.hip), and the issue arbiter serves the older
+//   wave first: the first 1024 waves ran at their stand-alone speed (600 us), the others on the issue slots left over
+//   and then alone (880-1000 us; kernel 1010 us). The waves therefore trade issue priority in 10 us slices of the
+//   wall clock, the younger wave holding it 5 slices of 8 (the share at which both finish together: 845 us each,
+//   kernel 910 us; 4 of 8: 720 / 860, 6 of 8: 860 / 750).
+// * every population's first two waves hold its five heuristic agents (mixed types: the wave runs the union of their
+//   code paths, 1.13x the work of a wave of Random agents), and b + n_simds is the same wave index of another
+//   population: the wave index is rotated by 8 per population so that two such waves do not share a SIMD (-3 %).
+constexpr int PRIO_SLICE_LOG2 = 10;       // 2^10 ticks of the 100 MHz wall clock
+constexpr unsigned PRIO_YOUNGER_OF_8 = 5;
+constexpr unsigned POP_ROTATE = 8;
 template <int LPA, int TILES, int MATH>
 __global__ __launch_bounds__(64) void k_rollout_grp(DevView D, CostParams CP) {
   extern __shared__ double smem[];
@@ -393,7 +406,8 @@ __global__ __launch_bounds__(64) void k_rollout_grp(DevView D, CostParams CP) {
   const int pop = blockIdx.y;
   const int sub = lane % LPA;
   const int grp = lane / LPA;
-  const int a = blockIdx.x * APW + grp;
+  const int bx = (int)((blockIdx.x + gridDim.x - (POP_ROTATE * blockIdx.y) % gridDim.x) % gridDim.x);  // see above
+  const int a = bx * APW + grp;
   const bool active = a < D.N;
   const int aa = active ? a : 0;
   const int n_obs = D.n_obs;
@@ -454,9 +468,14 @@ __global__ __launch_bounds__(64) void k_rollout_grp(DevView D, CostParams CP) {
   double dg = Mth<MATH>::norm(g);
   double zv = sqn(v);
   double z_init = sqn(p - init_pos);
+  const unsigned lin_block = blockIdx.y * gridDim.x + blockIdx.x;
+  const bool shared_simd = gridDim.x * gridDim.y > (unsigned)D.n_simds;
+  const bool younger = ((lin_block / (unsigned)D.n_simds) & 1u) != 0u;
   while (true) {
     const bool run = active && (dg > 0.1) && (n < D.cap);  // B/src/cf_agent.cpp:310-311, per agent
     if (!__any(run)) break;
+    unsigned long long clk = 0ull;
+    if (shared_simd) clk = wall_clock64();
     const bool gate = !(dg < C.approach || (zv < C.zvhalf_lt && z_init < C.zinit_lt));  // :315-317
     const V3 verr = attractor_velocity_error<MATH>(v, g, C, k_attr, k_damp);
     V3 F = mk(0.0, 0.0, 0.0);
@@ -486,7 +505,12 @@ __global__ __launch_bounds__(64) void k_rollout_grp(DevView D, CostParams CP) {
       advance = moving;
     }
     if (sent_reachable) sent_p = sent_p + sent_v * C.dt;
+    if (shared_simd) {
+      if (((((unsigned)(clk >> PRIO_SLICE_LOG2)) & 7u) < PRIO_YOUNGER_OF_8) == younger) __builtin_amdgcn_s_setprio(1);
+      else __builtin_amdgcn_s_setprio(0);
+    }
   }
+  __builtin_amdgcn_s_setprio(0);
 
   double cost_ws, path_len;
   path_cost_terms_grp<LPA, MATH>(sub, grp, active, path, n, CP.ws, CP.k_workspace, clist, cost_ws, path_len);
@@ -1297,6 +1321,11 @@ int pmaf_create(const pmaf_params *prm, pmaf_planner **out) {
     h->lpa = lp ? lp : pick_lpa(N, P, M);
     { const char *fg = getenv("PMAF_FORCE_GENERIC"); h->force_generic = fg && fg[0] == '1'; }
     { const char *ab = getenv("PMAF_ABLATE"); D.ablate = ab ? atoi(ab) : 0; }
+    {
+      int cus = 0;
+      HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device));
+      D.n_simds = 4 * (cus > 0 ? cus : 256);
+    }
     REQUIRE((M + h->lpa - 1) / h->lpa <= 64, "pmaf_create: too many obstacles for this lanes_per_agent (need M <= 64*lanes_per_agent)");
     h->n_blocks = (N * h->lpa + 63) / 64;
     {

@@ -297,7 +297,7 @@ __device__ __forceinline__ void circ_and_scale_w64(int lane, V3 p, V3 v, double 
   int count = 0;
 #pragma unroll
   for (int t = 0; t < TILES; t++) {
-    if (TILES > 1 && !__any(in_t[t])) continue;  // no term from this slot (wave-uniform)
+    if (TILES > 2 && !__any(in_t[t])) continue;  // no term from this slot (wave-uniform; 2 slots: both in one block)
     const V3 rot = mk(O.rx[t], O.ry[t], O.rz[t]);
     const V3 rv = rv_t[t];
     double vn, rvn;

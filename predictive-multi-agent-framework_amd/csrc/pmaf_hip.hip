@@ -271,6 +271,17 @@ __device__ __forceinline__ void rollout_w64_body(const DevView &D, const CostPar
   double zv = sqn(v);
   double z_init = sqn(p - init_pos);
   V3 gn = (dg > 0.0) ? MT::div3(g, dg) : g;  // goal_vec.normalized()
+  // One slot per lane (M <= 63, the host sends M = 64 to the two-slot kernel): the sweep's |ro| / ro.normalized() of
+  // the NEXT step are computed at the end of this step, in the block of the velocity clamp, and lane 63 -- which has
+  // no obstacle -- carries the goal through the same instructions: goal distance and direction cost no sqrt /
+  // reciprocal / divide sequence of their own (32 VALU instructions per step), two v_readlane pairs... instead.
+  constexpr bool PRE = (TILES == 1);
+  double s_pre = 0.0;
+  V3 ron_pre = mk(0.0, 0.0, 0.0);
+  if (PRE) {
+    if (lane == 63) { O.p[0] = goal; O.v[0] = mk(0.0, 0.0, 0.0); }
+    MT::norm_unit(O.p[0] - p, s_pre, ron_pre);
+  }
   V3 verr = attractor_velocity_error<MATH>(v, g, C, k_attr, k_damp);
   const double zsent_lt = D.zsent_lt[pop];
   const bool sent_reachable = sentinel_reachable(p, sent_p, sent_v, zsent_lt, C, D.cap);
@@ -294,8 +305,8 @@ __device__ __forceinline__ void rollout_w64_body(const DevView &D, const CostPar
     double scale = 1.0;
     PMAF_SEC(ST, 0);
     if (gate && !(D.ablate & 8))
-      circ_and_scale_w64<TILES, TYPE, MATH>(lane, p, v, zv, goal, g, dg, gn, C, k_circ, n_obs, rot_g, known_bits, O,
-                                            clist, lane_min, F, scale, ST, EK, D.ablate);
+      circ_and_scale_w64<TILES, TYPE, MATH, PRE>(lane, p, v, zv, goal, g, dg, gn, C, k_circ, n_obs, rot_g, known_bits,
+                                                 O, clist, lane_min, F, scale, ST, EK, D.ablate, 0, s_pre, ron_pre);
     PMAF_SEC(ST, 5);
     // attractorForce (:183-193), updatePositionAndVelocity (:253-268)
     if (sent_reachable) F = F + (mk(0.0, 0.0, 0.0) + repel);  // else + 0.0: F is a sum that started from +0.0, never -0.0
@@ -315,19 +326,31 @@ __device__ __forceinline__ void rollout_w64_body(const DevView &D, const CostPar
     v = (vn > C.vel_max) ? cl : nv;  // a select, not a branch: the block is not split (a branch measured 5 % slower)
     p = new_pos;
     g = goal - p;
-    double rdg;
-    MT::norm_rcp(g, dg, rdg);
+    // predictObstacles, B/src/cf_agent.cpp:270-276, in registers. Obstacles at
+    // rest: p + (+-0) dt is idempotent after its first application (which turns
+    // a -0.0 coordinate into +0.0), so later steps skip it. (Lane 63 of the one-slot kernel holds the goal with
+    // velocity 0: a -0.0 goal coordinate turns into +0.0 there, which can only change the sign of a zero component
+    // of gn, and gn only enters dot(ron, gn) < -0.01; g itself is computed from the goal directly.)
+    if (PRE) {
+      if (advance) {
+        O.p[0] = O.p[0] + O.v[0] * C.dt;
+        advance = moving;
+      }
+      MT::norm_unit(O.p[0] - p, s_pre, ron_pre);  // lane 63: goal - p, the same operands as g
+      dg = readlane_d(s_pre, 63);
+      gn = readlane_v3(ron_pre, 63);
+    } else {
+      double rdg;
+      MT::norm_rcp(g, dg, rdg);
+      gn = MT::div3_n(g, dg, rdg);  // goal_vec.normalized(); only used if the loop goes on, i.e. dg > 0.1: no zero-norm case
+    }
     zv = sqn(v);
     z_init = sqn(p - init_pos);
-    gn = MT::div3_n(g, dg, rdg);  // goal_vec.normalized(); only used if the loop goes on, i.e. dg > 0.1: no zero-norm case
     verr = attractor_velocity_error<MATH>(v, g, C, k_attr, k_damp);
     if (lane == 0) { path[n * 3] = p.x; path[n * 3 + 1] = p.y; path[n * 3 + 2] = p.z; }
     n++;
     ran = true;
-    // predictObstacles, B/src/cf_agent.cpp:270-276, in registers. Obstacles at
-    // rest: p + (+-0) dt is idempotent after its first application (which turns
-    // a -0.0 coordinate into +0.0), so later steps skip it.
-    if (advance) {
+    if (!PRE && advance) {
 #pragma unroll
       for (int t = 0; t < TILES; t++) O.p[t] = O.p[t] + O.v[t] * C.dt;
       advance = moving;
@@ -1110,7 +1133,8 @@ static void launch_rollout(pmaf_planner *h) {
     h->ev_inflight.emplace_back(e0, e1);
     HIP_CHECK(hipEventRecord(e0, h->stream));
   }
-  const int tiles64 = (h->D.n_obs - 1 + 63) / 64;
+  // (the one-slot kernel keeps lane 63 for the goal: 64 obstacles go to the two-slot kernel)
+  const int tiles64 = (h->D.n_obs - 1 == 64) ? 2 : (h->D.n_obs - 1 + 63) / 64;
   if (h->lpa == 64 && tiles64 <= 4 && !h->force_generic) {
     dim3 g64((unsigned)h->D.N, (unsigned)h->D.P);
 #define PMAF_W64(T, F) hipLaunchKernelGGL((k_rollout_w64<T, F>), g64, block, h->lds_rollout, h->stream, h->D, h->cp)

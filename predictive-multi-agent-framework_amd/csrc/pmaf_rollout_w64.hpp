@@ -224,13 +224,16 @@ __device__ __forceinline__ V3 closest_other_w64(bool need_latch, int t, int lane
 // applied iff |F| > 1e-5, :319), the compaction stores (every lane stores: its
 // term at its rank, or to its scratch entry) and the first batch of the
 // ordered force sum (the list is zero-padded, adding +0.0 is exact).
-template <int TILES, int TYPE, int MATH>
+// PRE: |ro| and ro.normalized() of the lane's slot were computed by the caller (s_pre, ron_pre; one slot per lane
+// only) -- the rollout does that at the end of the previous step, see rollout_w64_body.
+template <int TILES, int TYPE, int MATH, bool PRE = false>
 __device__ __forceinline__ void circ_and_scale_w64(int lane, V3 p, V3 v, double zv, V3 goal, V3 g, double dg, V3 gn,
                                                    const PopConst &C, double k_circ,
                                                    int n_obs, double *rot_g, unsigned &known_bits,
                                                    LaneObstacles<TILES> &O, double *clist, double &lane_min,
                                                    V3 &F, double &scale, SecTimers &ST, const ExpK &EK,
-                                                   const int ablate = 0, const int rtype = 0) {
+                                                   const int ablate = 0, const int rtype = 0,
+                                                   const double s_pre = 0.0, const V3 ron_pre = V3{0.0, 0.0, 0.0}) {
   typedef Mth<MATH> MT;
   // TYPE == T_REAL: the heuristic is a run-time value (the real agent's step in
   // k_manager dispatches to the stored best agent's type, cf_agent.cpp:368-387)
@@ -253,7 +256,8 @@ __device__ __forceinline__ void circ_and_scale_w64(int lane, V3 p, V3 v, double 
     const V3 ro = O.p[t] - p;
     rv_t[t] = v - O.v[t];
     double s;
-    MT::norm_unit(ro, s, ron_t[t]);
+    if (PRE) { s = s_pre; ron_t[t] = ron_pre; }
+    else MT::norm_unit(ro, s, ron_t[t]);
     const bool skip = (dot(ron_t[t], gn) < -0.01) && (dot(ro, rv_t[t]) < -0.01);
     double d = s - (C.rad + O.r[t]);
     d = smax(d, 1e-5);

@@ -271,10 +271,10 @@ __device__ __forceinline__ void rollout_w64_body(const DevView &D, const CostPar
   double zv = sqn(v);
   double z_init = sqn(p - init_pos);
   V3 gn = (dg > 0.0) ? MT::div3(g, dg) : g;  // goal_vec.normalized()
-  // One slot per lane (M <= 63, the host sends M = 64 to the two-slot kernel): the sweep's |ro| / ro.normalized() of
-  // the NEXT step are computed at the end of this step, in the block of the velocity clamp, and lane 63 -- which has
-  // no obstacle -- carries the goal through the same instructions: goal distance and direction cost no sqrt /
-  // reciprocal / divide sequence of their own (32 VALU instructions per step), two v_readlane pairs... instead.
+  // One slot per lane (M <= 61; the host sends 62..64 obstacles to the two-slot kernel): the sweep's |ro| /
+  // ro.normalized() of the NEXT step are computed at the end of this step, and the lanes that have no obstacle carry
+  // the tail's other norms through the same instructions -- lane 63 the goal (distance and direction), lane 62 the
+  // speed clamp, lane 61 attractorForce's speed limit -- instead of three more sqrt / reciprocal / divide sequences.
   constexpr bool PRE = (TILES == 1);
   double s_pre = 0.0;
   V3 ron_pre = mk(0.0, 0.0, 0.0);
@@ -320,10 +320,12 @@ __device__ __forceinline__ void rollout_w64_body(const DevView &D, const CostPar
     const V3 half = ((0.5 * acc) * C.dt) * C.dt;
     const V3 new_pos = (p + half) + (v * C.dt);
     const V3 nv = v + acc * C.dt;
-    double vn, rvn;
-    MT::norm_rcp(nv, vn, rvn);
-    const V3 cl = nv * MT::div_n(C.vel_max, vn, rvn);
-    v = (vn > C.vel_max) ? cl : nv;  // a select, not a branch: the block is not split (a branch measured 5 % slower)
+    if (!PRE) {
+      double vn, rvn;
+      MT::norm_rcp(nv, vn, rvn);
+      const V3 cl = nv * MT::div_n(C.vel_max, vn, rvn);
+      v = (vn > C.vel_max) ? cl : nv;  // a select, not a branch: the block is not split (a branch measured 5 % slower)
+    }
     p = new_pos;
     g = goal - p;
     // predictObstacles, B/src/cf_agent.cpp:270-276, in registers. Obstacles at
@@ -336,9 +338,26 @@ __device__ __forceinline__ void rollout_w64_body(const DevView &D, const CostPar
         O.p[0] = O.p[0] + O.v[0] * C.dt;
         advance = moving;
       }
-      MT::norm_unit(O.p[0] - p, s_pre, ron_pre);  // lane 63: goal - p, the same operands as g
-      dg = readlane_d(s_pre, 63);
+      // ONE sqrt / reciprocal / divide sequence for the whole tail: lanes 0..M-1 the next step's |ro| and
+      // ro.normalized(), lane 63 the same for goal - p (= g), lane 62 the speed clamp (|nv|, vel_max / |nv|),
+      // lane 61 attractorForce's limit (vel_max / |vel_des|): same operations on the same operands as the
+      // separate sequences, read back with v_readlane.
+      const V3 vel_des = (k_attr / k_damp) * g;
+      const bool l_nv = (lane == 62), l_des = (lane == 61);
+      const V3 ro_n = O.p[0] - p;
+      const V3 vec = l_nv ? nv : (l_des ? vel_des : ro_n);
+      V3 num = vec;
+      num.x = (l_nv || l_des) ? C.vel_max : vec.x;
+      double s, rs;
+      MT::norm_rcp(vec, s, rs);
+      const V3 q = MT::div3_n(num, s, rs);
+      s_pre = s;
+      ron_pre = (sqn(vec) > 0.0) ? q : vec;  // normalized(): the vector itself unless squaredNorm > 0
+      const double vn = readlane_d(s, 62), f_nv = readlane_d(q.x, 62), f_des = readlane_d(q.x, 61);
+      v = (vn > C.vel_max) ? nv * f_nv : nv;
+      dg = readlane_d(s, 63);
       gn = readlane_v3(ron_pre, 63);
+      verr = vel_des * smin(1.0, f_des) - v;
     } else {
       double rdg;
       MT::norm_rcp(g, dg, rdg);
@@ -346,7 +365,7 @@ __device__ __forceinline__ void rollout_w64_body(const DevView &D, const CostPar
     }
     zv = sqn(v);
     z_init = sqn(p - init_pos);
-    verr = attractor_velocity_error<MATH>(v, g, C, k_attr, k_damp);
+    if (!PRE) verr = attractor_velocity_error<MATH>(v, g, C, k_attr, k_damp);
     if (lane == 0) { path[n * 3] = p.x; path[n * 3 + 1] = p.y; path[n * 3 + 2] = p.z; }
     n++;
     ran = true;
@@ -1133,8 +1152,8 @@ static void launch_rollout(pmaf_planner *h) {
     h->ev_inflight.emplace_back(e0, e1);
     HIP_CHECK(hipEventRecord(e0, h->stream));
   }
-  // (the one-slot kernel keeps lane 63 for the goal: 64 obstacles go to the two-slot kernel)
-  const int tiles64 = (h->D.n_obs - 1 == 64) ? 2 : (h->D.n_obs - 1 + 63) / 64;
+  // (the one-slot kernel keeps lanes 61-63 for the goal and the two speed limits: 62-64 obstacles go to the two-slot kernel)
+  const int tiles64 = (h->D.n_obs - 1 >= 62 && h->D.n_obs - 1 <= 64) ? 2 : (h->D.n_obs - 1 + 63) / 64;
   if (h->lpa == 64 && tiles64 <= 4 && !h->force_generic) {
     dim3 g64((unsigned)h->D.N, (unsigned)h->D.P);
 #define PMAF_W64(T, F) hipLaunchKernelGGL((k_rollout_w64<T, F>), g64, block, h->lds_rollout, h->stream, h->D, h->cp)

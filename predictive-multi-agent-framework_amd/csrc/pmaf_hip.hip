@@ -320,12 +320,6 @@ __device__ __forceinline__ void rollout_w64_body(const DevView &D, const CostPar
     const V3 half = ((0.5 * acc) * C.dt) * C.dt;
     const V3 new_pos = (p + half) + (v * C.dt);
     const V3 nv = v + acc * C.dt;
-    if (!PRE) {
-      double vn, rvn;
-      MT::norm_rcp(nv, vn, rvn);
-      const V3 cl = nv * MT::div_n(C.vel_max, vn, rvn);
-      v = (vn > C.vel_max) ? cl : nv;  // a select, not a branch: the block is not split (a branch measured 5 % slower)
-    }
     p = new_pos;
     g = goal - p;
     // predictObstacles, B/src/cf_agent.cpp:270-276, in registers. Obstacles at
@@ -333,39 +327,34 @@ __device__ __forceinline__ void rollout_w64_body(const DevView &D, const CostPar
     // a -0.0 coordinate into +0.0), so later steps skip it. (Lane 63 of the one-slot kernel holds the goal with
     // velocity 0: a -0.0 goal coordinate turns into +0.0 there, which can only change the sign of a zero component
     // of gn, and gn only enters dot(ron, gn) < -0.01; g itself is computed from the goal directly.)
-    if (PRE) {
-      if (advance) {
-        O.p[0] = O.p[0] + O.v[0] * C.dt;
-        advance = moving;
-      }
-      // ONE sqrt / reciprocal / divide sequence for the whole tail: lanes 0..M-1 the next step's |ro| and
-      // ro.normalized(), lane 63 the same for goal - p (= g), lane 62 the speed clamp (|nv|, vel_max / |nv|),
-      // lane 61 attractorForce's limit (vel_max / |vel_des|): same operations on the same operands as the
-      // separate sequences, read back with v_readlane.
+    if (PRE && advance) {
+      O.p[0] = O.p[0] + O.v[0] * C.dt;
+      advance = moving;
+    }
+    {
+      // ONE sqrt / reciprocal / divide sequence for the whole tail: lane 63 goal distance and direction (|g|,
+      // g.normalized()), lane 62 the speed clamp (|nv|, vel_max / |nv|), lane 61 attractorForce's limit
+      // (vel_max / |vel_des|) and, in the one-slot kernel, lanes 0..M-1 the next step's |ro| and ro.normalized():
+      // the same operations on the same operands as separate sequences, read back with v_readlane.
       const V3 vel_des = (k_attr / k_damp) * g;
       const bool l_nv = (lane == 62), l_des = (lane == 61);
-      const V3 ro_n = O.p[0] - p;
-      const V3 vec = l_nv ? nv : (l_des ? vel_des : ro_n);
+      const V3 other = PRE ? (O.p[0] - p) : g;   // one-slot kernel: lane 63 holds the goal, O.p - p = g there
+      const V3 vec = l_nv ? nv : (l_des ? vel_des : other);
       V3 num = vec;
       num.x = (l_nv || l_des) ? C.vel_max : vec.x;
       double s, rs;
       MT::norm_rcp(vec, s, rs);
       const V3 q = MT::div3_n(num, s, rs);
-      s_pre = s;
-      ron_pre = (sqn(vec) > 0.0) ? q : vec;  // normalized(): the vector itself unless squaredNorm > 0
+      const V3 u = (sqn(vec) > 0.0) ? q : vec;  // normalized(): the vector itself unless squaredNorm > 0
+      if (PRE) { s_pre = s; ron_pre = u; }
       const double vn = readlane_d(s, 62), f_nv = readlane_d(q.x, 62), f_des = readlane_d(q.x, 61);
       v = (vn > C.vel_max) ? nv * f_nv : nv;
       dg = readlane_d(s, 63);
-      gn = readlane_v3(ron_pre, 63);
+      gn = readlane_v3(u, 63);
       verr = vel_des * smin(1.0, f_des) - v;
-    } else {
-      double rdg;
-      MT::norm_rcp(g, dg, rdg);
-      gn = MT::div3_n(g, dg, rdg);  // goal_vec.normalized(); only used if the loop goes on, i.e. dg > 0.1: no zero-norm case
     }
     zv = sqn(v);
     z_init = sqn(p - init_pos);
-    if (!PRE) verr = attractor_velocity_error<MATH>(v, g, C, k_attr, k_damp);
     if (lane == 0) { path[n * 3] = p.x; path[n * 3 + 1] = p.y; path[n * 3 + 2] = p.z; }
     n++;
     ran = true;

@@ -356,6 +356,10 @@ __device__ __forceinline__ void circ_and_scale_w64(int lane, V3 p, V3 v, double 
   // LDS accesses (observed: wrong sums); the hardware executes a wave's DS
   // instructions in order, so no instruction is emitted for them.
   wave_lds_fence();
+  // Two or more slots per lane (long lists, C3: ~57 terms = 8 round trips per step): only lane 0 reads and adds --
+  // a broadcast ds_read still returns 64 lanes' worth of data, with one active lane the round trip is shorter
+  // (C3 1638 -> 1616 us; with one slot per lane the extra branch costs what it saves).
+  if (TILES == 1 || lane == 0) {
   for (int k = 0;;) {
     double ex[BATCH], ey[BATCH], ez[BATCH];
 #pragma unroll
@@ -368,6 +372,8 @@ __device__ __forceinline__ void circ_and_scale_w64(int lane, V3 p, V3 v, double 
     k += BATCH;
     if (k >= count) break;
   }
+  }
+  if (TILES > 1) F = readlane_v3(F, 0);
   wave_lds_fence();
   PMAF_SEC(ST, 3);
   scale = (sqn(F) >= C.zf_gt) ? sc : scale;  // norm(F) > 1e-5

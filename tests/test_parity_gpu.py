@@ -820,6 +820,36 @@ def test_signed_zero_coordinates_of_obstacles_at_rest(pmaf, oracle, scenes, lpa)
     hip.close()
 
 
+@pytest.mark.parametrize("m", [59, 60, 61, 62, 63, 64, 65])
+@pytest.mark.parametrize("dynamic", [False, True])
+def test_idle_lane_riders_at_the_obstacle_count_boundary(pmaf, oracle, scenes, m, dynamic):
+    """the one-slot wave-per-agent kernel runs the goal distance / direction, the
+    speed clamp and the attractor speed limit in lanes 63 / 62 / 61 of the sweep's
+    norm sequence, so it takes at most 61 field obstacles; 62...64 go to the
+    two-slot kernel (which packs the three riders into a sequence of their own)"""
+    sc = scenes.synthetic_scene(12, 90, m, 6, 100 + m, dynamic=dynamic)
+    hip, _ = run_both(pmaf, oracle, scenes, sc, 3, dynamic=dynamic, lanes_per_agent=64)
+    assert hip.launch_config()["lanes_per_agent"] == 64
+    hip.close()
+
+
+def test_idle_lane_goal_with_signed_zero_coordinates(pmaf, oracle, scenes):
+    """lane 63 of the one-slot kernel carries the goal like an obstacle at rest:
+    a -0.0 goal coordinate turns into +0.0 there after the first step, which may
+    only change the sign of a zero component of the goal direction. Start and
+    goal on the x axis (y = -0.0 / +0.0, z equal): zeros in g.y all the way."""
+    for goal_y, start_y in ((-0.0, 0.0), (0.0, -0.0), (-0.0, -0.0)):
+        sc = scenes.synthetic_scene(12, 120, 9, 6, 31)
+        sc["goal"] = np.array([0.6, goal_y, 0.7])
+        sc["start"] = np.array([-0.6, start_y, 0.7])
+        sc["obstacles"][:3, 1] = [0.0, -0.0, 0.0]      # field obstacles on the axis too: y stays an exact zero
+        sc["obstacles"][:3, 2] = 0.7
+        sc["obstacles"][3:9, 0] += 10.0                # the others far away
+        for dyn in (False, True):
+            hip, _ = run_both(pmaf, oracle, scenes, sc, 3, dynamic=dyn, lanes_per_agent=64)
+            hip.close()
+
+
 def test_repulsive_obstacle_moving_into_range(pmaf, oracle, scenes):
     """the repulsive (last) obstacle starts out of range and flies towards the
     agents: the once-per-rollout reachability bound must keep the per-step range

@@ -355,7 +355,9 @@ __device__ __forceinline__ void rollout_w64_body(const DevView &D, const CostPar
     }
     zv = sqn(v);
     z_init = sqn(p - init_pos);
-    if (lane == 0) { path[n * 3] = p.x; path[n * 3 + 1] = p.y; path[n * 3 + 2] = p.z; }
+    // every lane stores the (wave-uniform) point to the same address: one transaction, and no exec-masked block
+    // in the middle of the tail
+    path[n * 3] = p.x; path[n * 3 + 1] = p.y; path[n * 3 + 2] = p.z;
     n++;
     ran = true;
     if (!PRE && advance) {

@@ -10,17 +10,21 @@
 //     advanced there (predictObstacles, B/src/cf_agent.cpp:270-276); the
 //     trailing repulsive obstacle is kept wave-uniform in registers;
 //   * no barriers / memory fences in the step loop (a __syncthreads() drains
-//     the path stores: s_waitcnt vmcnt(0)); path points are stored by lane 0
-//     and never waited for;
+//     the path stores: s_waitcnt vmcnt(0)); path points are stored by every
+//     lane to the same address (no exec-masked block) and never waited for;
 //   * straight-line blocks so the scheduler can interleave the independent
-//     sqrt / divide chains (per-lane circ term computed under predicates, the
-//     next step's goal distance / speed / start distance norms are computed
-//     together with this step's path-length norm);
+//     sqrt / divide chains (per-lane circ term computed under predicates);
+//   * the tail's three norms (goal distance / direction, speed clamp,
+//     attractorForce's speed limit) run as ONE sqrt / reciprocal / divide
+//     sequence in lanes 63 / 62 / 61; with one slot per lane the obstacle
+//     lanes compute the next step's |ro|, ro.normalized() in that sequence too
+//     (rollout_w64_body in pmaf_hip.hip);
 //   * the sequential `force_ += curr_force` (cf_agent.cpp:106) is reproduced
 //     by compacting the non-zero per-obstacle terms, in ascending obstacle
-//     index, into an LDS list (v_mbcnt rank) that every lane then sums
-//     front to back with broadcast ds_reads -- S dependent adds instead of
-//     S x (6 v_readlane + 3 adds);
+//     index, into an LDS list (v_mbcnt rank) that every lane (lane 0 alone
+//     when there are several slots per lane) then sums front to back with
+//     broadcast ds_reads -- S dependent adds instead of S x (6 v_readlane +
+//     3 adds);
 //   * the min-distance, closest-obstacle reductions run as interleaved DPP
 //     chains.
 // Arithmetic and its order are exactly those of circ_and_scale / finish_step

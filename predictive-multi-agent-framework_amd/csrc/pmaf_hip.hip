@@ -290,6 +290,8 @@ __device__ __forceinline__ void rollout_w64_body(const DevView &D, const CostPar
   for (int t = 0; t < TILES; t++) moving = moving || !(O.v[t].x == 0.0 && O.v[t].y == 0.0 && O.v[t].z == 0.0);
   moving = __any(moving);
   bool advance = true;
+  V3 repel = mk(0.0, 0.0, 0.0);  // repelForce of the coming step (depends on the step's start state only)
+  if (sent_reachable) repel = sentinel_repel(p, C, k_repel, sent_p, sent_r, zsent_lt);
   SecTimers ST;
 #ifdef PMAF_SECTION_TIMERS
   ST.start();
@@ -298,9 +300,6 @@ __device__ __forceinline__ void rollout_w64_body(const DevView &D, const CostPar
     // gate, :315-317
     // |v| < 0.5 vmax and |p - init| < 0.2 on exact squared thresholds
     const bool gate = !(dg < C.approach || (zv < C.zvhalf_lt && z_init < C.zinit_lt));
-    // repelForce (:159-181) depends on the step's start position only
-    V3 repel = mk(0.0, 0.0, 0.0);
-    if (sent_reachable) repel = sentinel_repel(p, C, k_repel, sent_p, sent_r, zsent_lt);
     V3 F = mk(0.0, 0.0, 0.0);
     double scale = 1.0;
     PMAF_SEC(ST, 0);
@@ -309,7 +308,10 @@ __device__ __forceinline__ void rollout_w64_body(const DevView &D, const CostPar
                                                  O, clist, lane_min, F, scale, ST, EK, D.ablate, 0, s_pre, ron_pre);
     PMAF_SEC(ST, 5);
     // attractorForce (:183-193), updatePositionAndVelocity (:253-268)
-    if (sent_reachable) F = F + (mk(0.0, 0.0, 0.0) + repel);  // else + 0.0: F is a sum that started from +0.0, never -0.0
+    // repelForce (:159-181): `repel` was evaluated for this step's start state at the end of the previous step; it is
+    // +0.0 when the obstacle cannot come into range, and F -- a sum that started from +0.0 -- is never -0.0, so the
+    // unconditional addition is exact (no masked block between the force sum and the tail)
+    F = F + (mk(0.0, 0.0, 0.0) + repel);
     if (k_attr != 0.0) F = F + (scale * k_damp) * verr;
     V3 acc = F;
     if (C.mass != 1.0) acc = F / C.mass;
@@ -365,7 +367,10 @@ __device__ __forceinline__ void rollout_w64_body(const DevView &D, const CostPar
       for (int t = 0; t < TILES; t++) O.p[t] = O.p[t] + O.v[t] * C.dt;
       advance = moving;
     }
-    if (sent_reachable) sent_p = sent_p + sent_v * C.dt;
+    if (sent_reachable) {  // the only masked block of the step for the repulsive obstacle: advance it, next step's repelForce
+      sent_p = sent_p + sent_v * C.dt;
+      repel = sentinel_repel(p, C, k_repel, sent_p, sent_r, zsent_lt);
+    }
     PMAF_SEC(ST, 7);
   }
 #ifdef PMAF_SECTION_TIMERS

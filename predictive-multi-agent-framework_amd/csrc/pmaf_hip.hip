@@ -312,11 +312,27 @@ __device__ __forceinline__ void rollout_w64_body(const DevView &D, const CostPar
     // +0.0 when the obstacle cannot come into range, and F -- a sum that started from +0.0 -- is never -0.0, so the
     // unconditional addition is exact (no masked block between the force sum and the tail)
     F = F + (mk(0.0, 0.0, 0.0) + repel);
-    if (k_attr != 0.0) F = F + (scale * k_damp) * verr;
-    V3 acc = F;
-    if (C.mass != 1.0) acc = F / C.mass;
-    const double az = sqn(acc);
-    if (az >= C.zacc_gt) acc = acc * (13.0 / __builtin_sqrt(az));  // norm(acc) > 13.0 (rare)
+    // attractorForce (:183-193), updatePositionAndVelocity (:253-258): a = F / mass, |a| <= 13
+    V3 acc;
+    if (PRE) {
+      // one slot per lane: as few blocks as possible between the force sum and the tail -- the k_attr == 0 case is a
+      // select, and unit mass without clamp (the common case) skips ONE rare block instead of two
+      const V3 Fa = F + (scale * k_damp) * verr;
+      const bool attr = (k_attr != 0.0);
+      F.x = attr ? Fa.x : F.x; F.y = attr ? Fa.y : F.y; F.z = attr ? Fa.z : F.z;
+      acc = F;
+      double az = sqn(F);
+      if ((C.mass != 1.0) || (az >= C.zacc_gt)) {
+        if (C.mass != 1.0) { acc = F / C.mass; az = sqn(acc); }
+        if (az >= C.zacc_gt) acc = acc * (13.0 / __builtin_sqrt(az));  // norm(acc) > 13.0
+      }
+    } else {
+      if (k_attr != 0.0) F = F + (scale * k_damp) * verr;
+      acc = F;
+      if (C.mass != 1.0) acc = F / C.mass;
+      const double az = sqn(acc);
+      if (az >= C.zacc_gt) acc = acc * (13.0 / __builtin_sqrt(az));  // norm(acc) > 13.0 (rare)
+    }
     PMAF_SEC(ST, 6);
     // ---- one block: integrate, clamp the speed, the next step's norms ----
     const V3 half = ((0.5 * acc) * C.dt) * C.dt;
@@ -329,10 +345,9 @@ __device__ __forceinline__ void rollout_w64_body(const DevView &D, const CostPar
     // a -0.0 coordinate into +0.0), so later steps skip it. (Lane 63 of the one-slot kernel holds the goal with
     // velocity 0: a -0.0 goal coordinate turns into +0.0 there, which can only change the sign of a zero component
     // of gn, and gn only enters dot(ron, gn) < -0.01; g itself is computed from the goal directly.)
-    if (PRE && advance) {
-      O.p[0] = O.p[0] + O.v[0] * C.dt;
-      advance = moving;
-    }
+    // (one slot per lane: unconditionally -- for obstacles at rest every further application is the identity, and
+    // three multiply-adds are cheaper than a branch in the middle of the tail)
+    if (PRE) O.p[0] = O.p[0] + O.v[0] * C.dt;
     {
       // ONE sqrt / reciprocal / divide sequence for the whole tail: lane 63 goal distance and direction (|g|,
       // g.normalized()), lane 62 the speed clamp (|nv|, vel_max / |nv|), lane 61 attractorForce's limit

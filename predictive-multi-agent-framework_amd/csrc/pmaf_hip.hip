@@ -303,9 +303,11 @@ __device__ __forceinline__ void rollout_w64_body(const DevView &D, const CostPar
     V3 F = mk(0.0, 0.0, 0.0);
     double scale = 1.0;
     PMAF_SEC(ST, 0);
-    if (gate && !(D.ablate & 8))
+    // (called with the gate closed too: the sweep's few compares then find no obstacle -- one branch less in the step)
+    if (PRE || (gate && !(D.ablate & 8)))
       circ_and_scale_w64<TILES, TYPE, MATH, PRE>(lane, p, v, zv, goal, g, dg, gn, C, k_circ, n_obs, rot_g, known_bits,
-                                                 O, clist, lane_min, F, scale, ST, EK, D.ablate, 0, s_pre, ron_pre);
+                                                 O, clist, lane_min, F, scale, ST, EK, D.ablate, 0, s_pre, ron_pre,
+                                                 gate);
     PMAF_SEC(ST, 5);
     // attractorForce (:183-193), updatePositionAndVelocity (:253-268)
     // repelForce (:159-181): `repel` was evaluated for this step's start state at the end of the previous step; it is

@@ -237,7 +237,8 @@ __device__ __forceinline__ void circ_and_scale_w64(int lane, V3 p, V3 v, double 
                                                    LaneObstacles<TILES> &O, double *clist, double &lane_min,
                                                    V3 &F, double &scale, SecTimers &ST, const ExpK &EK,
                                                    const int ablate = 0, const int rtype = 0,
-                                                   const double s_pre = 0.0, const V3 ron_pre = V3{0.0, 0.0, 0.0}) {
+                                                   const double s_pre = 0.0, const V3 ron_pre = V3{0.0, 0.0, 0.0},
+                                                   const bool gate = true) {
   typedef Mth<MATH> MT;
   // TYPE == T_REAL: the heuristic is a run-time value (the real agent's step in
   // k_manager dispatches to the stored best agent's type, cf_agent.cpp:368-387)
@@ -256,7 +257,7 @@ __device__ __forceinline__ void circ_and_scale_w64(int lane, V3 p, V3 v, double 
 #pragma unroll
   for (int t = 0; t < TILES; t++) {
     const int i = t * 64 + lane;
-    const bool valid = i < M;
+    const bool valid = gate && (i < M);  // gate (:315-317) closed: no obstacle counts, the sweep below finds nothing
     const V3 ro = O.p[t] - p;
     rv_t[t] = v - O.v[t];
     double s;

@@ -199,7 +199,9 @@ __global__ __launch_bounds__(64) void k_rollout(DevView D, CostParams CP) {
 // ---------------------------------------------------------------------------
 // the step loop, specialised on the agent's heuristic so the per-step code
 // carries no type dispatch (the type is uniform per wave)
-template <int TILES, int TYPE, int MATH>
+// SENT: 0 = the repulsive obstacle cannot come into range during this rollout (decided by the caller, one-slot kernel
+// only: the step loop then has no block for it), 1 = it can, 2 = decide here at run time (the other kernels)
+template <int TILES, int TYPE, int MATH, int SENT = 2>
 __device__ __forceinline__ void rollout_w64_body(const DevView &D, const CostParams &CP, const int lane,
                                                  const int pop, const int a) {
   extern __shared__ double smem[];
@@ -284,7 +286,7 @@ __device__ __forceinline__ void rollout_w64_body(const DevView &D, const CostPar
   }
   V3 verr = attractor_velocity_error<MATH>(v, g, C, k_attr, k_damp);
   const double zsent_lt = D.zsent_lt[pop];
-  const bool sent_reachable = sentinel_reachable(p, sent_p, sent_v, zsent_lt, C, D.cap);
+  const bool sent_reachable = (SENT == 2) ? sentinel_reachable(p, sent_p, sent_v, zsent_lt, C, D.cap) : (SENT == 1);
   bool moving = false;  // any field obstacle with a non-zero (or NaN) velocity component
 #pragma unroll
   for (int t = 0; t < TILES; t++) moving = moving || !(O.v[t].x == 0.0 && O.v[t].y == 0.0 && O.v[t].z == 0.0);
@@ -426,6 +428,31 @@ __global__ __launch_bounds__(64) void k_rollout_w64(DevView D, CostParams CP) {
   const int lane = threadIdx.x;
   const int pop = blockIdx.y;
   const int a = blockIdx.x;  // grid.x == N
+  if (TILES == 1) {
+    // one slot per lane: the repulsive obstacle's reachability (per rollout, see sentinel_reachable) picks a loop
+    // without any code for it -- in the shipped scenes it sits 170 m away
+    const int n_obs = D.n_obs, M = n_obs - 1;
+    const double *src = D.obs_start + (size_t)pop * 7 * n_obs;
+    const V3 sp = mk(src[M], src[n_obs + M], src[2 * n_obs + M]);
+    const V3 sv = mk(src[3 * n_obs + M], src[4 * n_obs + M], src[5 * n_obs + M]);
+    const V3 p0 = mk(D.start_pos[pop * 3], D.start_pos[pop * 3 + 1], D.start_pos[pop * 3 + 2]);
+    const PopConst C0 = D.C;
+    const bool reach = sentinel_reachable(p0, sp, sv, D.zsent_lt[pop], C0, D.cap);
+#define PMAF_BODY(T) \
+    if (reach) rollout_w64_body<TILES, T, MATH, 1>(D, CP, lane, pop, a); \
+    else rollout_w64_body<TILES, T, MATH, 0>(D, CP, lane, pop, a)
+    switch (D.types[a]) {
+      case T_GOAL: PMAF_BODY(T_GOAL); break;
+      case T_OBST: PMAF_BODY(T_OBST); break;
+      case T_GOALOBST: PMAF_BODY(T_GOALOBST); break;
+      case T_VEL: PMAF_BODY(T_VEL); break;
+      case T_RANDOM: PMAF_BODY(T_RANDOM); break;
+      case T_HAD: PMAF_BODY(T_HAD); break;
+      default: break;
+    }
+#undef PMAF_BODY
+    return;
+  }
   switch (D.types[a]) {
     case T_GOAL: rollout_w64_body<TILES, T_GOAL, MATH>(D, CP, lane, pop, a); break;
     case T_OBST: rollout_w64_body<TILES, T_OBST, MATH>(D, CP, lane, pop, a); break;

@@ -93,5 +93,29 @@ def test_throughput_kernels_keep_two_waves_per_simd(pmaf):
         assert int(kernels[k]["Occupancy [waves/SIMD]"]) >= 2, (k, kernels[k])
         assert int(kernels[k]["ScratchSize [bytes/lane]"]) == 0, (k, kernels[k])
     for k in kernels:
-        if re.match(r"_Z13k_rollout_w64ILi[12]ELi2EE", k):
+        if re.match(r"_Z13k_rollout_w64ILi2ELi2EE", k):
             assert int(kernels[k]["ScratchSize [bytes/lane]"]) == 0, (k, kernels[k])
+        if re.match(r"_Z13k_rollout_w64ILi1ELi2EE", k):
+            # the one-slot kernel holds two loop versions per heuristic (with / without code for the repulsive
+            # obstacle); the compiler reserves a few stack slots for it that no instruction uses (next test)
+            assert int(kernels[k]["ScratchSize [bytes/lane]"]) <= 128, (k, kernels[k])
+
+
+def test_no_kernel_touches_scratch_memory(pmaf, tmp_path):
+    """a rollout kernel that spills to scratch runs at a fraction of its speed
+    (seen twice while tuning): disassemble the gfx950 code object and make sure
+    there is not a single scratch instruction in the library"""
+    import shutil
+    import subprocess
+    llvm = "/opt/rocm/lib/llvm/bin"
+    tools = [os.path.join(llvm, t) for t in ("llvm-objcopy", "clang-offload-bundler", "llvm-objdump")]
+    if not all(os.path.exists(t) for t in tools):
+        pytest.skip("ROCm LLVM tools not available")
+    fat = str(tmp_path / "fatbin.bin")
+    co = str(tmp_path / "gfx950.o")
+    subprocess.run([tools[0], "--dump-section", ".hip_fatbin=" + fat, pmaf.LIB_PATH], check=True, capture_output=True)
+    subprocess.run([tools[1], "--unbundle", "--type=o", "--input=" + fat,
+                    "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + co], check=True, capture_output=True)
+    dis = subprocess.run([tools[2], "-d", co], check=True, capture_output=True, text=True).stdout
+    assert dis.count("v_add_f64") > 1000          # it is the kernels' code
+    assert dis.count("scratch_") == 0

@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define PMAF_ABI_VERSION 1
+#define PMAF_ABI_VERSION 2
 
 typedef enum pmaf_status {
   PMAF_OK = 0,
@@ -199,16 +199,83 @@ int pmaf_get_prediction_times_ns(pmaf_planner *h, double *out);
 int pmaf_set_best(pmaf_planner *h, const int32_t *id, const int32_t *type,
                   const double *rand_vecs);
 /*
- * Winner record of each population after the last evaluate/tick, written to
- * DEVICE memory `dst` (e.g. the send buffer of an RCCL all-gather):
- * per population {double cost; double idx; double n_points; double type;
- * double path[cap][3]} = (4 + 3*cap) doubles. Enqueued on the handle's stream;
- * pmaf_stop() or a stream-ordered consumer makes it visible.
+ * Winner record of a population = the result of its last selection
+ * (pmaf_evaluate / pmaf_tick): PMAF_WINNER_RECORD_HEADER doubles
+ *   {cost, agent index, n_points, agent type, real agent's position[3] (the
+ *    set-point just published), its distance from the goal}
+ * followed by the selected agent's predicted path[cap][3] (the path that was
+ * scored; entries past n_points are zero) = (8 + 3*cap) doubles.
+ * pmaf_write_winner_records packs the records of all P populations into DEVICE
+ * memory `dst` on the handle's stream (call it after pmaf_evaluate, before
+ * the agents are reset; pmaf_stop() or a stream-ordered consumer makes it
+ * visible).
  */
+#define PMAF_WINNER_RECORD_HEADER 8
 int pmaf_write_winner_records(pmaf_planner *h, void *dst_device, size_t bytes);
 size_t pmaf_winner_record_doubles(const pmaf_planner *h);
 /* the hipStream_t the handle launches on (as void*), for stream-ordered consumers */
 void *pmaf_stream(pmaf_planner *h);
+
+/* ---- multi-GPU: one process per GPU, populations sharded over ranks ----
+ * The path shards by POPULATION: every rank plans its own populations with its
+ * own handle and there is no collective on the rollout's data path. Where a
+ * run needs every population's winning trajectory on every rank (the dual-arm
+ * coupling of BASELINE config 4, a goal sweep's global pick) the fixed-size
+ * winner records are exchanged with ONE all-gather per tick -- RCCL
+ * (ncclAllGather over xGMI) between GPUs. No reference equivalent: the
+ * reference is a single-process CPU planner. */
+typedef struct pmaf_comm pmaf_comm;
+#define PMAF_COMM_ID_BYTES 128
+/* ncclGetUniqueId: call on ONE rank and hand the 128 bytes to every rank
+ * (MPI, a file, a socket, torch.distributed ...). */
+int pmaf_comm_unique_id(void *id_out);
+/* ncclCommInitRank on HIP device `device` (-1 = current device); collective
+ * over all `world` ranks. */
+int pmaf_comm_init_rccl(int32_t world, int32_t rank, const void *id, int32_t device, pmaf_comm **out);
+/* wrap an ncclComm_t the caller already owns (not destroyed by
+ * pmaf_comm_destroy), e.g. the communicator of a host application */
+int pmaf_comm_from_rccl(void *nccl_comm, int32_t device, pmaf_comm **out);
+/* Host-transport communicator (MPI, gloo, tests): `fn` must all-gather
+ * bytes_per_rank bytes of HOST memory of every rank into recv (rank-major)
+ * and return 0. Records are staged through pinned host memory. */
+typedef int (*pmaf_host_allgather_fn)(void *ctx, const void *send, void *recv, size_t bytes_per_rank);
+int pmaf_comm_init_host(int32_t world, int32_t rank, pmaf_host_allgather_fn fn, void *ctx, pmaf_comm **out);
+int pmaf_comm_destroy(pmaf_comm *c);
+int pmaf_comm_world(const pmaf_comm *c);
+int pmaf_comm_rank(const pmaf_comm *c);
+/* blocking all-gather of n_per_rank doubles of HOST data per rank (small
+ * control-plane exchanges: agent-range cost vectors, set-points). */
+int pmaf_comm_allgather(pmaf_comm *c, const double *send, double *recv, size_t n_per_rank);
+/* CfManager::evaluateAgents' selection rule (B/src/cf_manager.cpp:336-353) on
+ * a cost vector gathered from agent-range shards: first minimum, then the 0.9
+ * hysteresis against prev_best (global 0-based index, -1 = none). */
+int32_t pmaf_select_best(const double *costs, int32_t n, int32_t prev_best);
+
+/* One-shot exchange: pmaf_write_winner_records into an internal send buffer,
+ * then the all-gather of all ranks' P records into DEVICE memory recv_device
+ * [world][P][record] -- with an RCCL communicator both are enqueued on the
+ * handle's stream with no host synchronisation in between (pmaf_stop() or a
+ * stream-ordered consumer makes the result visible); a host communicator
+ * blocks. Same call-time rule as pmaf_write_winner_records. */
+int pmaf_allgather_winners(pmaf_planner *h, pmaf_comm *c, void *recv_device, size_t bytes);
+/* Per-tick exchange for the fused tick: once a communicator is attached,
+ * every pmaf_tick / pmaf_evaluate publishes the winner records of its
+ * selection and all-gathers them on a second stream while the next rollout
+ * runs (the handle then keeps two path buffers so the rollout cannot overwrite
+ * the path being sent). c = NULL detaches. The communicator must outlive the
+ * attachment. */
+int pmaf_attach_comm(pmaf_planner *h, pmaf_comm *c);
+/* wait for the exchange of the last pmaf_tick / pmaf_evaluate; *records =
+ * [world][P][record] doubles in pinned host memory, valid until the next
+ * pmaf_tick / pmaf_evaluate; *n_doubles = world * P * record. */
+int pmaf_winners_wait(pmaf_planner *h, const double **records, size_t *n_doubles);
+/* device copy of the same table (valid after pmaf_winners_wait) */
+void *pmaf_winners_device(pmaf_planner *h);
+/* duration of the completed exchanges' all-gathers in microseconds (device
+ * time between the events around ncclAllGather, i.e. including the wait for
+ * the slowest rank; host communicator: wall time of the callback), oldest
+ * first, at most max_n; *n = number written. Clears the record. */
+int pmaf_get_exchange_times_us(pmaf_planner *h, double *out, int32_t max_n, int32_t *n);
 
 /* ---- checkpoint / resume (no reference equivalent: its state lives in RAM) ---- */
 /* Serialise the complete planner state of a handle (agents' rotation vectors

@@ -68,6 +68,13 @@ def lib():
         L.orc_rollout_omp.argtypes = [C.c_void_p, C.c_int]
         L.orc_tick_omp.restype = C.c_int
         L.orc_tick_omp.argtypes = [C.c_void_p, _dp, C.c_double, _dp, _dp, C.c_int]
+        L.orc_move_agents.argtypes = [C.c_void_p, _dp, C.c_double, C.c_int]
+        L.orc_move_agent.restype = C.c_int
+        L.orc_move_agent.argtypes = [C.c_void_p, _dp, C.c_double, C.c_int, C.c_int, C.c_int]
+        L.orc_set_agent_positions.argtypes = [C.c_void_p, _dp]
+        L.orc_set_agent_pos_and_vels.argtypes = [C.c_void_p, _dp, _dp]
+        L.orc_eval_obstacle_distance.argtypes = [C.c_void_p, _dp, _dp]
+        L.orc_set_best.argtypes = [C.c_void_p, C.c_int, C.c_int, _dp]
         L.pmaf_portable_exp.restype = C.c_double
         L.pmaf_portable_exp.argtypes = [C.c_double]
         _LIB = L
@@ -156,6 +163,42 @@ class OraclePlanner:
         _, v = _d(vel)
         _, o = _d(obstacles)
         self._L.orc_reset_agents(self._h, p, v, o)
+
+    # same surface as PmafPlanner for the sharding helpers: rollouts here are synchronous
+    def start(self):
+        self.rollout()
+
+    def stop(self):
+        pass
+
+    def set_best(self, ids, types, rand_vecs=None):
+        rv = None
+        if rand_vecs is not None:
+            _a, rv = _d(rand_vecs)
+        self._L.orc_set_best(self._h, int(np.ravel(ids)[0]), int(np.ravel(types)[0]), rv)
+
+    def move_agents(self, obstacles, dt, steps):
+        _, o = _d(obstacles)
+        self._L.orc_move_agents(self._h, o, float(dt), int(steps))
+
+    def move_agent(self, obstacles, dt, steps, agent_id, max_calls=1 << 30):
+        _, o = _d(obstacles)
+        return self._L.orc_move_agent(self._h, o, float(dt), int(steps), int(agent_id), int(max_calls))
+
+    def set_agent_positions(self, pos):
+        _, p = _d(pos)
+        self._L.orc_set_agent_positions(self._h, p)
+
+    def set_agent_pos_and_vels(self, pos, vel):
+        _, p = _d(pos)
+        _, v = _d(vel)
+        self._L.orc_set_agent_pos_and_vels(self._h, p, v)
+
+    def eval_obstacle_distance(self, obstacles):
+        _, o = _d(obstacles)
+        out = np.zeros(self.N)
+        self._L.orc_eval_obstacle_distance(self._h, o, out.ctypes.data_as(_dp))
+        return out
 
     def tick(self, obstacles, dt, cost_gains, ws):
         _, o = _d(obstacles)

@@ -133,6 +133,12 @@ struct orc_planner {
   int64_t agent_steps;
 };
 
+#ifdef PMAF_FLOPCOUNT
+/* flopcount.cpp: agent-steps of the rollouts, and those with at least one obstacle inside the detection shell */
+static long long g_steps_total = 0, g_steps_in_shell = 0;
+static int g_step_in_shell = 0;
+#endif
+
 static v3 latest(const agent_t *a) { return a->pos[a->n_pos - 1]; }
 /* CfAgent::getDistFromGoal, cf_agent.h:116-118 */
 static double dist_goal(const agent_t *a) { return vnorm(vsub(a->g_pos, latest(a))); }
@@ -263,6 +269,9 @@ static void circ_force(agent_t *a, const obs_t *obstacles, int n_obs,
     if (track_min && dist_obs < a->min_obs_dist) a->min_obs_dist = dist_obs;
     v3 curr_force = V(0.0, 0.0, 0.0);
     if (dist_obs < a->shell) {
+#ifdef PMAF_FLOPCOUNT
+      g_step_in_shell = 1;
+#endif
       if (!a->known[i]) {
         a->rot[i] = calc_rot_vec(htype, p, a->g_pos, obstacles, n_obs, i, hrand);
         a->known[i] = 1;
@@ -366,6 +375,9 @@ static void prediction_step(agent_t *a, int n_obs, double k_attr, double k_circ,
                             double k_repel, double k_damp, double dt) {
   a->force = V(0.0, 0.0, 0.0);
   double k_goal_scale = 1.0;
+#ifdef PMAF_FLOPCOUNT
+  g_step_in_shell = 0;
+#endif
   if (gate_open(a)) {
     circ_force(a, a->obstacles, n_obs, k_circ, 1, a->type, a->rand_vecs);
     if (vnorm(a->force) > 1e-5) {
@@ -376,6 +388,10 @@ static void prediction_step(agent_t *a, int n_obs, double k_attr, double k_circ,
   attractor_force(a, k_attr, k_damp, k_goal_scale);
   update_pos_vel(a, dt);
   predict_obstacles(a, n_obs, dt);
+#ifdef PMAF_FLOPCOUNT
+  g_steps_total++;
+  g_steps_in_shell += g_step_in_shell;
+#endif
 }
 
 /* CfAgent::cfPrediction inner loop run until its guard fails,
@@ -641,6 +657,90 @@ void orc_reset_agents(orc_planner *p, const double *pos, const double *vel,
     }
     a->min_obs_dist = a->shell;
   }
+}
+
+/* ---- synchronous stepping API (no callers in the reference) ---- */
+
+/* CfAgent::cfPlanner, B/src/cf_agent.cpp:278-300: `steps` steps with the CALLER's obstacle list (positions,
+ * velocities AND radii; no obstacle advance), no loop guard, the agent's own known flags / rotation vectors, and
+ * min_obs_dist_ tracking as in cfPrediction */
+static void plan_steps(orc_planner *p, int i, const obs_t *obs, double dt, int steps) {
+  agent_t *a = &p->agents[i];
+  for (int s = 0; s < steps; s++) {
+    a->force = V(0.0, 0.0, 0.0);
+    double k_goal_scale = 1.0;
+    if (gate_open(a)) {
+      circ_force(a, obs, p->n_obs, p->k_circ[i], 1, a->type, a->rand_vecs);
+      if (vnorm(a->force) > 1e-5) k_goal_scale = attractor_force_scaling(a, obs, p->n_obs);
+    }
+    repel_force(a, obs, p->n_obs, p->k_repel[i]);
+    attractor_force(a, p->k_attr[i], p->k_damp[i], k_goal_scale);
+    update_pos_vel(a, dt);
+  }
+}
+
+/* CfManager::moveAgents / moveAgentsPar, B/src/cf_manager.cpp:274-291 */
+void orc_move_agents(orc_planner *p, const double *obstacles, double dt, int steps) {
+  obs_t *obs = (obs_t *)malloc(sizeof(obs_t) * (size_t)p->n_obs);
+  unpack_obstacles(obstacles, p->n_obs, obs);
+  for (int i = 0; i < p->n_agents; i++) plan_steps(p, i, obs, dt, steps);
+  free(obs);
+}
+
+/* CfManager::moveAgent, B/src/cf_manager.cpp:265-272: cfPlanner(steps) repeated while the agent is farther than
+ * 0.05 from the goal (run_prediction_ taken as true); at most max_calls calls (the reference has no bound).
+ * Returns the number of cfPlanner calls made. */
+int orc_move_agent(orc_planner *p, const double *obstacles, double dt, int steps, int id, int max_calls) {
+  obs_t *obs = (obs_t *)malloc(sizeof(obs_t) * (size_t)p->n_obs);
+  unpack_obstacles(obstacles, p->n_obs, obs);
+  int calls = 0;
+  while (dist_goal(&p->agents[id]) > 0.05 && calls < max_calls) {
+    plan_steps(p, id, obs, dt, steps);
+    calls++;
+  }
+  free(obs);
+  return calls;
+}
+
+/* CfManager::setEEAgentPositions, B/src/cf_manager.cpp:220-224 */
+void orc_set_agent_positions(orc_planner *p, const double *pos) {
+  for (int i = 0; i < p->n_agents; i++) {
+    p->agents[i].n_pos = 0;
+    push_pos(&p->agents[i], V(pos[0], pos[1], pos[2]));
+  }
+}
+
+/* CfManager::setEEAgentPosAndVels, B/src/cf_manager.cpp:238-244 */
+void orc_set_agent_pos_and_vels(orc_planner *p, const double *pos, const double *vel) {
+  for (int i = 0; i < p->n_agents; i++) {
+    p->agents[i].n_pos = 0;
+    push_pos(&p->agents[i], V(pos[0], pos[1], pos[2]));
+    set_velocity(&p->agents[i], V(vel[0], vel[1], vel[2]));
+  }
+}
+
+/* CfAgent::evalObstacleDistance, B/src/cf_agent.cpp:146-157, for every agent: min over ALL obstacles (the trailing
+ * one included) of the unclamped surface distance, starting from the shell radius */
+void orc_eval_obstacle_distance(const orc_planner *p, const double *obstacles, double *out) {
+  for (int i = 0; i < p->n_agents; i++) {
+    const agent_t *a = &p->agents[i];
+    double min_dist = a->shell;
+    for (int k = 0; k < p->n_obs; k++) {
+      v3 o = V(obstacles[7 * k + 0], obstacles[7 * k + 1], obstacles[7 * k + 2]);
+      double d = vnorm(vsub(latest(a), o)) - (a->rad + obstacles[7 * k + 6]);
+      if (min_dist > d) min_dist = d;
+    }
+    out[i] = min_dist;
+  }
+}
+
+/* install a best-agent copy (hysteresis reference / the real agent's heuristic) from outside: what survives
+ * CfManager::init in the reference, and what an agent-range shard receives from the winner's owner */
+void orc_set_best(orc_planner *p, int id, int type, const double *rand_vecs) {
+  p->has_best = id > 0;
+  p->best_id = id;
+  p->best_type = type;
+  if (rand_vecs) memcpy(p->best_rand, rand_vecs, sizeof(v3) * (size_t)p->n_obs);
 }
 
 int orc_tick(orc_planner *p, const double *obstacles, double dt,

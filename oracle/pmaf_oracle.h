@@ -94,6 +94,18 @@ void orc_move_real(orc_planner *p, const double *obstacles, double dt,
 /* CfManager::resetEEAgents, B/src/cf_manager.cpp:246-255 */
 void orc_reset_agents(orc_planner *p, const double *pos, const double *vel,
                       const double *obstacles);
+/* Synchronous stepping API: CfManager::moveAgents (B/src/cf_manager.cpp:274-291) ->
+ * CfAgent::cfPlanner (B/src/cf_agent.cpp:278-300), moveAgent (:265-272; bounded by max_calls, returns the number
+ * of cfPlanner calls), setEEAgentPositions (:220-224), setEEAgentPosAndVels (:238-244), and
+ * CfAgent::evalObstacleDistance (B/src/cf_agent.cpp:146-157) for every agent, out [N]. */
+void orc_move_agents(orc_planner *p, const double *obstacles, double dt, int steps);
+int orc_move_agent(orc_planner *p, const double *obstacles, double dt, int steps, int id, int max_calls);
+void orc_set_agent_positions(orc_planner *p, const double *pos);
+void orc_set_agent_pos_and_vels(orc_planner *p, const double *pos, const double *vel);
+void orc_eval_obstacle_distance(const orc_planner *p, const double *obstacles, double *out);
+/* install a best-agent copy: id 1-based (0 = none), type, rand_vecs [n_obs][3] or NULL */
+void orc_set_best(orc_planner *p, int id, int type, const double *rand_vecs);
+
 /* the planCallback sequence stop/evaluate/move/reset/start+complete,
  * B/src/panda_bimanual_control.cpp:336-352. Returns best index. */
 int orc_tick(orc_planner *p, const double *obstacles, double dt,

@@ -10,7 +10,9 @@ registers it as the module `pmaf_amd`:
 
 Contents: csrc/ (HIP kernels + C-ABI, built into lib/libpmaf_hip.so),
 planner.py (ctypes binding of include/pmaf.h), scenes.py (task scenes and the
-seeded synthetic scenes), shard.py (population sharding across ranks).
+seeded synthetic scenes), shard.py (population sharding across ranks: the
+orchestration over the C-ABI's communicator / winner-exchange entry points).
 """
 from . import scenes, shard  # noqa: F401
-from .planner import LIB_PATH, SYMBOLS, PmafError, PmafPlanner, debug_math, load_library  # noqa: F401
+from .planner import (LIB_PATH, SYMBOLS, PmafComm, PmafError, PmafPlanner, debug_math, load_library,  # noqa: F401
+                      select_best)  # noqa: F401

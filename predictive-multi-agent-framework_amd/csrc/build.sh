@@ -1,5 +1,14 @@
 #!/bin/bash
 # Builds libpmaf_hip.so (HIP kernels + C-ABI) for gfx950, in-tree.
+#
+# Translation units (compiled in parallel, objects kept in ../lib/obj):
+#   pmaf_k_w64.hip   x3  the wave-per-agent rollout kernel, once per arithmetic policy (-DPMAF_W64_MATH=0|1|2)
+#   pmaf_k_grp.hip   x2  the group rollout kernel (-DPMAF_GRP_MATH=0|2)
+#   pmaf_k_misc.hip      generic rollout, manager, scoring, winner records ... + the launch interface
+#   pmaf_host.cpp        the C-ABI (g++, plain C++ against the HIP runtime API)
+#   pmaf_shard.cpp       communicators + the winner-record exchange (RCCL / host-callback)
+# linked with -lamdhip64 -lrccl.
+#
 # -ffp-contract=off: no FMA contraction, so the kernels keep the reference's
 # double-precision operation order (see pmaf_device.hpp).
 # -amdgpu-sched-strategy=max-ilp: the rollout waves run one or two per SIMD, so
@@ -8,18 +17,53 @@
 # 403 -> 382 us, C3 1974 -> 1751 us, C5 1128 -> 1096 us per tick kernel).
 set -e
 cd "$(dirname "$0")"
-HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
+ROCM=${ROCM_PATH:-/opt/rocm}
+HIPCC=${HIPCC:-$ROCM/bin/hipcc}
+CXX=${CXX:-g++}
 OUT=../lib
-mkdir -p "$OUT"
+OBJ=$OUT/obj
+mkdir -p "$OBJ"
 # -Rpass-analysis=kernel-resource-usage: registers / occupancy of every kernel,
 # kept next to the library. The group kernel's throughput rests on TWO waves per
 # SIMD (<= 256 VGPRs; it sits at ~252, and one innocent-looking variant landed
 # on 268: occupancy 1, +50 % time), so tests/test_abi.py checks the record.
-$HIPCC --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared \
-  -ffp-contract=off -fno-fast-math -mllvm -amdgpu-sched-strategy=max-ilp \
-  -Wall -Wno-unused-function -Rpass-analysis=kernel-resource-usage ${PMAF_EXTRA_FLAGS} \
-  -o "$OUT/libpmaf_hip.so" pmaf_hip.hip 2> "$OUT/build.log" || { cat "$OUT/build.log" >&2; exit 1; }
-grep -E -A3 "warning:|error:" "$OUT/build.log" >&2 || true
-grep "kernel-resource-usage" "$OUT/build.log" | sed -e 's/^[^ ]* remark: *//' -e 's/ \[-Rpass-analysis=kernel-resource-usage\]//' > "$OUT/resource_usage.txt"
-rm -f "$OUT/build.log"
+KFLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -mllvm -amdgpu-sched-strategy=max-ilp \
+  -Wall -Wno-unused-function -Rpass-analysis=kernel-resource-usage ${PMAF_EXTRA_FLAGS}"
+HFLAGS="-O2 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function -D__HIP_PLATFORM_AMD__ -I$ROCM/include ${PMAF_EXTRA_FLAGS}"
+
+DEPS_K="pmaf_types.hpp pmaf_device.hpp pmaf_rollout_w64.hpp pmaf_rollout_grp.hpp"
+pids=()
+names=()
+kcompile() {  # kcompile <object stem> <source> [defines...]
+  local stem=$1 src=$2; shift 2
+  local o="$OBJ/$stem.o"
+  local stale=0
+  [ -f "$o" ] || stale=1
+  for d in $src $DEPS_K build.sh; do [ "$d" -nt "$o" ] && stale=1; done
+  [ -n "$PMAF_EXTRA_FLAGS" ] && stale=1
+  [ "$stale" = 0 ] && return 0
+  ( $HIPCC $KFLAGS "$@" -c "$src" -o "$o" 2> "$OBJ/$stem.log" ) &
+  pids+=($!); names+=("$stem")
+}
+kcompile k_w64_m2 pmaf_k_w64.hip -DPMAF_W64_MATH=2
+kcompile k_w64_m0 pmaf_k_w64.hip -DPMAF_W64_MATH=0
+kcompile k_w64_m1 pmaf_k_w64.hip -DPMAF_W64_MATH=1
+kcompile k_grp_m2 pmaf_k_grp.hip -DPMAF_GRP_MATH=2
+kcompile k_grp_m0 pmaf_k_grp.hip -DPMAF_GRP_MATH=0
+kcompile k_misc pmaf_k_misc.hip
+( $CXX $HFLAGS -c pmaf_host.cpp -o "$OBJ/host.o" 2> "$OBJ/host.log" ) &
+pids+=($!); names+=("host")
+( $CXX $HFLAGS -c pmaf_shard.cpp -o "$OBJ/shard.o" 2> "$OBJ/shard.log" ) &
+pids+=($!); names+=("shard")
+fail=0
+for i in "${!pids[@]}"; do
+  if ! wait "${pids[$i]}"; then echo "compile failed: ${names[$i]}" >&2; cat "$OBJ/${names[$i]}.log" >&2; fail=1; fi
+done
+[ "$fail" = 0 ] || exit 1
+for n in "${names[@]}"; do grep -E -A3 "warning:|error:" "$OBJ/$n.log" >&2 || true; done
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT/libpmaf_hip.so" \
+  "$OBJ"/k_w64_m2.o "$OBJ"/k_w64_m0.o "$OBJ"/k_w64_m1.o "$OBJ"/k_grp_m2.o "$OBJ"/k_grp_m0.o "$OBJ"/k_misc.o \
+  "$OBJ"/host.o "$OBJ"/shard.o -L"$ROCM/lib" -lrccl -Wl,-rpath,"$ROCM/lib"
+# (the log of an object that was up to date is the one of its last compile)
+cat "$OBJ"/k_*.log | grep "kernel-resource-usage" | sed -e 's/^[^ ]* remark: *//' -e 's/ \[-Rpass-analysis=kernel-resource-usage\]//' > "$OUT/resource_usage.txt"
 echo "built $OUT/libpmaf_hip.so"

@@ -23,6 +23,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "pmaf_types.hpp"
+
 namespace pmaf {
 
 struct V3 { double x, y, z; };
@@ -78,7 +80,7 @@ __device__ __forceinline__ double smin(double a, double b) { return (b < a) ? b 
 // MATH_FAST (1)  opt-in (PMAF_FLAG_FAST_MATH): v_rcp_f64 / v_rsq_f64 seeds
 //                (2^-24) + two Newton iterations, no residual correction:
 //                1-2 ulp per operation; tolerance parity only.
-enum : int { MATH_IEEE = 0, MATH_FAST = 1, MATH_XACT = 2 };
+// (enum MATH_IEEE / MATH_FAST / MATH_XACT: pmaf_types.hpp)
 
 template <int MATH> struct Mth;
 template <> struct Mth<MATH_IEEE> {
@@ -259,19 +261,7 @@ __device__ __forceinline__ double portable_exp(double x) { return portable_exp<M
 enum : int { T_REAL = 0, T_GOAL = 1, T_OBST = 2, T_GOALOBST = 3, T_VEL = 4, T_RANDOM = 5, T_HAD = 6 };
 
 // population-wide scalars (CfManager::init arguments)
-struct PopConst {
-  double dt, vel_max, approach, shell, mass, rad;
-  // exact squared thresholds (computed on the host, pmaf_hip.hip:sq_gt/sq_ge):
-  // for every z >= 0   sqrt(z) > 1e-5  <=>  z >= zf_gt
-  //                    sqrt(z) > 13.0  <=>  z >= zacc_gt
-  //                    sqrt(z) < 0.2   <=>  z <  zinit_lt
-  // (sqrt is monotonic and correctly rounded, so each predicate has one
-  // boundary double); they let the w64 kernel skip square roots whose value
-  // is only compared, never used.
-  //                    sqrt(z) < 0.5 vmax        <=>  z < zvhalf_lt
-  //                    sqrt(z) < vmax - 0.1 vmax <=>  z < zv09_lt
-  double zf_gt, zacc_gt, zinit_lt, zvhalf_lt, zv09_lt;
-};
+// (struct PopConst: pmaf_types.hpp)
 
 // LDS-resident obstacle table, structure of arrays, n_obs entries each
 struct ObsTab {

@@ -1,0 +1,1319 @@
+// pmaf_host.cpp -- host side of libpmaf_hip.so: the C-ABI of include/pmaf.h (handle, buffers, streams, the tick
+// protocol, getters, checkpointing) over the kernels of pmaf_k_*.hip (launch interface: pmaf_types.hpp).
+// Plain C++ against the HIP runtime API; there is no CPU fallback in this library.
+#include <hip/hip_runtime_api.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <algorithm>
+#include <chrono>
+#include <thread>
+#include <vector>
+
+#include "../../include/pmaf.h"
+#include "pmaf_comm.hpp"
+#include "pmaf_types.hpp"
+
+using namespace pmaf;
+
+static thread_local std::string g_err;
+void pmaf_set_last_error(const std::string &msg) { g_err = msg; }  // pmaf_shard.cpp reports through the same channel
+
+struct HipError {
+  hipError_t e;
+  const char *what;
+  int line;
+};
+#define HIP_CHECK(x)                                   \
+  do {                                                 \
+    hipError_t _e = (x);                               \
+    if (_e != hipSuccess) throw HipError{_e, #x, __LINE__}; \
+  } while (0)
+
+struct StatusError {
+  int code;
+  std::string msg;
+};
+static void fail(int code, const std::string &msg) { throw StatusError{code, msg}; }
+
+// Supported numeric range of every input (metres, m/s, gains, seconds): finite
+// and either exactly 0 or 2^-100 <= |x| <= 2^100. Keeps all divisions / square
+// roots of the path inside the exponent range where the hand-expanded
+// sequences (MATH_XACT) equal the IEEE ones.
+static void check_range(const double *v, size_t n, const char *what) {
+  for (size_t i = 0; i < n; i++) {
+    const double a = std::fabs(v[i]);
+    if (!(a == 0.0 || (a >= 0x1p-100 && a <= 0x1p100)))
+      fail(PMAF_ERR_INVALID, std::string(what) + ": value outside the supported numeric range (finite, 0 or 2^-100 <= |x| <= 2^100)");
+  }
+}
+
+struct pmaf_planner {
+  DevView D{};
+  int device = 0;
+  int lpa = 64;
+  int math = MATH_XACT;        // arithmetic policy of the w64 rollout kernels (pmaf_device.hpp)
+  bool force_generic = false;  // PMAF_FORCE_GENERIC=1: always use the generic k_rollout<LPA>
+  int n_blocks = 0;
+  size_t lds_rollout = 0, lds_manager = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev_mgr = nullptr;
+  uint64_t mailbox_seq = 0;     // sequence number of the last pmaf_tick (mailbox entry 11)
+  std::vector<void *> allocs;
+  std::vector<size_t> alloc_bytes;  // size of every device buffer (state save / load)
+  double *h_out = nullptr;      // pinned [P][12] mailbox written by k_manager
+  // host copy of the real agent's state (getNextPosition / getNextVelocity /
+  // getEEForce / getDistFromGoal must not wait for the running rollout)
+  std::vector<double> real_pos_h, real_vel_h, real_force_h;
+  double *d_out = nullptr;      // device alias of h_out
+  static constexpr int kStage = 4;
+  double *h_stage[kStage] = {nullptr, nullptr, nullptr, nullptr};  // pinned staging ring for obstacle SoA uploads
+  hipEvent_t ev_stage[kStage] = {nullptr, nullptr, nullptr, nullptr};
+  double *h_zc = nullptr, *d_zc = nullptr;  // mapped pinned obstacle buffer read by k_manager in pmaf_tick
+  int stage_next = 0;
+  // ---- winner-record exchange of sharded runs (pmaf_attach_comm) ----
+  struct Exchange {
+    pmaf_comm *c = nullptr;
+    hipStream_t xs = nullptr;          // exchange stream: pack + all-gather overlap the next rollout
+    hipEvent_t ev_sel = nullptr;       // selection (k_manager) done on the handle's stream
+    hipEvent_t ev_pack = nullptr;      // k_winner_path has read the scored paths
+    hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;  // around ncclAllGather (timing)
+    hipEvent_t ev_done = nullptr;      // table on the host
+    double *d_send = nullptr, *d_recv = nullptr;  // [P][rec], [world][P][rec]
+    double *h_send = nullptr, *h_recv = nullptr;  // pinned
+    double *paths_a = nullptr, *paths_b = nullptr;  // the two path buffers (a = the handle's original one)
+    bool inflight = false;
+    std::vector<double> ag_us;
+  } x;
+  double *d_send1 = nullptr;           // send buffer of the one-shot pmaf_allgather_winners
+  double *d_link = nullptr, *h_link = nullptr;  // pmaf_link_force scratch (device / pinned host), grown on demand
+  size_t link_scratch_doubles = 0;
+  double *d_reset_in = nullptr; // [P][6]
+  int32_t *d_agent_id = nullptr;// [P]
+  CostParams cp{};
+  bool cp_valid = false;        // cp holds the workspace terms the stored cost_ws was computed with
+  bool scores_valid = false;
+  bool rollout_pending = false; // agents were (re)set since the last rollout
+  std::vector<std::vector<double>> real_path;  // per population, xyz triples
+  std::vector<double> goal_h;
+  // profiling
+  bool profiling = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_free, ev_inflight;
+  double rollout_ms = 0.0, last_rollout_ms = 0.0;
+  int64_t launches = 0, timed_launches = 0;
+
+  template <typename T>
+  T *dalloc(size_t n) {
+    void *p = nullptr;
+    HIP_CHECK(hipMalloc(&p, sizeof(T) * (n ? n : 1)));
+    allocs.push_back(p);
+    alloc_bytes.push_back(sizeof(T) * (n ? n : 1));
+    HIP_CHECK(hipMemsetAsync(p, 0, sizeof(T) * (n ? n : 1), stream));
+    return static_cast<T *>(p);
+  }
+  template <typename T>
+  void upload(T *dst, const T *src, size_t n) {
+    HIP_CHECK(hipMemcpyAsync(dst, src, sizeof(T) * n, hipMemcpyHostToDevice, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+  }
+  template <typename T>
+  void download(T *dst, const T *src, size_t n) {
+    HIP_CHECK(hipMemcpyAsync(dst, src, sizeof(T) * n, hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+  }
+  void use_device() { HIP_CHECK(hipSetDevice(device)); }
+};
+
+static void aos_to_soa(const double *aos, double *soa, int P, int n_obs) {
+  for (int p = 0; p < P; p++)
+    for (int i = 0; i < n_obs; i++)
+      for (int c = 0; c < 7; c++) soa[((size_t)p * 7 + c) * n_obs + i] = aos[((size_t)p * n_obs + i) * 7 + c];
+}
+
+// smallest z >= 0 with sqrt(z) > c, i.e. (sqrt(z) > c) == (z >= sq_gt(c)) for all z >= 0.
+// std::sqrt is correctly rounded on the host and bit-identical to the device's
+// (tests/test_parity_gpu.py::test_device_arithmetic_is_ieee_exact).
+static double sq_gt(double c) {
+  double z = c * c;
+  while (z > 0.0 && std::sqrt(z) > c) z = std::nextafter(z, 0.0);
+  while (!(std::sqrt(z) > c)) z = std::nextafter(z, INFINITY);
+  return z;
+}
+// smallest z >= 0 with sqrt(z) >= c, i.e. (sqrt(z) < c) == (z < sq_ge(c))
+static double sq_ge(double c) {
+  double z = c * c;
+  while (z > 0.0 && std::sqrt(z) >= c) z = std::nextafter(z, 0.0);
+  while (!(std::sqrt(z) >= c)) z = std::nextafter(z, INFINITY);
+  return z;
+}
+
+// Boundary of the repulsive obstacle's range test (repelForce, B/src/cf_agent.cpp:168-171):
+// smallest z >= 0 for which  max(sqrt(z) - R, 1e-5) < shell  is false; the predicate is
+// monotone in z, so  (max(sqrt(z) - R, 1e-5) < shell) == (z < boundary).
+static double repel_boundary(double R, double shell) {
+  auto in_range = [&](double z) { double d = std::sqrt(z) - R; d = (d < 1e-5) ? 1e-5 : d; return d < shell; };
+  if (!in_range(0.0)) return 0.0;
+  double lo = 0.0, hi = 1.0;
+  while (in_range(hi)) { hi *= 4.0; if (!(hi < 1e300)) return INFINITY; }
+  // bisection on the ordered bit patterns of non-negative doubles
+  uint64_t a, b;
+  std::memcpy(&a, &lo, 8); std::memcpy(&b, &hi, 8);
+  while (b - a > 1) {
+    uint64_t m = a + (b - a) / 2;
+    double z; std::memcpy(&z, &m, 8);
+    if (in_range(z)) a = m; else b = m;
+  }
+  double z; std::memcpy(&z, &b, 8);
+  return z;
+}
+
+static int pick_lpa(int N, int P, int M) {
+  // Heuristic: fill the 1024 SIMDs of the chip with waves, but never use more
+  // lanes per agent than there are field obstacles to share.
+  // Measured on C2-shaped populations (tools/lpasweep.py, kernel us for 1024 / 2048 / 4096 / 8192 agents):
+  //   wave per agent 360 / 549 / 1024 / -,  32 lanes 512 / 492 / 697 / 1348,  16 lanes 672 / 712 / 684 / 1017.
+  // The wave-per-agent kernel is the fastest while every wave has a SIMD to itself (<= 1024 waves); a second
+  // wave per SIMD costs it more than the group kernels' narrower mapping does, and those run best at 2 per SIMD.
+  int lpa = 64;
+  while (lpa > 1) {
+    long waves = ((long)N * lpa + 63) / 64 * P;
+    if (waves > (lpa == 64 ? 1024 : 2048)) lpa /= 2; else break;
+  }
+  // known-flag bitmask holds 64 tiles per lane
+  while ((M + lpa - 1) / lpa > 64 && lpa < 64) lpa *= 2;
+  return lpa;
+}
+
+// fold finished rollout event pairs (oldest first) into the stats; all=true
+// requires the stream to be idle
+static void drain_events(pmaf_planner *h, bool all) {
+  size_t done = 0;
+  for (; done < h->ev_inflight.size(); done++) {
+    auto &pr = h->ev_inflight[done];
+    if (!all && hipEventQuery(pr.second) != hipSuccess) break;
+    float ms = 0.f;
+    HIP_CHECK(hipEventElapsedTime(&ms, pr.first, pr.second));
+    h->rollout_ms += ms;
+    h->last_rollout_ms = ms;
+    h->timed_launches++;
+    h->ev_free.push_back(pr);
+  }
+  h->ev_inflight.erase(h->ev_inflight.begin(), h->ev_inflight.begin() + (long)done);
+}
+
+static void launch_rollout(pmaf_planner *h) {
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (h->profiling) {
+    drain_events(h, false);
+    if (h->ev_free.empty()) {
+      hipEvent_t a, b;
+      HIP_CHECK(hipEventCreate(&a));
+      HIP_CHECK(hipEventCreate(&b));
+      h->ev_free.emplace_back(a, b);
+    }
+    e0 = h->ev_free.back().first;
+    e1 = h->ev_free.back().second;
+    h->ev_free.pop_back();
+    h->ev_inflight.emplace_back(e0, e1);
+    HIP_CHECK(hipEventRecord(e0, h->stream));
+  }
+  // with a communicator attached the rollout writes the OTHER path buffer: the exchange of the selection just made
+  // may still be packing the path it scored (the getters follow D.paths)
+  if (h->x.c) h->D.paths = (h->D.paths == h->x.paths_a) ? h->x.paths_b : h->x.paths_a;
+  // (the one-slot kernel keeps lanes 61-63 for the goal and the two speed limits: 62-64 obstacles go to the two-slot kernel)
+  const int M = h->D.n_obs - 1;
+  const int tiles64 = (M >= 62 && M <= 64) ? 2 : (M + 63) / 64;
+  bool ok;
+  if (h->lpa == 64 && tiles64 <= 4 && !h->force_generic)
+    ok = pmaf_k_launch_w64(h->D, h->cp, tiles64, h->math, h->lds_rollout, h->stream);
+  else if (!h->force_generic && (h->lpa == 32 || h->lpa == 16 || h->lpa == 8) && (M + h->lpa - 1) / h->lpa <= 4)
+    // (the opt-in fast arithmetic exists for the w64 kernels only)
+    ok = pmaf_k_launch_grp(h->D, h->cp, h->lpa, (M + h->lpa - 1) / h->lpa, h->math == MATH_IEEE ? MATH_IEEE : MATH_XACT,
+                           h->n_blocks, h->lds_rollout, h->stream);
+  else
+    ok = pmaf_k_launch_generic(h->D, h->cp, h->lpa, h->n_blocks, h->lds_rollout, h->stream);
+  if (!ok) fail(PMAF_ERR_INVALID, "bad lanes_per_agent");
+  HIP_CHECK(hipGetLastError());
+  if (h->profiling) HIP_CHECK(hipEventRecord(e1, h->stream));
+  h->launches++;
+  h->scores_valid = true;
+  h->cp_valid = true;
+  h->rollout_pending = false;
+}
+
+static void sync(pmaf_planner *h) {
+  HIP_CHECK(hipStreamSynchronize(h->stream));
+  // an exchange in flight still reads the scored path buffer until its pack kernel is through
+  if (h->x.inflight) HIP_CHECK(hipEventSynchronize(h->x.ev_pack));
+  if (!h->ev_inflight.empty()) drain_events(h, true);
+}
+
+static void set_cost_params(pmaf_planner *h, const double *cost_gains, const double *ws) {
+  CostParams n{};
+  n.k_goal_dist = cost_gains[0];
+  n.k_path_len = cost_gains[1];
+  n.k_safe_dist = cost_gains[2];
+  n.k_workspace = cost_gains[3];
+  for (int i = 0; i < 6; i++) n.ws[i] = ws[i];
+  bool same_ws = h->cp_valid && n.k_workspace == h->cp.k_workspace && std::memcmp(n.ws, h->cp.ws, sizeof(n.ws)) == 0;
+  h->cp = n;
+  if (!same_ws) h->scores_valid = false;
+  h->cp_valid = true;
+}
+
+static void ensure_scores(pmaf_planner *h) {
+  if (h->scores_valid) return;
+  pmaf_k_launch_score(h->D, h->cp, h->stream);
+  HIP_CHECK(hipGetLastError());
+  h->scores_valid = true;
+}
+
+static void upload_live_obstacles(pmaf_planner *h, const double *obstacles) {
+  if (!obstacles) return;
+  check_range(obstacles, (size_t)h->D.P * h->D.n_obs * 7, "obstacles");
+  // ring of pinned staging buffers: wait only for the copy that last used this slot
+  int s = h->stage_next;
+  h->stage_next = (s + 1) % pmaf_planner::kStage;
+  HIP_CHECK(hipEventSynchronize(h->ev_stage[s]));
+  aos_to_soa(obstacles, h->h_stage[s], h->D.P, h->D.n_obs);
+  HIP_CHECK(hipMemcpyAsync(h->D.obs_live, h->h_stage[s], sizeof(double) * (size_t)h->D.P * 7 * h->D.n_obs,
+                           hipMemcpyHostToDevice, h->stream));
+  HIP_CHECK(hipEventRecord(h->ev_stage[s], h->stream));
+}
+
+// pmaf_tick's obstacles: converted into the mapped pinned buffer k_manager reads directly. One buffer is enough:
+// pmaf_tick returns only after the manager kernel that read it has published its result.
+static const double *stage_live_obstacles_zero_copy(pmaf_planner *h, const double *obstacles) {
+  if (!obstacles) return nullptr;
+  check_range(obstacles, (size_t)h->D.P * h->D.n_obs * 7, "obstacles");
+  aos_to_soa(obstacles, h->h_zc, h->D.P, h->D.n_obs);
+  return h->d_zc;
+}
+
+static void launch_manager(pmaf_planner *h, const ManagerArgs &A0) {
+  ManagerArgs A = A0;
+  A.tuned_real_step = (h->math == MATH_XACT && !h->force_generic) ? 1 : 0;
+  pmaf_k_launch_manager(h->D, h->cp, A, h->lds_manager, h->stream);
+  HIP_CHECK(hipGetLastError());
+}
+
+// copy the mailbox into the host-side real-agent state (call after the
+// k_manager launch has completed)
+static void refresh_real_cache(pmaf_planner *h) {
+  for (int p = 0; p < h->D.P; p++) {
+    const double *o = h->h_out + p * 12;
+    for (int c = 0; c < 3; c++) {
+      h->real_pos_h[p * 3 + c] = o[1 + c];
+      h->real_vel_h[p * 3 + c] = o[4 + c];
+      h->real_force_h[p * 3 + c] = o[8 + c];
+    }
+  }
+}
+
+// Spin until k_manager has published sequence number `seq` for every
+// population. The stream is queried now and then so that a failed or finished
+// launch cannot leave the host spinning.
+static void wait_mailbox(pmaf_planner *h, double seq) {
+  for (int p = 0; p < h->D.P; p++) {
+    const volatile double *s = h->h_out + p * 12 + 11;
+    unsigned spins = 0;
+    while (*s != seq) {
+#if defined(__x86_64__) || defined(__i386__)
+      __builtin_ia32_pause();
+#else
+      std::this_thread::yield();
+#endif
+      if ((++spins & 0x3fffu) == 0) {
+        hipError_t e = hipStreamQuery(h->stream);
+        if (e == hipErrorNotReady) continue;
+        if (e != hipSuccess) throw HipError{e, "hipStreamQuery (mailbox wait)", __LINE__};
+        if (*s != seq) fail(PMAF_ERR_DEVICE, "pmaf_tick: manager kernel finished without publishing its result");
+      }
+    }
+  }
+  __atomic_thread_fence(__ATOMIC_ACQUIRE);
+}
+
+static void append_real_path(pmaf_planner *h) {
+  for (int p = 0; p < h->D.P; p++) {
+    const double *o = h->h_out + p * 12;
+    h->real_path[p].insert(h->real_path[p].end(), {o[1], o[2], o[3]});
+  }
+}
+
+// ---- winner-record exchange ---------------------------------------------------
+static size_t winner_rec(const pmaf_planner *h) { return PMAF_WINNER_HDR + (size_t)h->D.cap * 3; }
+
+// complete the exchange in flight (if any): RCCL -- wait for the table on the host and book the all-gather's device
+// time; host transport -- wait for the packed records, then run the caller's collective here
+static void finish_exchange(pmaf_planner *h) {
+  pmaf_planner::Exchange &x = h->x;
+  if (!x.inflight) return;
+  HIP_CHECK(hipEventSynchronize(x.ev_done));
+  const size_t n_local = (size_t)h->D.P * winner_rec(h);
+  if (x.c->rccl) {
+    float ms = 0.f;
+    HIP_CHECK(hipEventElapsedTime(&ms, x.ev_t0, x.ev_t1));
+    x.ag_us.push_back((double)ms * 1e3);
+  } else {
+    const auto t0 = std::chrono::steady_clock::now();
+    if (x.c->fn(x.c->ctx, x.h_send, x.h_recv, n_local * sizeof(double)) != 0)
+      fail(PMAF_ERR_DEVICE, "winner exchange: the host all-gather callback failed");
+    x.ag_us.push_back(std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count());
+    HIP_CHECK(hipMemcpyAsync(x.d_recv, x.h_recv, n_local * x.c->world * sizeof(double), hipMemcpyHostToDevice, x.xs));
+    HIP_CHECK(hipStreamSynchronize(x.xs));
+  }
+  if (x.ag_us.size() > (1u << 20)) x.ag_us.erase(x.ag_us.begin(), x.ag_us.begin() + (1u << 19));
+  x.inflight = false;
+}
+
+// after k_manager (which wrote the record headers into d_send) has been enqueued on the handle's stream: pack the
+// selected agents' paths out of `scored_paths` and all-gather the records, all on the exchange stream
+static void begin_exchange(pmaf_planner *h, const double *scored_paths) {
+  pmaf_planner::Exchange &x = h->x;
+  const size_t n_local = (size_t)h->D.P * winner_rec(h);
+  HIP_CHECK(hipEventRecord(x.ev_sel, h->stream));
+  HIP_CHECK(hipStreamWaitEvent(x.xs, x.ev_sel, 0));
+  pmaf_k_launch_winner_path(h->D, scored_paths, x.d_send, x.xs);
+  HIP_CHECK(hipGetLastError());
+  HIP_CHECK(hipEventRecord(x.ev_pack, x.xs));
+  if (x.c->rccl) {
+    HIP_CHECK(hipEventRecord(x.ev_t0, x.xs));
+    const std::string err = pmaf_comm_enqueue_allgather(x.c, x.d_send, x.d_recv, n_local, x.xs);
+    if (!err.empty()) fail(PMAF_ERR_DEVICE, err);
+    HIP_CHECK(hipEventRecord(x.ev_t1, x.xs));
+    HIP_CHECK(hipMemcpyAsync(x.h_recv, x.d_recv, n_local * x.c->world * sizeof(double), hipMemcpyDeviceToHost, x.xs));
+  } else {
+    HIP_CHECK(hipMemcpyAsync(x.h_send, x.d_send, n_local * sizeof(double), hipMemcpyDeviceToHost, x.xs));
+  }
+  HIP_CHECK(hipEventRecord(x.ev_done, x.xs));
+  x.inflight = true;
+}
+
+static void detach_comm(pmaf_planner *h) {
+  pmaf_planner::Exchange &x = h->x;
+  if (!x.c) return;
+  if (x.inflight) {
+    // an RCCL all-gather already enqueued completes (every rank enqueued it); a host collective not yet run is dropped
+    (void)hipStreamSynchronize(x.xs);
+    x.inflight = false;
+  }
+  (void)hipStreamSynchronize(h->stream);
+  if (h->D.paths != x.paths_a) {  // the handle goes back to its own path buffer
+    (void)hipMemcpy(x.paths_a, x.paths_b, sizeof(double) * (size_t)h->D.P * h->D.N * h->D.cap * 3, hipMemcpyDeviceToDevice);
+    h->D.paths = x.paths_a;
+  }
+  if (x.paths_b) (void)hipFree(x.paths_b);
+  if (x.d_send) (void)hipFree(x.d_send);
+  if (x.d_recv) (void)hipFree(x.d_recv);
+  if (x.h_send) (void)hipHostFree(x.h_send);
+  if (x.h_recv) (void)hipHostFree(x.h_recv);
+  for (hipEvent_t e : {x.ev_sel, x.ev_pack, x.ev_t0, x.ev_t1, x.ev_done}) if (e) (void)hipEventDestroy(e);
+  if (x.xs) (void)hipStreamDestroy(x.xs);
+  x = pmaf_planner::Exchange{};
+}
+
+template <typename F>
+static int guarded(F &&f) {
+  try {
+    f();
+    return PMAF_OK;
+  } catch (const StatusError &e) {
+    g_err = e.msg;
+    return e.code;
+  } catch (const HipError &e) {
+    char buf[512];
+    snprintf(buf, sizeof(buf), "HIP error %d (%s) at %s [pmaf_hip.hip:%d]", (int)e.e, hipGetErrorString(e.e), e.what, e.line);
+    g_err = buf;
+    return PMAF_ERR_DEVICE;
+  } catch (const std::bad_alloc &) {
+    g_err = "host allocation failed";
+    return PMAF_ERR_NOMEM;
+  } catch (...) {
+    g_err = "unknown error";
+    return PMAF_ERR_INVALID;
+  }
+}
+
+#define REQUIRE(c, msg) do { if (!(c)) fail(PMAF_ERR_INVALID, msg); } while (0)
+
+
+extern "C" {
+
+const char *pmaf_last_error(void) { return g_err.c_str(); }
+int pmaf_abi_version(void) { return PMAF_ABI_VERSION; }
+
+int pmaf_create(const pmaf_params *prm, pmaf_planner **out) {
+  pmaf_planner *h = nullptr;
+  int rc = guarded([&] {
+    REQUIRE(prm && out, "pmaf_create: NULL argument");
+    REQUIRE(prm->abi_version == PMAF_ABI_VERSION, "pmaf_create: ABI version mismatch");
+    REQUIRE(prm->n_populations >= 1 && prm->n_agents >= 1, "pmaf_create: need n_populations >= 1 and n_agents >= 1");
+    REQUIRE(prm->n_obstacles >= 1, "pmaf_create: obstacle list must hold at least the trailing repulsive obstacle");
+    REQUIRE(prm->max_prediction_steps >= 1, "pmaf_create: max_prediction_steps must be >= 1");
+    REQUIRE(prm->goal && prm->obstacles && prm->k_attr && prm->k_circ && prm->k_repel && prm->k_damp,
+            "pmaf_create: goal, obstacles and gain arrays are required");
+    {
+      const size_t P_ = (size_t)prm->n_populations, N_ = (size_t)prm->n_agents, O_ = (size_t)prm->n_obstacles;
+      check_range(prm->goal, P_ * 3, "pmaf_create: goal");
+      if (prm->init_pos) check_range(prm->init_pos, P_ * 3, "pmaf_create: init_pos");
+      check_range(prm->obstacles, P_ * O_ * 7, "pmaf_create: obstacles");
+      check_range(prm->k_attr, P_ * N_, "pmaf_create: k_attr"); check_range(prm->k_circ, P_ * N_, "pmaf_create: k_circ");
+      check_range(prm->k_repel, P_ * N_, "pmaf_create: k_repel"); check_range(prm->k_damp, P_ * N_, "pmaf_create: k_damp");
+      if (prm->random_vecs) check_range(prm->random_vecs, P_ * N_ * O_ * 3, "pmaf_create: random_vecs");
+      const double sc[6] = {prm->dt, prm->velocity_max, prm->approach_dist, prm->detect_shell_rad, prm->agent_mass, prm->radius};
+      check_range(sc, 6, "pmaf_create: scalar parameter");
+    }
+    int lp = prm->lanes_per_agent;
+    REQUIRE(lp == 0 || (lp >= 1 && lp <= 64 && (lp & (lp - 1)) == 0), "pmaf_create: lanes_per_agent must be 0 or a power of two <= 64");
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) fail(PMAF_ERR_DEVICE, "pmaf_create: no HIP device available (this library has no CPU fallback)");
+    h = new pmaf_planner();
+    if (prm->device >= 0) h->device = prm->device; else HIP_CHECK(hipGetDevice(&h->device));
+    REQUIRE(h->device < ndev, "pmaf_create: device ordinal out of range");
+    h->use_device();
+    HIP_CHECK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    HIP_CHECK(hipEventCreateWithFlags(&h->ev_mgr, hipEventDisableTiming));
+    const int P = prm->n_populations, N = prm->n_agents, n_obs = prm->n_obstacles, cap = prm->max_prediction_steps;
+    const int M = n_obs - 1;
+    DevView &D = h->D;
+    D.P = P; D.N = N; D.n_obs = n_obs; D.cap = cap;
+    D.C.dt = prm->dt; D.C.vel_max = prm->velocity_max; D.C.approach = prm->approach_dist;
+    D.C.shell = prm->detect_shell_rad; D.C.mass = prm->agent_mass; D.C.rad = prm->radius;
+    D.C.zf_gt = sq_gt(1e-5); D.C.zacc_gt = sq_gt(13.0); D.C.zinit_lt = sq_ge(0.2);
+    D.C.zvhalf_lt = sq_ge(0.5 * prm->velocity_max);
+    D.C.zv09_lt = sq_ge(prm->velocity_max - 0.1 * prm->velocity_max);
+    h->math = (prm->flags & PMAF_FLAG_FAST_MATH) ? MATH_FAST : (prm->flags & PMAF_FLAG_IEEE_SEQUENCES) ? MATH_IEEE : MATH_XACT;
+    h->lpa = lp ? lp : pick_lpa(N, P, M);
+    { const char *fg = getenv("PMAF_FORCE_GENERIC"); h->force_generic = fg && fg[0] == '1'; }
+    { const char *ab = getenv("PMAF_ABLATE"); D.ablate = ab ? atoi(ab) : 0; }
+    {
+      int cus = 0;
+      HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device));
+      D.n_simds = 4 * (cus > 0 ? cus : 256);
+    }
+    REQUIRE((M + h->lpa - 1) / h->lpa <= 64, "pmaf_create: too many obstacles for this lanes_per_agent (need M <= 64*lanes_per_agent)");
+    h->n_blocks = (N * h->lpa + 63) / 64;
+    {
+      // obstacle table + known flags, then (w64 kernels) the per-step list of
+      // circular-field terms: 64 * TILES entries of 4 doubles
+      size_t off = 7 * (size_t)n_obs + ((size_t)n_obs + 1) / 2;
+      off += off & 1;
+      // w64: (64 * TILES + 8 padding + 64 scratch) entries; groups: 64 * TILES + one zero entry per group (<= 8)
+      h->lds_rollout = sizeof(double) * (off + (64 * 4 + 8 + 64) * 4 + 8 * 4);
+    }
+    // table | known flags | costs | the tuned real step's list (64 * 4 + 8 + 64 entries of 4 doubles)
+    h->lds_manager = sizeof(double) * (7 * (size_t)n_obs + ((size_t)n_obs + 1) / 2 + (size_t)N + 1 + (64 * 4 + 8 + 64) * 4);
+    REQUIRE(h->lds_rollout <= 160 * 1024, "pmaf_create: obstacle table does not fit in LDS");
+    REQUIRE(h->lds_manager <= 160 * 1024,
+            "pmaf_create: n_agents + obstacle table exceed the manager kernel's LDS budget (160 KB: 8 B per agent, 60 B per obstacle)");
+    // dynamic LDS beyond the 64 KB default needs the per-function opt-in
+    HIP_CHECK(pmaf_k_set_lds_limits(h->lds_manager, h->lds_rollout));
+
+    size_t PN = (size_t)P * N;
+    double *goal = h->dalloc<double>(P * 3);
+    D.goal = goal;
+    D.agent_init_pos = h->dalloc<double>(P * 3);
+    D.start_pos = h->dalloc<double>(P * 3);
+    D.start_vel = h->dalloc<double>(P * 3);
+    D.obs_start = h->dalloc<double>((size_t)P * 7 * n_obs);
+    D.known_start = h->dalloc<int32_t>((size_t)P * n_obs);
+    D.obs_live = h->dalloc<double>((size_t)P * 7 * n_obs);
+    double *ka = h->dalloc<double>(PN), *kc = h->dalloc<double>(PN), *kr = h->dalloc<double>(PN), *kd = h->dalloc<double>(PN);
+    D.k_attr = ka; D.k_circ = kc; D.k_repel = kr; D.k_damp = kd;
+    int32_t *types = h->dalloc<int32_t>(N);
+    D.types = types;
+    D.rot = h->dalloc<double>(PN * 3 * n_obs);
+    double *rnd = h->dalloc<double>(PN * 3 * n_obs);
+    D.rnd = rnd;
+    D.paths = h->dalloc<double>(PN * (size_t)cap * 3);
+    D.n_points = h->dalloc<int32_t>(PN);
+    D.agent_vel = h->dalloc<double>(PN * 3);
+    D.min_obs = h->dalloc<double>(PN);
+    D.cost_ws = h->dalloc<double>(PN);
+    D.path_len = h->dalloc<double>(PN);
+    D.goal_dist = h->dalloc<double>(PN);
+    D.reached = h->dalloc<int32_t>(PN);
+    D.known_out = h->dalloc<int32_t>(PN * n_obs);
+    D.costs = h->dalloc<double>(PN);
+    D.real_pos = h->dalloc<double>(P * 3);
+    D.real_vel = h->dalloc<double>(P * 3);
+    D.real_force = h->dalloc<double>(P * 3);
+    D.real_init_pos = h->dalloc<double>(P * 3);
+    D.real_known = h->dalloc<int32_t>((size_t)P * n_obs);
+    D.real_rot = h->dalloc<double>((size_t)P * 3 * n_obs);
+    D.has_best = h->dalloc<int32_t>(P);
+    D.best_id = h->dalloc<int32_t>(P);
+    D.best_type = h->dalloc<int32_t>(P);
+    D.best_rnd = h->dalloc<double>((size_t)P * 3 * n_obs);
+    D.best_idx = h->dalloc<int32_t>(P);
+    D.step_counter = h->dalloc<unsigned long long>(1);
+    D.pred_ticks = h->dalloc<unsigned long long>(PN);
+    double *zsent = h->dalloc<double>(P);
+    D.zsent_lt = zsent;
+    h->d_reset_in = h->dalloc<double>(P * 6);
+    h->d_agent_id = h->dalloc<int32_t>(P);
+    HIP_CHECK(hipHostMalloc((void **)&h->h_out, sizeof(double) * P * 12, hipHostMallocMapped));
+    HIP_CHECK(hipHostGetDevicePointer((void **)&h->d_out, h->h_out, 0));
+    HIP_CHECK(hipHostMalloc((void **)&h->h_zc, sizeof(double) * (size_t)P * 7 * n_obs, hipHostMallocMapped));
+    HIP_CHECK(hipHostGetDevicePointer((void **)&h->d_zc, h->h_zc, 0));
+    for (int i = 0; i < pmaf_planner::kStage; i++) {
+      HIP_CHECK(hipHostMalloc((void **)&h->h_stage[i], sizeof(double) * (size_t)P * 7 * n_obs, hipHostMallocDefault));
+      HIP_CHECK(hipEventCreateWithFlags(&h->ev_stage[i], hipEventDisableTiming));
+    }
+    std::memset(h->h_out, 0, sizeof(double) * P * 12);
+
+    // ---- initial state = freshly constructed agents (cf_agent.h:69-97) ----
+    std::vector<double> init(P * 3, 0.0);
+    if (prm->init_pos) init.assign(prm->init_pos, prm->init_pos + P * 3);
+    h->goal_h.assign(prm->goal, prm->goal + P * 3);
+    h->upload(goal, prm->goal, P * 3);
+    // CfAgent::init_pos_ member starts at zero (cf_agent.h:78), positions at CfManager::init_pos_
+    h->upload(D.start_pos, init.data(), P * 3);
+    h->upload(D.real_pos, init.data(), P * 3);
+    std::vector<double> v0(P * 3, 0.0);
+    for (int p = 0; p < P; p++) v0[p * 3] = 0.01;  // vel_{0.01, 0, 0}, cf_agent.h:76
+    h->upload(D.start_vel, v0.data(), P * 3);
+    h->upload(D.real_vel, v0.data(), P * 3);
+    std::vector<double> soa((size_t)P * 7 * n_obs);
+    aos_to_soa(prm->obstacles, soa.data(), P, n_obs);
+    {
+      std::vector<double> zs(P);
+      for (int p = 0; p < P; p++)
+        zs[p] = repel_boundary(prm->radius + prm->obstacles[((size_t)p * n_obs + (n_obs - 1)) * 7 + 6], prm->detect_shell_rad);
+      h->upload(zsent, zs.data(), P);
+    }
+    h->upload(D.obs_start, soa.data(), soa.size());
+    h->upload(D.obs_live, soa.data(), soa.size());
+    h->upload(ka, prm->k_attr, PN); h->upload(kc, prm->k_circ, PN);
+    h->upload(kr, prm->k_repel, PN); h->upload(kd, prm->k_damp, PN);
+    std::vector<int32_t> ty(N);
+    static const int layout[5] = {PMAF_HAD_HEURISTIC, PMAF_GOAL_HEURISTIC, PMAF_OBSTACLE_HEURISTIC,
+                                  PMAF_GOAL_OBSTACLE_HEURISTIC, PMAF_VEL_HEURISTIC};
+    for (int i = 0; i < N; i++) {
+      ty[i] = prm->agent_types ? prm->agent_types[i] : (i < 5 ? layout[i] : PMAF_RANDOM_AGENT);
+      REQUIRE(ty[i] >= PMAF_GOAL_HEURISTIC && ty[i] <= PMAF_HAD_HEURISTIC, "pmaf_create: agent type must be one of the six heuristics");
+    }
+    h->upload(types, ty.data(), N);
+    // rotation vectors start at (0,0,1), cf_agent.h:92-96; component-major [3][n_obs]
+    {
+      std::vector<double> rot(PN * 3 * n_obs, 0.0);
+      for (size_t pa = 0; pa < PN; pa++)
+        for (int i = 0; i < n_obs; i++) rot[(pa * 3 + 2) * n_obs + i] = 1.0;
+      h->upload(D.rot, rot.data(), rot.size());
+      std::vector<double> rr((size_t)P * 3 * n_obs, 0.0);
+      for (int p = 0; p < P; p++)
+        for (int i = 0; i < n_obs; i++) rr[((size_t)p * 3 + 2) * n_obs + i] = 1.0;
+      h->upload(D.real_rot, rr.data(), rr.size());
+    }
+    if (prm->random_vecs) {
+      std::vector<double> r(PN * 3 * n_obs);
+      for (size_t pa = 0; pa < PN; pa++)
+        for (int i = 0; i < n_obs; i++)
+          for (int c = 0; c < 3; c++) r[(pa * 3 + c) * n_obs + i] = prm->random_vecs[(pa * n_obs + i) * 3 + c];
+      h->upload(rnd, r.data(), r.size());
+    }
+    // 1-point paths at init_pos, min_obs = shell
+    {
+      std::vector<double> paths(PN * (size_t)cap * 3, 0.0);
+      std::vector<int32_t> np(PN, 1);
+      std::vector<double> mo(PN, prm->detect_shell_rad), av(PN * 3, 0.0);
+      for (size_t pa = 0; pa < PN; pa++) {
+        int p = (int)(pa / N);
+        for (int c = 0; c < 3; c++) paths[pa * cap * 3 + c] = init[p * 3 + c];
+        av[pa * 3] = 0.01;
+      }
+      h->upload(D.paths, paths.data(), paths.size());
+      h->upload(D.n_points, np.data(), np.size());
+      h->upload(D.min_obs, mo.data(), mo.size());
+      h->upload(D.agent_vel, av.data(), av.size());
+    }
+    h->real_pos_h = init;
+    h->real_vel_h = v0;
+    h->real_force_h.assign(P * 3, 0.0);
+    h->real_path.assign(P, {});
+    for (int p = 0; p < P; p++) h->real_path[p].insert(h->real_path[p].end(), {init[p * 3], init[p * 3 + 1], init[p * 3 + 2]});
+    h->rollout_pending = true;
+    sync(h);
+    *out = h;
+  });
+  if (rc != PMAF_OK && h) { pmaf_destroy(h); }
+  return rc;
+}
+
+int pmaf_destroy(pmaf_planner *h) {
+  if (!h) return PMAF_OK;
+  (void)hipSetDevice(h->device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  detach_comm(h);
+  if (h->d_send1) (void)hipFree(h->d_send1);
+  for (void *p : h->allocs) (void)hipFree(p);
+  if (h->h_out) (void)hipHostFree(h->h_out);
+  if (h->h_zc) (void)hipHostFree(h->h_zc);
+  if (h->d_link) (void)hipFree(h->d_link);
+  if (h->h_link) (void)hipHostFree(h->h_link);
+  for (int i = 0; i < pmaf_planner::kStage; i++) {
+    if (h->h_stage[i]) (void)hipHostFree(h->h_stage[i]);
+    if (h->ev_stage[i]) (void)hipEventDestroy(h->ev_stage[i]);
+  }
+  for (auto &e : h->ev_free) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+  for (auto &e : h->ev_inflight) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+  if (h->ev_mgr) (void)hipEventDestroy(h->ev_mgr);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+  return PMAF_OK;
+}
+
+int pmaf_set_initial_position(pmaf_planner *h, const double *pos) {
+  return guarded([&] {
+    REQUIRE(h && pos, "pmaf_set_initial_position: NULL argument");
+    check_range(pos, (size_t)h->D.P * 3, "pmaf_set_initial_position");
+    h->use_device();
+    sync(h);
+    DevView &D = h->D;
+    const int P = D.P;
+    h->upload(D.agent_init_pos, pos, P * 3);
+    h->upload(D.real_init_pos, pos, P * 3);
+    h->upload(D.real_pos, pos, P * 3);
+    h->upload(D.start_pos, pos, P * 3);
+    // CfAgent::setPosition = clear + push_back for every predicted agent
+    pmaf_k_launch_restart_paths(D, D.start_pos, h->stream);
+    HIP_CHECK(hipGetLastError());
+    h->real_pos_h.assign(pos, pos + P * 3);
+    for (int p = 0; p < P; p++)  // RealCfAgent::setPosition = push_back
+      h->real_path[p].insert(h->real_path[p].end(), {pos[p * 3], pos[p * 3 + 1], pos[p * 3 + 2]});
+    sync(h);
+    h->scores_valid = false;
+    h->rollout_pending = true;
+  });
+}
+
+int pmaf_set_real_position(pmaf_planner *h, const double *pos) {
+  return guarded([&] {
+    REQUIRE(h && pos, "pmaf_set_real_position: NULL argument");
+    check_range(pos, (size_t)h->D.P * 3, "pmaf_set_real_position");
+    h->use_device();
+    sync(h);
+    h->upload(h->D.real_pos, pos, h->D.P * 3);
+    h->real_pos_h.assign(pos, pos + h->D.P * 3);
+    for (int p = 0; p < h->D.P; p++)
+      h->real_path[p].insert(h->real_path[p].end(), {pos[p * 3], pos[p * 3 + 1], pos[p * 3 + 2]});
+  });
+}
+
+int pmaf_start(pmaf_planner *h) {
+  return guarded([&] {
+    REQUIRE(h, "pmaf_start: NULL handle");
+    h->use_device();
+    // a finished rollout that was not reset has nothing left to predict
+    // (guard B/src/cf_agent.cpp:310-311 is already false)
+    if (!h->rollout_pending) return;
+    if (!h->cp_valid) {  // no evaluate yet: score with neutral workspace terms, rescored on evaluate
+      h->cp = CostParams{};
+      h->cp.ws[0] = h->cp.ws[2] = h->cp.ws[4] = INFINITY;
+      h->cp.ws[1] = h->cp.ws[3] = h->cp.ws[5] = -INFINITY;
+    }
+    bool had_cp = h->cp_valid;
+    launch_rollout(h);
+    h->cp_valid = had_cp;
+    if (!had_cp) h->scores_valid = false;
+  });
+}
+
+int pmaf_stop(pmaf_planner *h) {
+  return guarded([&] {
+    REQUIRE(h, "pmaf_stop: NULL handle");
+    h->use_device();
+    sync(h);
+  });
+}
+
+int pmaf_evaluate(pmaf_planner *h, const double *cost_gains, const double *ws, int32_t *best_idx) {
+  return guarded([&] {
+    REQUIRE(h && cost_gains && ws, "pmaf_evaluate: NULL argument");
+    h->use_device();
+    set_cost_params(h, cost_gains, ws);
+    ensure_scores(h);
+    ManagerArgs A{};
+    A.do_select = 1;
+    A.out = h->d_out;
+    if (h->x.c) {
+      finish_exchange(h);  // the previous exchange owns the send buffer until it is through
+      A.winner_hdr = h->x.d_send;
+      A.winner_stride = (int)winner_rec(h);
+    }
+    launch_manager(h, A);
+    if (h->x.c) begin_exchange(h, h->D.paths);
+    HIP_CHECK(hipStreamSynchronize(h->stream));
+    if (!h->ev_inflight.empty()) drain_events(h, true);
+    refresh_real_cache(h);
+    if (best_idx)
+      for (int p = 0; p < h->D.P; p++) best_idx[p] = (int32_t)h->h_out[p * 12];
+  });
+}
+
+int pmaf_move_real(pmaf_planner *h, const double *obstacles, double dt, int32_t steps, const int32_t *agent_id) {
+  return guarded([&] {
+    REQUIRE(h && agent_id, "pmaf_move_real: NULL argument");
+    REQUIRE(steps >= 0, "pmaf_move_real: steps must be >= 0");
+    h->use_device();
+    sync(h);
+    int32_t hb = 0;
+    h->download(&hb, h->D.has_best, 1);
+    if (!hb) fail(PMAF_ERR_STATE, "pmaf_move_real: no best agent yet (call pmaf_evaluate first; the reference dereferences a null best_agent_ here)");
+    for (int p = 0; p < h->D.P; p++) REQUIRE(agent_id[p] >= 0 && agent_id[p] < h->D.N, "pmaf_move_real: agent_id out of range");
+    upload_live_obstacles(h, obstacles);
+    h->upload(h->d_agent_id, agent_id, h->D.P);
+    for (int s = 0; s < steps; s++) {
+      ManagerArgs A{};
+      A.do_move = 1;
+      A.dt_real = dt;
+      A.agent_id = h->d_agent_id;
+      A.out = h->d_out;
+      launch_manager(h, A);
+      sync(h);
+      refresh_real_cache(h);
+      append_real_path(h);
+    }
+  });
+}
+
+int pmaf_reset_agents(pmaf_planner *h, const double *pos, const double *vel, const double *obstacles) {
+  return guarded([&] {
+    REQUIRE(h && pos && vel, "pmaf_reset_agents: NULL argument");
+    check_range(pos, (size_t)h->D.P * 3, "pmaf_reset_agents: pos");
+    check_range(vel, (size_t)h->D.P * 3, "pmaf_reset_agents: vel");
+    h->use_device();
+    sync(h);
+    upload_live_obstacles(h, obstacles);
+    std::vector<double> in(h->D.P * 6);
+    for (int p = 0; p < h->D.P; p++)
+      for (int c = 0; c < 3; c++) { in[p * 6 + c] = pos[p * 3 + c]; in[p * 6 + 3 + c] = vel[p * 3 + c]; }
+    h->upload(h->d_reset_in, in.data(), in.size());
+    ManagerArgs A{};
+    A.do_reset = 1;
+    A.reset_in = h->d_reset_in;
+    A.out = h->d_out;
+    launch_manager(h, A);
+    sync(h);
+    refresh_real_cache(h);
+    h->scores_valid = false;
+    h->rollout_pending = true;
+  });
+}
+
+int pmaf_tick(pmaf_planner *h, const double *obstacles, double dt, const double *cost_gains, const double *ws,
+              int32_t *best_idx, double *next_pos, double *next_vel) {
+  return guarded([&] {
+    REQUIRE(h && cost_gains && ws, "pmaf_tick: NULL argument");
+    h->use_device();
+    set_cost_params(h, cost_gains, ws);
+    ensure_scores(h);
+    ManagerArgs A{};
+    A.live_src = stage_live_obstacles_zero_copy(h, obstacles);
+    A.do_select = 1; A.do_move = 1; A.do_reset = 1; A.reset_from_real = 1;
+    A.rollout_follows = 1;
+    A.dt_real = dt;
+    A.out = h->d_out;
+    A.seq = (double)(++h->mailbox_seq);
+    if (h->x.c) {
+      finish_exchange(h);  // normally long through: it ran beside the previous rollout
+      A.winner_hdr = h->x.d_send;
+      A.winner_stride = (int)winner_rec(h);
+    }
+    launch_manager(h, A);
+    if (h->x.c) begin_exchange(h, h->D.paths);  // the paths this selection scored; the rollout below writes the other buffer
+    h->rollout_pending = true;
+    launch_rollout(h);
+    // outputs of k_manager land in mapped pinned memory; wait for them only
+    // (no event between the two launches: the host polls the sequence number)
+    wait_mailbox(h, A.seq);
+    refresh_real_cache(h);
+    append_real_path(h);
+    for (int p = 0; p < h->D.P; p++) {
+      const double *o = h->h_out + p * 12;
+      if (best_idx) best_idx[p] = (int32_t)o[0];
+      if (next_pos) { next_pos[p * 3] = o[1]; next_pos[p * 3 + 1] = o[2]; next_pos[p * 3 + 2] = o[3]; }
+      if (next_vel) { next_vel[p * 3] = o[4]; next_vel[p * 3 + 1] = o[5]; next_vel[p * 3 + 2] = o[6]; }
+    }
+  });
+}
+
+int pmaf_link_force(pmaf_planner *h, int32_t pop, int32_t n, const double *link_pos, const double *k_r_force,
+                    const double *obstacles, double *out) {
+  return guarded([&] {
+    REQUIRE(h && link_pos && k_r_force && obstacles && out, "pmaf_link_force: NULL argument");
+    REQUIRE(pop >= 0 && pop < h->D.P && n >= 0, "pmaf_link_force: bad population or count");
+    if (n == 0) return;
+    const double *sent = obstacles + ((size_t)pop * h->D.n_obs + (h->D.n_obs - 1)) * 7;
+    check_range(link_pos, (size_t)n * 3, "pmaf_link_force: link_pos");
+    check_range(k_r_force, (size_t)n, "pmaf_link_force: k_r_force");
+    check_range(sent, 7, "pmaf_link_force: obstacles (last)");
+    h->use_device();
+    // per-handle scratch, grown on demand: [3n] link points | [n] gains | [7] obstacle | [3n] forces
+    const size_t need = (size_t)n * 7 + 7;
+    if (need > h->link_scratch_doubles) {
+      sync(h);
+      if (h->d_link) { (void)hipFree(h->d_link); h->d_link = nullptr; h->link_scratch_doubles = 0; }
+      if (h->h_link) { (void)hipHostFree(h->h_link); h->h_link = nullptr; }
+      const size_t cap_d = need < 512 ? 512 : need * 2;
+      HIP_CHECK(hipMalloc((void **)&h->d_link, sizeof(double) * cap_d));
+      HIP_CHECK(hipHostMalloc((void **)&h->h_link, sizeof(double) * cap_d, hipHostMallocDefault));
+      h->link_scratch_doubles = cap_d;
+    }
+    double *hb = h->h_link, *db = h->d_link;
+    std::memcpy(hb, link_pos, sizeof(double) * 3 * n);
+    std::memcpy(hb + 3 * (size_t)n, k_r_force, sizeof(double) * n);
+    std::memcpy(hb + 4 * (size_t)n, sent, sizeof(double) * 7);
+    const size_t in_d = 4 * (size_t)n + 7;
+    HIP_CHECK(hipMemcpyAsync(db, hb, sizeof(double) * in_d, hipMemcpyHostToDevice, h->stream));
+    pmaf_k_launch_link_force(n, db, db + 3 * (size_t)n, db + 4 * (size_t)n, h->D.C.rad, h->D.C.shell, db + in_d, h->stream);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipMemcpyAsync(hb + in_d, db + in_d, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, h->stream));
+    sync(h);
+    std::memcpy(out, hb + in_d, sizeof(double) * 3 * n);
+  });
+}
+
+#define GETTER_PROLOGUE(name)                    \
+  REQUIRE(h, name ": NULL handle");              \
+  h->use_device();                               \
+  sync(h);                                       \
+  const DevView &D = h->D;                       \
+  const size_t PN = (size_t)D.P * D.N;           \
+  (void)PN;
+
+int pmaf_get_paths(pmaf_planner *h, double *paths, int32_t *n_points) {
+  return guarded([&] {
+    GETTER_PROLOGUE("pmaf_get_paths")
+    std::vector<int32_t> np(PN);
+    h->download(np.data(), D.n_points, PN);
+    if (paths) {
+      h->download(paths, D.paths, PN * (size_t)D.cap * 3);
+      // entries past an agent's path end are stale device memory: report zeros
+      for (size_t pa = 0; pa < PN; pa++)
+        std::memset(paths + (pa * D.cap + np[pa]) * 3, 0, sizeof(double) * 3 * (size_t)(D.cap - np[pa]));
+    }
+    if (n_points) std::memcpy(n_points, np.data(), sizeof(int32_t) * PN);
+  });
+}
+int pmaf_get_costs(pmaf_planner *h, double *costs) {
+  return guarded([&] { GETTER_PROLOGUE("pmaf_get_costs") REQUIRE(costs, "NULL out"); h->download(costs, D.costs, PN); });
+}
+int pmaf_get_path_lengths(pmaf_planner *h, double *out) {
+  return guarded([&] {
+    GETTER_PROLOGUE("pmaf_get_path_lengths")
+    REQUIRE(out, "NULL out");
+    if (!h->cp_valid) {
+      h->cp = CostParams{};
+      h->cp.ws[0] = h->cp.ws[2] = h->cp.ws[4] = INFINITY;
+      h->cp.ws[1] = h->cp.ws[3] = h->cp.ws[5] = -INFINITY;
+    }
+    bool had = h->cp_valid;
+    ensure_scores(h);
+    if (!had) h->scores_valid = false;
+    sync(h);
+    h->download(out, D.path_len, PN);
+  });
+}
+int pmaf_get_min_obs_dist(pmaf_planner *h, double *out) {
+  return guarded([&] { GETTER_PROLOGUE("pmaf_get_min_obs_dist") REQUIRE(out, "NULL out"); h->download(out, D.min_obs, PN); });
+}
+int pmaf_get_success(pmaf_planner *h, int32_t *out) {
+  return guarded([&] { GETTER_PROLOGUE("pmaf_get_success") REQUIRE(out, "NULL out"); h->download(out, D.reached, PN); });
+}
+int pmaf_get_agent_velocities(pmaf_planner *h, double *out) {
+  return guarded([&] { GETTER_PROLOGUE("pmaf_get_agent_velocities") REQUIRE(out, "NULL out"); h->download(out, D.agent_vel, PN * 3); });
+}
+int pmaf_get_rotation_vectors(pmaf_planner *h, double *rot, int32_t *known) {
+  return guarded([&] {
+    GETTER_PROLOGUE("pmaf_get_rotation_vectors")
+    const int n_obs = D.n_obs;
+    if (rot) {
+      std::vector<double> r(PN * 3 * n_obs);
+      h->download(r.data(), D.rot, r.size());
+      for (size_t pa = 0; pa < PN; pa++)
+        for (int i = 0; i < n_obs; i++)
+          for (int c = 0; c < 3; c++) rot[(pa * n_obs + i) * 3 + c] = r[(pa * 3 + c) * n_obs + i];
+    }
+    if (known) h->download(known, D.known_out, PN * n_obs);
+  });
+}
+int pmaf_get_real_state(pmaf_planner *h, double *pos, double *vel, double *force) {
+  return guarded([&] {
+    // served from the host copy kept current by every call that changes the real
+    // agent: no wait for the running rollout (the reference's getters are instant)
+    REQUIRE(h, "pmaf_get_real_state: NULL handle");
+    const size_t n = sizeof(double) * 3 * (size_t)h->D.P;
+    if (pos) std::memcpy(pos, h->real_pos_h.data(), n);
+    if (vel) std::memcpy(vel, h->real_vel_h.data(), n);
+    if (force) std::memcpy(force, h->real_force_h.data(), n);
+  });
+}
+int pmaf_get_real_known(pmaf_planner *h, int32_t *known, double *rot) {
+  return guarded([&] {
+    GETTER_PROLOGUE("pmaf_get_real_known")
+    const int n_obs = D.n_obs;
+    if (known) h->download(known, D.real_known, (size_t)D.P * n_obs);
+    if (rot) {
+      std::vector<double> r((size_t)D.P * 3 * n_obs);
+      h->download(r.data(), D.real_rot, r.size());
+      for (int p = 0; p < D.P; p++)
+        for (int i = 0; i < n_obs; i++)
+          for (int c = 0; c < 3; c++) rot[((size_t)p * n_obs + i) * 3 + c] = r[((size_t)p * 3 + c) * n_obs + i];
+    }
+  });
+}
+int pmaf_get_real_path(pmaf_planner *h, int32_t pop, double *out, int32_t max_points, int32_t *n_total) {
+  return guarded([&] {
+    REQUIRE(h && pop >= 0 && pop < h->D.P, "pmaf_get_real_path: bad argument");
+    const std::vector<double> &rp = h->real_path[pop];
+    int n = (int)(rp.size() / 3);
+    if (n_total) *n_total = n;
+    if (out && max_points > 0) std::memcpy(out, rp.data(), sizeof(double) * 3 * (size_t)(n < max_points ? n : max_points));
+  });
+}
+int pmaf_get_dist_from_goal(pmaf_planner *h, double *out) {
+  return guarded([&] {
+    REQUIRE(h && out, "pmaf_get_dist_from_goal: NULL argument");
+    // (goal_pos_ - real.getLatestPosition()).norm(), cf_manager.h:87-89, from the
+    // host copy of the real position; same operation order as the device code
+    const std::vector<double> &rp = h->real_pos_h;
+    for (int p = 0; p < h->D.P; p++) {
+      double dx = h->goal_h[p * 3] - rp[p * 3], dy = h->goal_h[p * 3 + 1] - rp[p * 3 + 1], dz = h->goal_h[p * 3 + 2] - rp[p * 3 + 2];
+#ifdef PMAF_DOT_RIGHT_ASSOC
+      out[p] = std::sqrt(dx * dx + (dy * dy + dz * dz));
+#else
+      out[p] = std::sqrt((dx * dx + dy * dy) + dz * dz);
+#endif
+    }
+  });
+}
+int pmaf_get_best(pmaf_planner *h, int32_t *type, int32_t *id) {
+  return guarded([&] {
+    GETTER_PROLOGUE("pmaf_get_best")
+    std::vector<int32_t> hb(D.P), bt(D.P), bi(D.P);
+    h->download(hb.data(), D.has_best, D.P);
+    h->download(bt.data(), D.best_type, D.P);
+    h->download(bi.data(), D.best_id, D.P);
+    for (int p = 0; p < D.P; p++) {
+      if (type) type[p] = hb[p] ? bt[p] : -1;
+      if (id) id[p] = hb[p] ? bi[p] : 0;
+    }
+  });
+}
+int pmaf_get_prediction_times_ns(pmaf_planner *h, double *out) {
+  return guarded([&] {
+    GETTER_PROLOGUE("pmaf_get_prediction_times_ns")
+    REQUIRE(out, "NULL out");
+    // per-agent device clock (wall_clock64: constant-rate counter, rate in kHz)
+    int khz = 0;
+    HIP_CHECK(hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, h->device));
+    if (khz <= 0) khz = 100000;
+    std::vector<unsigned long long> t(PN);
+    h->download(t.data(), D.pred_ticks, PN);
+    for (size_t i = 0; i < PN; i++) out[i] = (double)t[i] * (1e6 / (double)khz);
+  });
+}
+
+int pmaf_set_best(pmaf_planner *h, const int32_t *id, const int32_t *type, const double *rand_vecs) {
+  return guarded([&] {
+    REQUIRE(h && id && type, "pmaf_set_best: NULL argument");
+    h->use_device();
+    sync(h);
+    const DevView &D = h->D;
+    std::vector<int32_t> hb(D.P);
+    for (int p = 0; p < D.P; p++) {
+      REQUIRE(id[p] >= 0 && id[p] <= D.N, "pmaf_set_best: id out of range");
+      REQUIRE(id[p] == 0 || (type[p] >= PMAF_GOAL_HEURISTIC && type[p] <= PMAF_HAD_HEURISTIC),
+              "pmaf_set_best: type must be one of the six heuristics when id > 0");
+      hb[p] = id[p] > 0;
+    }
+    h->upload(D.has_best, hb.data(), D.P);
+    h->upload(D.best_id, id, D.P);
+    h->upload(D.best_type, type, D.P);
+    if (rand_vecs) {
+      const int n_obs = D.n_obs;
+      check_range(rand_vecs, (size_t)D.P * n_obs * 3, "pmaf_set_best: rand_vecs");
+      std::vector<double> r((size_t)D.P * 3 * n_obs);
+      for (int p = 0; p < D.P; p++)
+        for (int i = 0; i < n_obs; i++)
+          for (int c = 0; c < 3; c++) r[((size_t)p * 3 + c) * n_obs + i] = rand_vecs[((size_t)p * n_obs + i) * 3 + c];
+      h->upload(D.best_rnd, r.data(), r.size());
+    }
+  });
+}
+
+size_t pmaf_winner_record_doubles(const pmaf_planner *h) { return h ? winner_rec(h) : 0; }
+
+int pmaf_write_winner_records(pmaf_planner *h, void *dst_device, size_t bytes) {
+  return guarded([&] {
+    REQUIRE(h && dst_device, "pmaf_write_winner_records: NULL argument");
+    REQUIRE(bytes >= sizeof(double) * pmaf_winner_record_doubles(h) * h->D.P, "pmaf_write_winner_records: buffer too small");
+    h->use_device();
+    pmaf_k_launch_winner(h->D, (double *)dst_device, h->stream);
+    HIP_CHECK(hipGetLastError());
+  });
+}
+
+int pmaf_allgather_winners(pmaf_planner *h, pmaf_comm *c, void *recv_device, size_t bytes) {
+  return guarded([&] {
+    REQUIRE(h && c && recv_device, "pmaf_allgather_winners: NULL argument");
+    const size_t n_local = (size_t)h->D.P * winner_rec(h);
+    REQUIRE(bytes >= sizeof(double) * n_local * (size_t)c->world, "pmaf_allgather_winners: receive buffer too small");
+    h->use_device();
+    if (!h->d_send1) HIP_CHECK(hipMalloc((void **)&h->d_send1, sizeof(double) * n_local));
+    pmaf_k_launch_winner(h->D, h->d_send1, h->stream);
+    HIP_CHECK(hipGetLastError());
+    if (c->rccl) {
+      // stream-ordered behind the pack kernel: no host synchronisation between the two
+      const std::string err = pmaf_comm_enqueue_allgather(c, h->d_send1, (double *)recv_device, n_local, h->stream);
+      if (!err.empty()) fail(PMAF_ERR_DEVICE, err);
+    } else {
+      std::vector<double> snd(n_local), rcv(n_local * (size_t)c->world);
+      h->download(snd.data(), h->d_send1, n_local);
+      if (c->fn(c->ctx, snd.data(), rcv.data(), n_local * sizeof(double)) != 0)
+        fail(PMAF_ERR_DEVICE, "pmaf_allgather_winners: the host all-gather callback failed");
+      h->upload((double *)recv_device, rcv.data(), rcv.size());
+    }
+  });
+}
+
+int pmaf_attach_comm(pmaf_planner *h, pmaf_comm *c) {
+  return guarded([&] {
+    REQUIRE(h, "pmaf_attach_comm: NULL handle");
+    h->use_device();
+    sync(h);
+    detach_comm(h);
+    if (!c) return;
+    REQUIRE(!c->rccl || c->device == h->device, "pmaf_attach_comm: the communicator lives on another device than the handle");
+    pmaf_planner::Exchange &x = h->x;
+    const size_t n_local = (size_t)h->D.P * winner_rec(h);
+    const size_t path_bytes = sizeof(double) * (size_t)h->D.P * h->D.N * h->D.cap * 3;
+    try {
+      HIP_CHECK(hipStreamCreateWithFlags(&x.xs, hipStreamNonBlocking));
+      HIP_CHECK(hipEventCreateWithFlags(&x.ev_sel, hipEventDisableTiming));
+      HIP_CHECK(hipEventCreateWithFlags(&x.ev_pack, hipEventDisableTiming));
+      HIP_CHECK(hipEventCreate(&x.ev_t0));
+      HIP_CHECK(hipEventCreate(&x.ev_t1));
+      HIP_CHECK(hipEventCreateWithFlags(&x.ev_done, hipEventDisableTiming));
+      HIP_CHECK(hipMalloc((void **)&x.d_send, sizeof(double) * n_local));
+      HIP_CHECK(hipMalloc((void **)&x.d_recv, sizeof(double) * n_local * (size_t)c->world));
+      HIP_CHECK(hipHostMalloc((void **)&x.h_send, sizeof(double) * n_local, hipHostMallocDefault));
+      HIP_CHECK(hipHostMalloc((void **)&x.h_recv, sizeof(double) * n_local * (size_t)c->world, hipHostMallocDefault));
+      HIP_CHECK(hipMalloc((void **)&x.paths_b, path_bytes));
+      HIP_CHECK(hipMemset(x.d_send, 0, sizeof(double) * n_local));
+      HIP_CHECK(hipMemset(x.d_recv, 0, sizeof(double) * n_local * (size_t)c->world));
+      std::memset(x.h_recv, 0, sizeof(double) * n_local * (size_t)c->world);
+      x.paths_a = h->D.paths;
+      x.c = c;
+    } catch (...) {
+      x.c = c;  // so that detach_comm releases what was created
+      x.paths_a = h->D.paths;
+      detach_comm(h);
+      throw;
+    }
+  });
+}
+
+int pmaf_winners_wait(pmaf_planner *h, const double **records, size_t *n_doubles) {
+  return guarded([&] {
+    REQUIRE(h, "pmaf_winners_wait: NULL handle");
+    if (!h->x.c) fail(PMAF_ERR_STATE, "pmaf_winners_wait: no communicator attached (pmaf_attach_comm)");
+    h->use_device();
+    finish_exchange(h);
+    if (records) *records = h->x.h_recv;
+    if (n_doubles) *n_doubles = (size_t)h->D.P * winner_rec(h) * (size_t)h->x.c->world;
+  });
+}
+
+void *pmaf_winners_device(pmaf_planner *h) { return h ? (void *)h->x.d_recv : nullptr; }
+
+int pmaf_get_exchange_times_us(pmaf_planner *h, double *out, int32_t max_n, int32_t *n) {
+  return guarded([&] {
+    REQUIRE(h && n, "pmaf_get_exchange_times_us: NULL argument");
+    std::vector<double> &v = h->x.ag_us;
+    const size_t k = (out && max_n > 0) ? std::min(v.size(), (size_t)max_n) : 0;
+    for (size_t i = 0; i < k; i++) out[i] = v[i];
+    *n = (int32_t)k;
+    v.clear();
+  });
+}
+
+// ---- checkpoint / resume ----------------------------------------------------
+// The blob holds every device buffer of the handle (agents' rotation vectors,
+// known flags, paths, real agent, best-agent copy, obstacle tables ...) plus
+// the host-side planner state (real agent's trajectory, scoring parameters).
+// the blob stores the handle's own buffers: with a communicator attached the current paths may live in the second
+// path buffer -- finish the exchange in flight and move them back
+static void normalise_path_buffer(pmaf_planner *h) {
+  if (!h->x.c) return;
+  finish_exchange(h);
+  if (h->D.paths != h->x.paths_a) {
+    HIP_CHECK(hipMemcpy(h->x.paths_a, h->x.paths_b, sizeof(double) * (size_t)h->D.P * h->D.N * h->D.cap * 3, hipMemcpyDeviceToDevice));
+    h->D.paths = h->x.paths_a;
+  }
+}
+
+struct StateHeader {
+  uint64_t magic;
+  int32_t abi, P, N, n_obs, cap, n_bufs;
+  int32_t cp_valid, scores_valid, rollout_pending, pad;
+  uint64_t dev_bytes;
+};
+static const uint64_t kStateMagic = 0x504d41465f535431ull;  // "PMAF_ST1"
+
+static size_t state_bytes(const pmaf_planner *h) {
+  size_t n = sizeof(StateHeader) + sizeof(CostParams) + sizeof(PopConst);
+  for (size_t b : h->alloc_bytes) n += b;
+  n += sizeof(double) * 9 * (size_t)h->D.P;                    // host mirror of the real agent
+  for (auto &rp : h->real_path) n += sizeof(uint64_t) + sizeof(double) * rp.size();
+  return n;
+}
+
+size_t pmaf_state_size(const pmaf_planner *h) { return h ? state_bytes(h) : 0; }
+
+int pmaf_save_state(pmaf_planner *h, void *blob, size_t bytes) {
+  return guarded([&] {
+    REQUIRE(h && blob, "pmaf_save_state: NULL argument");
+    REQUIRE(bytes >= state_bytes(h), "pmaf_save_state: buffer too small (see pmaf_state_size)");
+    h->use_device();
+    sync(h);
+    normalise_path_buffer(h);
+    char *w = static_cast<char *>(blob);
+    StateHeader hd{};
+    hd.magic = kStateMagic; hd.abi = PMAF_ABI_VERSION;
+    hd.P = h->D.P; hd.N = h->D.N; hd.n_obs = h->D.n_obs; hd.cap = h->D.cap; hd.n_bufs = (int32_t)h->allocs.size();
+    hd.cp_valid = h->cp_valid; hd.scores_valid = h->scores_valid; hd.rollout_pending = h->rollout_pending;
+    hd.dev_bytes = 0;
+    for (size_t b : h->alloc_bytes) hd.dev_bytes += b;
+    std::memcpy(w, &hd, sizeof(hd)); w += sizeof(hd);
+    std::memcpy(w, &h->cp, sizeof(CostParams)); w += sizeof(CostParams);
+    std::memcpy(w, &h->D.C, sizeof(PopConst)); w += sizeof(PopConst);
+    for (size_t i = 0; i < h->allocs.size(); i++) {
+      HIP_CHECK(hipMemcpyAsync(w, h->allocs[i], h->alloc_bytes[i], hipMemcpyDeviceToHost, h->stream));
+      w += h->alloc_bytes[i];
+    }
+    HIP_CHECK(hipStreamSynchronize(h->stream));
+    const size_t n3 = sizeof(double) * 3 * (size_t)h->D.P;
+    std::memcpy(w, h->real_pos_h.data(), n3); w += n3;
+    std::memcpy(w, h->real_vel_h.data(), n3); w += n3;
+    std::memcpy(w, h->real_force_h.data(), n3); w += n3;
+    for (auto &rp : h->real_path) {
+      uint64_t n = rp.size();
+      std::memcpy(w, &n, sizeof(n)); w += sizeof(n);
+      std::memcpy(w, rp.data(), sizeof(double) * n); w += sizeof(double) * n;
+    }
+  });
+}
+
+int pmaf_load_state(pmaf_planner *h, const void *blob, size_t bytes) {
+  return guarded([&] {
+    REQUIRE(h && blob, "pmaf_load_state: NULL argument");
+    REQUIRE(bytes >= sizeof(StateHeader) + sizeof(CostParams) + sizeof(PopConst), "pmaf_load_state: blob too small");
+    const char *r = static_cast<const char *>(blob);
+    StateHeader hd;
+    std::memcpy(&hd, r, sizeof(hd)); r += sizeof(hd);
+    uint64_t dev = 0;
+    for (size_t b : h->alloc_bytes) dev += b;
+    REQUIRE(hd.magic == kStateMagic && hd.abi == PMAF_ABI_VERSION, "pmaf_load_state: not a pmaf state blob of this ABI version");
+    REQUIRE(hd.P == h->D.P && hd.N == h->D.N && hd.n_obs == h->D.n_obs && hd.cap == h->D.cap &&
+                hd.n_bufs == (int32_t)h->allocs.size() && hd.dev_bytes == dev,
+            "pmaf_load_state: blob was saved from a handle with different dimensions");
+    REQUIRE(bytes >= sizeof(StateHeader) + sizeof(CostParams) + sizeof(PopConst) + dev + sizeof(double) * 9 * (size_t)h->D.P,
+            "pmaf_load_state: blob truncated");
+    h->use_device();
+    sync(h);
+    normalise_path_buffer(h);
+    std::memcpy(&h->cp, r, sizeof(CostParams)); r += sizeof(CostParams);
+    std::memcpy(&h->D.C, r, sizeof(PopConst)); r += sizeof(PopConst);
+    for (size_t i = 0; i < h->allocs.size(); i++) {
+      HIP_CHECK(hipMemcpyAsync(h->allocs[i], r, h->alloc_bytes[i], hipMemcpyHostToDevice, h->stream));
+      r += h->alloc_bytes[i];
+    }
+    HIP_CHECK(hipStreamSynchronize(h->stream));
+    h->download(h->goal_h.data(), h->D.goal, (size_t)h->D.P * 3);  // host copy of the goals
+    const size_t n3 = sizeof(double) * 3 * (size_t)h->D.P;
+    std::memcpy(h->real_pos_h.data(), r, n3); r += n3;
+    std::memcpy(h->real_vel_h.data(), r, n3); r += n3;
+    std::memcpy(h->real_force_h.data(), r, n3); r += n3;
+    const char *end = static_cast<const char *>(blob) + bytes;
+    for (auto &rp : h->real_path) {
+      uint64_t n = 0;
+      REQUIRE(r + sizeof(n) <= end, "pmaf_load_state: blob truncated");
+      std::memcpy(&n, r, sizeof(n)); r += sizeof(n);
+      REQUIRE(r + sizeof(double) * n <= end, "pmaf_load_state: blob truncated");
+      rp.assign(reinterpret_cast<const double *>(r), reinterpret_cast<const double *>(r) + n);
+      r += sizeof(double) * n;
+    }
+    h->cp_valid = hd.cp_valid != 0;
+    h->scores_valid = hd.scores_valid != 0;
+    h->rollout_pending = hd.rollout_pending != 0;
+  });
+}
+
+void *pmaf_stream(pmaf_planner *h) { return h ? (void *)h->stream : nullptr; }
+
+int pmaf_set_profiling(pmaf_planner *h, int32_t enable) {
+  return guarded([&] {
+    REQUIRE(h, "pmaf_set_profiling: NULL handle");
+    h->use_device();
+    sync(h);
+    h->profiling = enable != 0;
+  });
+}
+int pmaf_get_kernel_stats(pmaf_planner *h, double *rollout_ms, int64_t *launches, int64_t *agent_steps) {
+  return guarded([&] {
+    GETTER_PROLOGUE("pmaf_get_kernel_stats")
+    if (rollout_ms) *rollout_ms = h->rollout_ms;
+    if (launches) *launches = h->profiling ? h->timed_launches : h->launches;
+    if (agent_steps) {
+      unsigned long long s = 0;
+      h->download(&s, D.step_counter, 1);
+      *agent_steps = (int64_t)s;
+    }
+  });
+}
+int pmaf_reset_kernel_stats(pmaf_planner *h) {
+  return guarded([&] {
+    REQUIRE(h, "pmaf_reset_kernel_stats: NULL handle");
+    h->use_device();
+    sync(h);
+    h->rollout_ms = 0.0;
+    h->launches = 0;
+    h->timed_launches = 0;
+    HIP_CHECK(hipMemsetAsync(h->D.step_counter, 0, sizeof(unsigned long long), h->stream));
+    sync(h);
+  });
+}
+int pmaf_debug_math(int32_t op, int32_t n, const double *a, const double *b, double *out) {
+  return guarded([&] {
+    REQUIRE(a && b && out && n > 0 && op >= 0 && op <= 10, "pmaf_debug_math: bad argument");
+    double *da = nullptr, *db = nullptr, *dout = nullptr;
+    HIP_CHECK(hipMalloc((void **)&da, sizeof(double) * n));
+    HIP_CHECK(hipMalloc((void **)&db, sizeof(double) * n));
+    HIP_CHECK(hipMalloc((void **)&dout, sizeof(double) * n));
+    HIP_CHECK(hipMemcpy(da, a, sizeof(double) * n, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(db, b, sizeof(double) * n, hipMemcpyHostToDevice));
+    pmaf_k_launch_debug_math(op, n, da, db, dout, nullptr);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipMemcpy(out, dout, sizeof(double) * n, hipMemcpyDeviceToHost));
+    (void)hipFree(da); (void)hipFree(db); (void)hipFree(dout);
+  });
+}
+
+int pmaf_get_launch_config(pmaf_planner *h, int32_t *lanes_per_agent, int32_t *n_blocks, int32_t *lds_bytes) {
+  return guarded([&] {
+    REQUIRE(h, "pmaf_get_launch_config: NULL handle");
+    if (lanes_per_agent) *lanes_per_agent = h->lpa;
+    if (n_blocks) *n_blocks = h->n_blocks * h->D.P;
+    if (lds_bytes) *lds_bytes = (int32_t)h->lds_rollout;
+  });
+}
+
+}  // extern "C"
+

@@ -1,0 +1,187 @@
+// pmaf_k_grp.hip -- k_rollout_grp<LPA, TILES, MATH>: 8/16/32 lanes per agent (throughput shape: C5) and its launcher.
+// Compiled once per arithmetic policy (-DPMAF_GRP_MATH=0|2; the opt-in fast arithmetic exists for the w64 kernels only).
+#include <hip/hip_runtime.h>
+
+#include "pmaf_types.hpp"
+#include "pmaf_device.hpp"
+#include "pmaf_rollout_w64.hpp"
+#include "pmaf_rollout_grp.hpp"
+
+using namespace pmaf;
+
+// ---------------------------------------------------------------------------
+// k_rollout_grp<LPA, TILES>: 64/LPA agents per wave (see pmaf_rollout_grp.hpp)
+// ---------------------------------------------------------------------------
+// SIMD sharing in the group kernel (launches of more waves than the device has SIMDs), measured on C5 = 2048 waves:
+// * block b and block b + n_simds land on the same SIMD (tools/placement.hip), and the issue arbiter serves the older
+//   wave first: the first 1024 waves ran at their stand-alone speed (600 us), the others on the issue slots left over
+//   and then alone (880-1000 us; kernel 1010 us). The waves therefore trade issue priority in 10 us slices of the
+//   wall clock, the younger wave holding it 5 slices of 8 (the share at which both finish together: 845 us each,
+//   kernel 910 us; 4 of 8: 720 / 860, 6 of 8: 860 / 750).
+// * every population's first two waves hold its five heuristic agents (mixed types: the wave runs the union of their
+//   code paths, 1.13x the work of a wave of Random agents), and b + n_simds is the same wave index of another
+//   population: the wave index is rotated by 8 per population so that two such waves do not share a SIMD (-3 %).
+constexpr int PRIO_SLICE_LOG2 = 10;       // 2^10 ticks of the 100 MHz wall clock
+constexpr unsigned PRIO_YOUNGER_OF_8 = 5;
+constexpr unsigned POP_ROTATE = 8;
+template <int LPA, int TILES, int MATH>
+__global__ __launch_bounds__(64) void k_rollout_grp(DevView D, CostParams CP) {
+  extern __shared__ double smem[];
+  constexpr int APW = 64 / LPA;
+  const unsigned long long t_begin = wall_clock64();
+  const int lane = threadIdx.x;
+  const int pop = blockIdx.y;
+  const int sub = lane % LPA;
+  const int grp = lane / LPA;
+  const int bx = (int)((blockIdx.x + gridDim.x - (POP_ROTATE * blockIdx.y) % gridDim.x) % gridDim.x);  // see above
+  const int a = bx * APW + grp;
+  const bool active = a < D.N;
+  const int aa = active ? a : 0;
+  const int n_obs = D.n_obs;
+  const int M = n_obs - 1;
+  const PopConst C = D.C;
+  const size_t pa = (size_t)pop * D.N + aa;
+  const int type = D.types[aa];
+  const double *src = D.obs_start + (size_t)pop * 7 * n_obs;
+  const int32_t *ks = D.known_start + (size_t)pop * n_obs;
+  double *rot_g = D.rot + pa * 3 * n_obs;
+  const double *rnd_g = D.rnd + pa * 3 * n_obs;
+
+  LaneObstacles<TILES> O;
+  unsigned known_bits = 0u;
+#pragma unroll
+  for (int t = 0; t < TILES; t++) {
+    int i = t * LPA + sub;
+    bool valid = i < M;
+    int ii = valid ? i : 0;
+    O.p[t] = mk(src[ii], src[n_obs + ii], src[2 * n_obs + ii]);
+    O.v[t] = mk(src[3 * n_obs + ii], src[4 * n_obs + ii], src[5 * n_obs + ii]);
+    O.r[t] = src[6 * n_obs + ii];
+    O.rx[t] = rot_g[ii]; O.ry[t] = rot_g[n_obs + ii]; O.rz[t] = rot_g[2 * n_obs + ii];
+    O.qx[t] = rnd_g[ii]; O.qy[t] = rnd_g[n_obs + ii]; O.qz[t] = rnd_g[2 * n_obs + ii];
+    if (valid && ks[ii]) known_bits |= (1u << t);
+  }
+  V3 sent_p = mk(src[M], src[n_obs + M], src[2 * n_obs + M]);
+  const V3 sent_v = mk(src[3 * n_obs + M], src[4 * n_obs + M], src[5 * n_obs + M]);
+  const double sent_r = src[6 * n_obs + M];
+  wave_lds_fence();
+
+  const V3 goal = mk(D.goal[pop * 3], D.goal[pop * 3 + 1], D.goal[pop * 3 + 2]);
+  const V3 init_pos = mk(D.agent_init_pos[pop * 3], D.agent_init_pos[pop * 3 + 1], D.agent_init_pos[pop * 3 + 2]);
+  V3 p = mk(D.start_pos[pop * 3], D.start_pos[pop * 3 + 1], D.start_pos[pop * 3 + 2]);
+  V3 v = mk(D.start_vel[pop * 3], D.start_vel[pop * 3 + 1], D.start_vel[pop * 3 + 2]);
+  const double k_attr = D.k_attr[pa], k_circ = D.k_circ[pa], k_repel = D.k_repel[pa], k_damp = D.k_damp[pa];
+  double *path = D.paths + pa * (size_t)D.cap * 3;
+  const double zsent_lt = D.zsent_lt[pop];
+  const bool sent_reachable = __any(sentinel_reachable(p, sent_p, sent_v, zsent_lt, C, D.cap));  // wave-uniform
+  bool moving = false;
+#pragma unroll
+  for (int t = 0; t < TILES; t++) moving = moving || !(O.v[t].x == 0.0 && O.v[t].y == 0.0 && O.v[t].z == 0.0);
+  moving = __any(moving);
+  bool advance = true;
+
+  int clist_off = 7 * n_obs + (n_obs + 1) / 2;
+  clist_off += clist_off & 1;
+  double *clist = smem + clist_off + (size_t)grp * ((LPA * TILES + 1) * 4);
+  if (sub < 4) clist[(size_t)LPA * TILES * 4 + sub] = 0.0;  // the group's all-zero list entry
+  wave_lds_fence();
+
+  double lane_min = C.shell;
+  int n = 1;
+  bool ran = false;
+  if (active && sub == 0) { path[0] = p.x; path[1] = p.y; path[2] = p.z; }
+
+  V3 g = goal - p;
+  double dg = Mth<MATH>::norm(g);
+  double zv = sqn(v);
+  double z_init = sqn(p - init_pos);
+  const unsigned lin_block = blockIdx.y * gridDim.x + blockIdx.x;
+  const bool shared_simd = gridDim.x * gridDim.y > (unsigned)D.n_simds;
+  const bool younger = ((lin_block / (unsigned)D.n_simds) & 1u) != 0u;
+  while (true) {
+    const bool run = active && (dg > 0.1) && (n < D.cap);  // B/src/cf_agent.cpp:310-311, per agent
+    if (!__any(run)) break;
+    unsigned long long clk = 0ull;
+    if (shared_simd) clk = wall_clock64();
+    const bool gate = !(dg < C.approach || (zv < C.zvhalf_lt && z_init < C.zinit_lt));  // :315-317
+    const V3 verr = attractor_velocity_error<MATH>(v, g, C, k_attr, k_damp);
+    V3 F = mk(0.0, 0.0, 0.0);
+    double scale = 1.0;
+    if (__any(run && gate))
+      circ_and_scale_grp<LPA, TILES, MATH>(run && gate, sub, grp, type, p, v, zv, goal, g, dg, C, k_circ, n_obs, rot_g,
+                                     known_bits, O, clist, lane_min, F, scale);
+    V3 new_pos;
+    V3 nv = v;
+    finish_step_w64<MATH>(p, nv, verr, F, scale, C, k_attr, k_repel, k_damp, sent_p, sent_r, zsent_lt, new_pos,
+                          sent_reachable);
+    if (run) {
+      p = new_pos;
+      v = nv;
+      g = goal - p;
+      dg = Mth<MATH>::norm(g);
+      zv = sqn(v);
+      z_init = sqn(p - init_pos);
+      if (sub == 0) { path[n * 3] = p.x; path[n * 3 + 1] = p.y; path[n * 3 + 2] = p.z; }
+      n++;
+      ran = true;
+    }
+    // predictObstacles, B/src/cf_agent.cpp:270-276, in registers (obstacles at rest: once, see the w64 kernel)
+    if (advance) {
+#pragma unroll
+      for (int t = 0; t < TILES; t++) O.p[t] = O.p[t] + O.v[t] * C.dt;
+      advance = moving;
+    }
+    if (sent_reachable) sent_p = sent_p + sent_v * C.dt;
+    if (shared_simd) {
+      if (((((unsigned)(clk >> PRIO_SLICE_LOG2)) & 7u) < PRIO_YOUNGER_OF_8) == younger) __builtin_amdgcn_s_setprio(1);
+      else __builtin_amdgcn_s_setprio(0);
+    }
+  }
+  __builtin_amdgcn_s_setprio(0);
+
+  double cost_ws, path_len;
+  path_cost_terms_grp<LPA, MATH>(sub, grp, active, path, n, CP.ws, CP.k_workspace, clist, cost_ws, path_len);
+
+  const double min_obs = group_min_dpp<LPA>(lane_min);
+  if (active) {
+    int32_t *ko = D.known_out + pa * n_obs;
+#pragma unroll
+    for (int t = 0; t < TILES; t++) {
+      int i = t * LPA + sub;
+      if (i < M) ko[i] = (int32_t)((known_bits >> t) & 1u);
+    }
+    if (sub == 0) {
+      ko[M] = ks[M];
+      D.n_points[pa] = n;
+      D.agent_vel[pa * 3] = v.x; D.agent_vel[pa * 3 + 1] = v.y; D.agent_vel[pa * 3 + 2] = v.z;
+      D.min_obs[pa] = min_obs;
+      D.cost_ws[pa] = cost_ws;
+      D.path_len[pa] = path_len;
+      D.goal_dist[pa] = dg;
+      if (ran) D.reached[pa] = dg < 0.100001;  // B/src/cf_agent.cpp:330-337
+      atomicAdd(D.step_counter, (unsigned long long)(n - 1));
+      D.pred_ticks[pa] = wall_clock64() - t_begin;
+    }
+  }
+}
+
+
+#ifndef PMAF_GRP_MATH
+#error "compile with -DPMAF_GRP_MATH=0|2"
+#endif
+#define PMAF_CAT2(a, b) a##b
+#define PMAF_CAT(a, b) PMAF_CAT2(a, b)
+bool PMAF_CAT(pmaf_k_launch_grp_m, PMAF_GRP_MATH)(const DevView &D, const CostParams &cp, int lpa, int tiles,
+                                                  int n_blocks, size_t lds, hipStream_t s) {
+  const dim3 grid((unsigned)n_blocks, (unsigned)D.P), block(64);
+#define PMAF_GRP(L, T) hipLaunchKernelGGL((k_rollout_grp<L, T, PMAF_GRP_MATH>), grid, block, lds, s, D, cp)
+#define PMAF_GRP_T(L) do { if (tiles <= 1) PMAF_GRP(L, 1); else if (tiles == 2) PMAF_GRP(L, 2); else PMAF_GRP(L, 4); } while (0)
+  if (tiles > 4) return false;
+  if (lpa == 32) PMAF_GRP_T(32);
+  else if (lpa == 16) PMAF_GRP_T(16);
+  else if (lpa == 8) PMAF_GRP_T(8);
+  else return false;
+#undef PMAF_GRP_T
+#undef PMAF_GRP
+  return true;
+}

@@ -1,0 +1,606 @@
+// pmaf_k_misc.hip -- the remaining kernels of libpmaf_hip.so and the launch interface of pmaf_types.hpp:
+//   k_rollout<LPA>  generic agent x horizon rollout (CfAgent::cfPrediction, B/src/cf_agent.cpp:302-341): any
+//                   lanes-per-agent mapping, obstacle table in LDS advanced once per step (fallback shape).
+//   k_manager       one wave per population: evaluateAgents' cost assembly + argmin + hysteresis
+//                   (B/src/cf_manager.cpp:325-353), RealCfAgent::cfPlanner single step (B/src/cf_agent.cpp:343-366)
+//                   and resetEEAgents (B/src/cf_manager.cpp:246-255).
+//   k_score         re-scores stored paths (before the first rollout / other workspace gains).
+//   k_link_force    CfAgent::bodyForce (B/src/cf_agent.cpp:229-234).
+//   k_winner        packs winner records for sharded runs.
+#include <hip/hip_runtime.h>
+
+#include "pmaf_types.hpp"
+#include "pmaf_device.hpp"
+#include "pmaf_rollout_w64.hpp"
+#include "pmaf_rollout_grp.hpp"
+
+using namespace pmaf;
+
+// ---------------------------------------------------------------------------
+// k_rollout
+// ---------------------------------------------------------------------------
+template <int LPA>
+__global__ __launch_bounds__(64) void k_rollout(DevView D, CostParams CP) {
+  extern __shared__ double smem[];
+  const int lane = threadIdx.x;
+  const int pop = blockIdx.y;
+  constexpr int APW = 64 / LPA;  // agents per wave
+  const int sub = lane % LPA;
+  const int grp = lane / LPA;
+  const int a = blockIdx.x * APW + grp;
+  const bool active = a < D.N;
+  const int aa = active ? a : 0;
+  const int n_obs = D.n_obs;
+  const PopConst C = D.C;
+  const unsigned long long t_begin = wall_clock64();
+
+  ObsTab T = carve_obstab(smem, n_obs);
+  int32_t *s_known = reinterpret_cast<int32_t *>(smem + 7 * n_obs);
+  {
+    const double *src = D.obs_start + (size_t)pop * 7 * n_obs;
+    for (int i = lane; i < 7 * n_obs; i += 64) smem[i] = src[i];
+    const int32_t *ks = D.known_start + (size_t)pop * n_obs;
+    for (int i = lane; i < n_obs; i += 64) s_known[i] = ks[i];
+  }
+  __syncthreads();
+
+  const size_t pa = (size_t)pop * D.N + aa;
+  const V3 goal = mk(D.goal[pop * 3], D.goal[pop * 3 + 1], D.goal[pop * 3 + 2]);
+  const V3 init_pos = mk(D.agent_init_pos[pop * 3], D.agent_init_pos[pop * 3 + 1], D.agent_init_pos[pop * 3 + 2]);
+  V3 p = mk(D.start_pos[pop * 3], D.start_pos[pop * 3 + 1], D.start_pos[pop * 3 + 2]);
+  V3 v = mk(D.start_vel[pop * 3], D.start_vel[pop * 3 + 1], D.start_vel[pop * 3 + 2]);
+  const double k_attr = D.k_attr[pa], k_circ = D.k_circ[pa], k_repel = D.k_repel[pa], k_damp = D.k_damp[pa];
+  const int type = D.types[aa];
+  double *rot_g = D.rot + pa * 3 * n_obs;
+  const double *rnd_g = D.rnd + pa * 3 * n_obs;
+  double *path = D.paths + pa * (size_t)D.cap * 3;
+
+  const int M = n_obs - 1;
+  const int ntiles = (M + LPA - 1) / LPA;
+  unsigned long long known_bits = 0ull;
+  for (int t = 0; t < ntiles; t++) {
+    int i = t * LPA + sub;
+    if (i < M && s_known[i]) known_bits |= (1ull << t);
+  }
+
+  double min_obs = C.shell;
+  double cost_ws = 0.0;
+  double path_len = 0.0;
+  int n = 1;
+  bool ran = false;
+  ws_cost_add(cost_ws, p, CP.ws, CP.k_workspace);
+  if (active && sub == 0) { path[0] = p.x; path[1] = p.y; path[2] = p.z; }
+
+  while (true) {
+    V3 g = goal - p;
+    double dg = norm(g);
+    bool run = active && (dg > 0.1) && (n < D.cap);
+    if (!__any(run)) break;
+    // gate, B/src/cf_agent.cpp:315-317
+    bool gate = !(dg < C.approach || (norm(v) < 0.5 * C.vel_max && norm(p - init_pos) < 0.2));
+    V3 F = mk(0.0, 0.0, 0.0);
+    double scale = 1.0;
+    circ_and_scale<LPA, false>(run && gate, sub, grp, type, p, v, goal, g, C, k_circ, T, n_obs, rot_g,
+                               rnd_g, known_bits, min_obs, F, scale);
+    V3 new_pos;
+    V3 nv = v;
+    finish_step(p, nv, g, F, scale, C, k_attr, k_repel, k_damp, C.dt, T.pos(n_obs - 1), T.r[n_obs - 1], new_pos);
+    if (run) {
+      path_len += norm(new_pos - p);
+      p = new_pos;
+      v = nv;
+      ws_cost_add(cost_ws, p, CP.ws, CP.k_workspace);
+      if (sub == 0) { path[n * 3] = p.x; path[n * 3 + 1] = p.y; path[n * 3 + 2] = p.z; }
+      n++;
+      ran = true;
+    }
+    // predictObstacles, B/src/cf_agent.cpp:270-276 (shared copy, once per step)
+    __syncthreads();
+    for (int i = lane; i < n_obs; i += 64) {
+      T.px[i] = T.px[i] + T.vx[i] * C.dt;
+      T.py[i] = T.py[i] + T.vy[i] * C.dt;
+      T.pz[i] = T.pz[i] + T.vz[i] * C.dt;
+    }
+    __syncthreads();
+  }
+
+  if (active) {
+    // known_obstacles_ of this agent after the rollout (getter only)
+    int32_t *ko = D.known_out + pa * n_obs;
+    for (int t = 0; t < ntiles; t++) {
+      int i = t * LPA + sub;
+      if (i < M) ko[i] = (int32_t)((known_bits >> t) & 1ull);
+    }
+    if (sub == 0) {
+      ko[M] = s_known[M];
+      D.n_points[pa] = n;
+      D.agent_vel[pa * 3] = v.x; D.agent_vel[pa * 3 + 1] = v.y; D.agent_vel[pa * 3 + 2] = v.z;
+      D.min_obs[pa] = min_obs;
+      D.cost_ws[pa] = cost_ws;
+      D.path_len[pa] = path_len;
+      double dgf = norm(goal - p);
+      D.goal_dist[pa] = dgf;
+      if (ran) D.reached[pa] = dgf < 0.100001;  // B/src/cf_agent.cpp:330-337
+      atomicAdd(D.step_counter, (unsigned long long)(n - 1));
+      D.pred_ticks[pa] = wall_clock64() - t_begin;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// k_score: cost terms from stored paths (one thread per agent)
+// ---------------------------------------------------------------------------
+__global__ void k_score(DevView D, CostParams CP) {
+  int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= D.P * D.N) return;
+  int pop = idx / D.N;
+  const double *path = D.paths + (size_t)idx * D.cap * 3;
+  int n = D.n_points[idx];
+  double cost = 0.0, len = 0.0;
+  V3 prev = mk(path[0], path[1], path[2]);
+  ws_cost_add(cost, prev, CP.ws, CP.k_workspace);
+  for (int k = 1; k < n; k++) {
+    V3 q = mk(path[k * 3], path[k * 3 + 1], path[k * 3 + 2]);
+    ws_cost_add(cost, q, CP.ws, CP.k_workspace);
+    len += norm(q - prev);
+    prev = q;
+  }
+  V3 goal = mk(D.goal[pop * 3], D.goal[pop * 3 + 1], D.goal[pop * 3 + 2]);
+  D.cost_ws[idx] = cost;
+  D.path_len[idx] = len;
+  D.goal_dist[idx] = norm(goal - prev);
+}
+
+// ---------------------------------------------------------------------------
+// k_manager: evaluate / real step / reset, one wave per population
+// ---------------------------------------------------------------------------
+// RealCfAgent::cfPlanner, ONE step (B/src/cf_agent.cpp:343-366), with the tuned
+// wave-per-agent step functions: the live obstacles, the real agent's rotation
+// vectors and known flags sit in this wave's registers exactly as an agent's do
+// in k_rollout_w64 (the generic LDS-table path took 7 us per call, this one
+// is the same code the rollout spends ~2 us per step in). No min_obs_dist_
+// tracking (RealCfAgent::circForce :110-144), heuristic = the stored best agent's.
+template <int TILES>
+__device__ __forceinline__ void real_step_w64(const DevView &D, const double dt_real, const int pop, const int lane,
+                                              const int htype, const double *live, const int32_t *s_known,
+                                              double *rot_g, const double *rand_g, double *clist, const double k_attr,
+                                              const double k_circ, const double k_repel, const double k_damp,
+                                              const V3 goal, const V3 init_pos, V3 &rp, V3 &rv, V3 &F_total,
+                                              unsigned &known_bits) {
+  typedef Mth<MATH_XACT> MT;
+  PopConst C = D.C;
+  C.dt = dt_real;
+  const int n_obs = D.n_obs, M = n_obs - 1;
+  LaneObstacles<TILES> O;
+  known_bits = 0u;
+#pragma unroll
+  for (int t = 0; t < TILES; t++) {
+    const int i = t * 64 + lane;
+    const bool valid = i < M;
+    const int ii = valid ? i : 0;
+    O.p[t] = mk(live[ii], live[n_obs + ii], live[2 * n_obs + ii]);
+    O.v[t] = mk(live[3 * n_obs + ii], live[4 * n_obs + ii], live[5 * n_obs + ii]);
+    O.r[t] = live[6 * n_obs + ii];
+    O.rx[t] = rot_g[ii]; O.ry[t] = rot_g[n_obs + ii]; O.rz[t] = rot_g[2 * n_obs + ii];
+    O.qx[t] = rand_g[ii]; O.qy[t] = rand_g[n_obs + ii]; O.qz[t] = rand_g[2 * n_obs + ii];
+    if (valid && s_known[ii]) known_bits |= (1u << t);
+  }
+  const V3 sent_p = mk(live[M], live[n_obs + M], live[2 * n_obs + M]);
+  const double sent_r = live[6 * n_obs + M];
+  const V3 g = goal - rp;
+  const double dg = MT::norm(g);
+  const double zv = sqn(rv);
+  const double z_init = sqn(rp - init_pos);
+  const bool gate = !(dg < C.approach || (zv < C.zvhalf_lt && z_init < C.zinit_lt));  // :347-349
+  const V3 gn = (dg > 0.0) ? MT::div3(g, dg) : g;
+  const V3 verr = attractor_velocity_error<MATH_XACT>(rv, g, C, k_attr, k_damp);
+  const V3 repel = sentinel_repel_live(rp, C, k_repel, sent_p, sent_r);  // live radius (the caller's list)
+  V3 F = mk(0.0, 0.0, 0.0);
+  double scale = 1.0, no_min = C.shell;
+  SecTimers ST;
+  if (gate)
+    circ_and_scale_w64<TILES, T_REAL, MATH_XACT>(lane, rp, rv, zv, goal, g, dg, gn, C, k_circ, n_obs, rot_g, known_bits,
+                                                 O, clist, no_min, F, scale, ST, exp_consts(), 0, htype);
+  F = F + (mk(0.0, 0.0, 0.0) + repel);
+  if (k_attr != 0.0) F = F + (scale * k_damp) * verr;
+  F_total = F;
+  V3 acc = F;
+  if (C.mass != 1.0) acc = F / C.mass;
+  const double az = sqn(acc);
+  if (az >= C.zacc_gt) acc = acc * (13.0 / __builtin_sqrt(az));
+  const V3 half = ((0.5 * acc) * C.dt) * C.dt;
+  const V3 new_pos = (rp + half) + (rv * C.dt);
+  const V3 nv = rv + acc * C.dt;
+  double vn, rvn;
+  MT::norm_rcp(nv, vn, rvn);
+  const V3 cl = nv * MT::div_n(C.vel_max, vn, rvn);
+  rv = (vn > C.vel_max) ? cl : nv;
+  rp = new_pos;
+}
+
+
+// Latency matters here (the set-point reaches the host when this kernel is
+// done): everything that does not depend on the selection is loaded up front
+// (per-agent results, the real agent's state, the live obstacles), the values
+// that lanes exchange (costs, known flags, the obstacle table) go through LDS,
+// not global memory, and the host-visible outputs are written before the
+// agents' reset stores. The dependent global round trips on the critical path
+// are: results -> (selected agent's type and gains) -> rotation vectors of the
+// obstacles inside the real agent's shell.
+__global__ __launch_bounds__(64) void k_manager(DevView D, CostParams CP, ManagerArgs A) {
+  extern __shared__ double smem[];
+  const int lane = threadIdx.x;
+  const int pop = blockIdx.x;
+  const int n_obs = D.n_obs;
+  const int N = D.N;
+  const int M = n_obs - 1;
+  const PopConst C = D.C;
+  // LDS: live obstacle table [7][n_obs] | known flags [n_obs] i32 | costs [N]
+  ObsTab T = carve_obstab(smem, n_obs);
+  int32_t *s_known = reinterpret_cast<int32_t *>(smem + 7 * n_obs);
+  double *s_cost = smem + 7 * n_obs + (n_obs + 1) / 2;
+
+  // ---- loads that depend on nothing ----
+  const V3 goal = mk(D.goal[pop * 3], D.goal[pop * 3 + 1], D.goal[pop * 3 + 2]);
+  int best = D.best_idx[pop];
+  const int had_best = D.has_best[pop];
+  const int old_best_id = D.best_id[pop];
+  int htype = D.best_type[pop];
+  V3 rp = mk(D.real_pos[pop * 3], D.real_pos[pop * 3 + 1], D.real_pos[pop * 3 + 2]);
+  V3 rv = mk(D.real_vel[pop * 3], D.real_vel[pop * 3 + 1], D.real_vel[pop * 3 + 2]);
+  V3 rf = mk(D.real_force[pop * 3], D.real_force[pop * 3 + 1], D.real_force[pop * 3 + 2]);
+  const V3 init_pos = mk(D.real_init_pos[pop * 3], D.real_init_pos[pop * 3 + 1], D.real_init_pos[pop * 3 + 2]);
+  int32_t *rk = D.real_known + (size_t)pop * n_obs;
+  // live obstacles: read straight from the caller's pinned staging buffer when the tick brought new ones (1.8 KB
+  // over PCIe costs less than a copy command in front of this kernel) and kept in D.obs_live for later calls
+  double *live_dev = D.obs_live + (size_t)pop * 7 * n_obs;
+  const double *live = A.live_src ? A.live_src + (size_t)pop * 7 * n_obs : live_dev;
+  if (A.do_move || A.do_reset) {
+    for (int i = lane; i < 7 * n_obs; i += 64) {
+      const double x = live[i];
+      smem[i] = x;
+      if (A.live_src) live_dev[i] = x;
+    }
+    for (int i = lane; i < n_obs; i += 64) s_known[i] = rk[i];
+  }
+  // random vectors the real agent's heuristic uses (best_agent_'s copy)
+  const double *rand_g = D.best_rnd + (size_t)pop * 3 * n_obs;
+
+  if (A.do_select) {
+    // cost assembly + argmin, B/src/cf_manager.cpp:325-343
+    double lmin = 1.7976931348623157e308;
+    int lidx = 0x7fffffff;
+    for (int a = lane; a < N; a += 64) {
+      size_t pa = (size_t)pop * N + a;
+      double cost = D.cost_ws[pa];
+      double gd = D.goal_dist[pa];
+      if (gd > C.approach) cost += gd * CP.k_goal_dist;
+      cost += D.path_len[pa] * CP.k_path_len;
+      double mo = D.min_obs[pa];
+      cost += CP.k_safe_dist / mo;
+      if (mo < 2e-5) cost += 10000.0;
+      D.costs[pa] = cost;
+      s_cost[a] = cost;
+      if (cost < lmin) { lmin = cost; lidx = a; }
+    }
+    group_argmin<64>(lmin, lidx);
+    int min_idx = (lidx == 0x7fffffff) ? 0 : lidx;
+    wave_lds_fence();  // costs visible to the whole wave
+    // hysteresis, :344-353
+    bool take;
+    if (had_best) {
+      int bi = old_best_id - 1;
+      double cb = s_cost[bi];
+      double cm = s_cost[min_idx];
+      if (cm < 0.9 * cb) take = true;
+      else { take = false; min_idx = bi; }
+    } else {
+      take = true;
+    }
+    if (take) {  // best_agent_ = makeCopy()
+      const double *src = D.rnd + ((size_t)pop * N + min_idx) * 3 * n_obs;
+      double *dst = D.best_rnd + (size_t)pop * 3 * n_obs;
+      for (int i = lane; i < 3 * n_obs; i += 64) dst[i] = src[i];
+      rand_g = src;  // same values; the copy need not have landed
+      htype = D.types[min_idx];
+      if (lane == 0) {
+        D.has_best[pop] = 1;
+        D.best_id[pop] = min_idx + 1;
+        D.best_type[pop] = htype;
+      }
+    }
+    best = min_idx;
+    if (lane == 0) D.best_idx[pop] = best;
+  }
+
+  if (A.do_move) {
+    // RealCfAgent::cfPlanner one step, B/src/cf_agent.cpp:343-366
+    int gid = A.agent_id ? A.agent_id[pop] : best;
+    size_t pg = (size_t)pop * N + gid;
+    double k_attr = D.k_attr[pg], k_circ = D.k_circ[pg], k_repel = D.k_repel[pg], k_damp = D.k_damp[pg];
+    wave_lds_fence();  // obstacle table + known flags in LDS
+    const int ntiles = (M + 63) / 64;
+    unsigned long long kb = 0ull;
+    V3 F = mk(0.0, 0.0, 0.0);
+    if (A.tuned_real_step && ntiles <= 4) {
+      double *rrot = D.real_rot + (size_t)pop * 3 * n_obs;
+      double *clist = s_cost + N + (N & 1);
+      unsigned kb32 = 0u;
+      if (ntiles <= 1)
+        real_step_w64<1>(D, A.dt_real, pop, lane, htype, smem, s_known, rrot, rand_g, clist, k_attr, k_circ, k_repel,
+                         k_damp, goal, init_pos, rp, rv, F, kb32);
+      else if (ntiles == 2)
+        real_step_w64<2>(D, A.dt_real, pop, lane, htype, smem, s_known, rrot, rand_g, clist, k_attr, k_circ, k_repel,
+                         k_damp, goal, init_pos, rp, rv, F, kb32);
+      else
+        real_step_w64<4>(D, A.dt_real, pop, lane, htype, smem, s_known, rrot, rand_g, clist, k_attr, k_circ, k_repel,
+                         k_damp, goal, init_pos, rp, rv, F, kb32);
+      kb = kb32;
+    } else {
+      for (int t = 0; t < ntiles; t++) {
+        int i = t * 64 + lane;
+        if (i < M && s_known[i]) kb |= (1ull << t);
+      }
+      V3 g = goal - rp;
+      double dg = norm(g);
+      bool gate = !(dg < C.approach || (norm(rv) < 0.5 * C.vel_max && norm(rp - init_pos) < 0.2));
+      double scale = 1.0, dummy_min = C.shell;
+      circ_and_scale<64, true>(gate, lane, 0, htype, rp, rv, goal, g, C, k_circ, T, n_obs,
+                               D.real_rot + (size_t)pop * 3 * n_obs, rand_g, kb, dummy_min, F, scale);
+      V3 new_pos;
+      finish_step(rp, rv, g, F, scale, C, k_attr, k_repel, k_damp, A.dt_real, T.pos(n_obs - 1), T.r[n_obs - 1], new_pos);
+      rp = new_pos;
+    }
+    rf = F;
+    for (int t = 0; t < ntiles; t++) {
+      int i = t * 64 + lane;
+      if (i < M) {
+        const int32_t f = (int32_t)((kb >> t) & 1ull);
+        rk[i] = f;
+        s_known[i] = f;
+      }
+    }
+    if (lane == 0) {
+      D.real_pos[pop * 3] = rp.x; D.real_pos[pop * 3 + 1] = rp.y; D.real_pos[pop * 3 + 2] = rp.z;
+      D.real_vel[pop * 3] = rv.x; D.real_vel[pop * 3 + 1] = rv.y; D.real_vel[pop * 3 + 2] = rv.z;
+      D.real_force[pop * 3] = F.x; D.real_force[pop * 3 + 1] = F.y; D.real_force[pop * 3 + 2] = F.z;
+    }
+  }
+
+  // host-visible outputs first: the caller waits for these only
+  if (lane == 0 && A.out) {
+    double *o = A.out + pop * 12;
+    o[0] = (double)best;
+    o[1] = rp.x; o[2] = rp.y; o[3] = rp.z;
+    o[4] = rv.x; o[5] = rv.y; o[6] = rv.z;
+    o[7] = norm(goal - rp);
+    o[8] = rf.x; o[9] = rf.y; o[10] = rf.z;
+    if (A.seq != 0.0) {
+      __threadfence_system();  // entries 0..10 visible to the host before the sequence number
+      *reinterpret_cast<volatile double *>(o + 11) = A.seq;
+    }
+  }
+
+  // header of this population's winner record (sharded runs): the selection just made, with the path length the
+  // selected agent's rollout had when it was scored and the set-point the real agent moves to
+  if (lane == 0 && A.winner_hdr && A.do_select) {
+    double *w = A.winner_hdr + (size_t)pop * A.winner_stride;
+    const size_t pb = (size_t)pop * N + best;
+    w[0] = s_cost[best];
+    w[1] = (double)best;
+    w[2] = (double)D.n_points[pb];
+    w[3] = (double)D.types[best];
+    w[4] = rp.x; w[5] = rp.y; w[6] = rp.z;
+    w[7] = norm(goal - rp);
+  }
+
+  if (A.do_reset) {
+    // resetEEAgents, B/src/cf_manager.cpp:246-255
+    V3 sp, sv;
+    if (A.reset_from_real) { sp = rp; sv = rv; }
+    else {
+      const double *in = A.reset_in + pop * 6;
+      sp = mk(in[0], in[1], in[2]);
+      sv = mk(in[3], in[4], in[5]);
+    }
+    // setVelocity clamp, B/src/cf_agent.cpp:54-61
+    double vn = norm(sv);
+    if (vn > C.vel_max) sv = (C.vel_max / vn) * sv;
+    wave_lds_fence();  // table / known flags (written above by other lanes)
+    // setObstacles, :63-70: position and velocity from the live obstacles,
+    // radius keeps its init value; known flags from the real agent
+    double *st = D.obs_start + (size_t)pop * 7 * n_obs;
+    for (int i = lane; i < 6 * n_obs; i += 64) st[i] = smem[i];
+    int32_t *ks = D.known_start + (size_t)pop * n_obs;
+    for (int i = lane; i < n_obs; i += 64) ks[i] = s_known[i];
+    // The agents' own copies (path start, point count, velocity, min_obs_dist_, known_obstacles_) are what
+    // getters see between a reset and the next rollout. When the rollout is launched right behind this
+    // kernel (pmaf_tick) it rewrites every one of them, so the stores are skipped.
+    if (!A.rollout_follows) {
+      for (int a = lane; a < N; a += 64) {
+        size_t pa = (size_t)pop * N + a;
+        double *path = D.paths + pa * (size_t)D.cap * 3;
+        path[0] = sp.x; path[1] = sp.y; path[2] = sp.z;
+        D.n_points[pa] = 1;
+        D.agent_vel[pa * 3] = sv.x; D.agent_vel[pa * 3 + 1] = sv.y; D.agent_vel[pa * 3 + 2] = sv.z;
+        D.min_obs[pa] = C.shell;
+      }
+      // known_obstacles_ of every agent <- the real agent's flags (setObstacles, cf_agent.cpp:68):
+      // one coalesced sweep over [N][n_obs] instead of a per-agent loop
+      int32_t *ko = D.known_out + (size_t)pop * N * n_obs;
+      for (int k = lane; k < N * n_obs; k += 64) ko[k] = s_known[k % n_obs];
+    }
+    if (lane == 0) {
+      D.start_pos[pop * 3] = sp.x; D.start_pos[pop * 3 + 1] = sp.y; D.start_pos[pop * 3 + 2] = sp.z;
+      D.start_vel[pop * 3] = sv.x; D.start_vel[pop * 3 + 1] = sv.y; D.start_vel[pop * 3 + 2] = sv.z;
+    }
+  }
+}
+
+// CfAgent::setPosition for every predicted agent (clear + push_back,
+// B/src/cf_agent.cpp:39-42): 1-point paths at pos[pop]
+__global__ void k_restart_paths(DevView D, const double *pos) {
+  int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= D.P * D.N) return;
+  int pop = idx / D.N;
+  double *path = D.paths + (size_t)idx * D.cap * 3;
+  path[0] = pos[pop * 3]; path[1] = pos[pop * 3 + 1]; path[2] = pos[pop * 3 + 2];
+  D.n_points[idx] = 1;
+}
+
+// CfAgent::bodyForce -> repelForce, B/src/cf_agent.cpp:229-234, 159-181
+__global__ void k_link_force(int n, const double *link_pos, const double *k_r, const double *sent /*7*/,
+                             double rad, double shell, double *out) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  V3 p = mk(link_pos[3 * i], link_pos[3 * i + 1], link_pos[3 * i + 2]);
+  V3 sp = mk(sent[0], sent[1], sent[2]);
+  V3 ro = sp - p;
+  V3 dist_vec = -ro;
+  double d = norm(dist_vec) - (rad + sent[6]);
+  d = smax(d, 1e-5);
+  V3 repel = mk(0.0, 0.0, 0.0);
+  if (d < shell) {
+    V3 otr = normalized(p - sp);
+    double t = 1.0 / d - 1.0 / shell;
+    double dd = d * d;
+    repel = ((k_r[i] * otr) * t) / dd;
+  }
+  V3 F = mk(0.0, 0.0, 0.0) + (mk(0.0, 0.0, 0.0) + repel);
+  out[3 * i] = F.x; out[3 * i + 1] = F.y; out[3 * i + 2] = F.z;
+}
+
+// elementary operations the parity argument rests on, exposed for the GPU
+// self-test: 0 a/b, 1 sqrt(a), 2 exp(a), 3 a*b, 4 a+b (compiler sequences);
+// 5 Xact::sqrt(a), 6 Xact::div(a,b), 7 / 8 a 3-vector divided by a scalar
+// through Xact::div3 / the compiler (summed to one double)
+__global__ void k_debug_math(int op, int n, const double *a, const double *b, double *out) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double r = 0.0;
+  switch (op) {
+    case 0: r = a[i] / b[i]; break;
+    case 1: r = __builtin_sqrt(a[i]); break;
+    case 2: r = portable_exp(a[i]); break;
+    case 3: r = a[i] * b[i]; break;
+    case 4: r = a[i] + b[i]; break;
+    case 5: r = Mth<MATH_XACT>::sqrt(a[i]); break;
+    case 6: r = Mth<MATH_XACT>::div(a[i], b[i]); break;
+    case 7: { V3 q = Mth<MATH_XACT>::div3(mk(a[i], b[i], a[i] * 0.5), b[i] + a[i]); r = (q.x + q.y) + q.z; } break;
+    case 8: { V3 q = mk(a[i], b[i], a[i] * 0.5) / (b[i] + a[i]); r = (q.x + q.y) + q.z; } break;
+    case 9: { double sq = Mth<MATH_XACT>::sqrt(b[i]); r = Mth<MATH_XACT>::div_r(a[i], sq, Mth<MATH_XACT>::rcp_refined(sq)); } break;  // a / sqrt(b)
+    case 10: r = a[i] / __builtin_sqrt(b[i]); break;
+  }
+  out[i] = r;
+}
+
+// winner record per population: {cost, idx, n_points, type, real agent's position[3], its goal distance,
+// path[cap][3]} = (PMAF_WINNER_HDR + 3 cap) doubles; path entries past n_points are zero
+__global__ void k_winner(DevView D, double *dst) {
+  int pop = blockIdx.x;
+  int best = D.best_idx[pop];
+  size_t pa = (size_t)pop * D.N + best;
+  size_t rec = PMAF_WINNER_HDR + (size_t)D.cap * 3;
+  double *o = dst + pop * rec;
+  if (threadIdx.x == 0) {
+    o[0] = D.costs[pa];
+    o[1] = (double)best;
+    o[2] = (double)D.n_points[pa];
+    o[3] = (double)D.types[best];
+    const V3 rp = mk(D.real_pos[pop * 3], D.real_pos[pop * 3 + 1], D.real_pos[pop * 3 + 2]);
+    const V3 goal = mk(D.goal[pop * 3], D.goal[pop * 3 + 1], D.goal[pop * 3 + 2]);
+    o[4] = rp.x; o[5] = rp.y; o[6] = rp.z;
+    o[7] = norm(goal - rp);
+  }
+  const double *path = D.paths + pa * (size_t)D.cap * 3;
+  int n3 = D.n_points[pa] * 3;
+  for (int i = threadIdx.x; i < D.cap * 3; i += blockDim.x) o[PMAF_WINNER_HDR + i] = (i < n3) ? path[i] : 0.0;
+}
+
+// the path part only: header (incl. n_points) already written by k_manager; `paths` is the buffer the scored
+// rollout wrote (the handle may already be rolling out into its other path buffer)
+__global__ void k_winner_path(DevView D, const double *paths, double *dst) {
+  int pop = blockIdx.x;
+  size_t rec = PMAF_WINNER_HDR + (size_t)D.cap * 3;
+  double *o = dst + pop * rec;
+  const int best = (int)o[1];
+  const int n3 = (int)o[2] * 3;
+  const double *path = paths + ((size_t)pop * D.N + best) * (size_t)D.cap * 3;
+  for (int i = threadIdx.x; i < D.cap * 3; i += blockDim.x) o[PMAF_WINNER_HDR + i] = (i < n3) ? path[i] : 0.0;
+}
+
+// ---------------------------------------------------------------------------
+// launch interface (pmaf_types.hpp)
+// ---------------------------------------------------------------------------
+bool pmaf_k_launch_w64_m0(const DevView &, const CostParams &, int, size_t, hipStream_t);
+bool pmaf_k_launch_w64_m1(const DevView &, const CostParams &, int, size_t, hipStream_t);
+bool pmaf_k_launch_w64_m2(const DevView &, const CostParams &, int, size_t, hipStream_t);
+bool pmaf_k_launch_grp_m0(const DevView &, const CostParams &, int, int, int, size_t, hipStream_t);
+bool pmaf_k_launch_grp_m2(const DevView &, const CostParams &, int, int, int, size_t, hipStream_t);
+
+bool pmaf_k_launch_w64(const DevView &D, const CostParams &cp, int tiles, int math, size_t lds, hipStream_t s) {
+  if (math == MATH_FAST) return pmaf_k_launch_w64_m1(D, cp, tiles, lds, s);
+  if (math == MATH_IEEE) return pmaf_k_launch_w64_m0(D, cp, tiles, lds, s);
+  return pmaf_k_launch_w64_m2(D, cp, tiles, lds, s);
+}
+
+bool pmaf_k_launch_grp(const DevView &D, const CostParams &cp, int lpa, int tiles, int math, int n_blocks, size_t lds,
+                       hipStream_t s) {
+  if (math == MATH_IEEE) return pmaf_k_launch_grp_m0(D, cp, lpa, tiles, n_blocks, lds, s);
+  return pmaf_k_launch_grp_m2(D, cp, lpa, tiles, n_blocks, lds, s);
+}
+
+bool pmaf_k_launch_generic(const DevView &D, const CostParams &cp, int lpa, int n_blocks, size_t lds, hipStream_t s) {
+  const dim3 grid((unsigned)n_blocks, (unsigned)D.P), block(64);
+  switch (lpa) {
+#define PMAF_CASE(L) case L: hipLaunchKernelGGL((k_rollout<L>), grid, block, lds, s, D, cp); break;
+    PMAF_CASE(1) PMAF_CASE(2) PMAF_CASE(4) PMAF_CASE(8) PMAF_CASE(16) PMAF_CASE(32) PMAF_CASE(64)
+#undef PMAF_CASE
+    default: return false;
+  }
+  return true;
+}
+
+void pmaf_k_launch_manager(const DevView &D, const CostParams &cp, const ManagerArgs &A, size_t lds, hipStream_t s) {
+  hipLaunchKernelGGL(k_manager, dim3((unsigned)D.P), dim3(64), lds, s, D, cp, A);
+}
+
+void pmaf_k_launch_score(const DevView &D, const CostParams &cp, hipStream_t s) {
+  const int total = D.P * D.N;
+  hipLaunchKernelGGL(k_score, dim3((total + 63) / 64), dim3(64), 0, s, D, cp);
+}
+
+void pmaf_k_launch_restart_paths(const DevView &D, const double *pos, hipStream_t s) {
+  hipLaunchKernelGGL(k_restart_paths, dim3((D.P * D.N + 255) / 256), dim3(256), 0, s, D, pos);
+}
+
+void pmaf_k_launch_link_force(int n, const double *link_pos, const double *k_r, const double *sent, double rad,
+                              double shell, double *out, hipStream_t s) {
+  hipLaunchKernelGGL(k_link_force, dim3((n + 63) / 64), dim3(64), 0, s, n, link_pos, k_r, sent, rad, shell, out);
+}
+
+void pmaf_k_launch_debug_math(int op, int n, const double *a, const double *b, double *out, hipStream_t s) {
+  hipLaunchKernelGGL(k_debug_math, dim3((n + 255) / 256), dim3(256), 0, s, op, n, a, b, out);
+}
+
+void pmaf_k_launch_winner(const DevView &D, double *dst, hipStream_t s) {
+  hipLaunchKernelGGL(k_winner, dim3((unsigned)D.P), dim3(256), 0, s, D, dst);
+}
+
+void pmaf_k_launch_winner_path(const DevView &D, const double *paths, double *dst, hipStream_t s) {
+  hipLaunchKernelGGL(k_winner_path, dim3((unsigned)D.P), dim3(256), 0, s, D, paths, dst);
+}
+
+hipError_t pmaf_k_set_lds_limits(size_t lds_manager, size_t lds_rollout) {
+  hipError_t e = hipSuccess;
+  if (lds_manager > 64 * 1024)
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_manager), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds_manager);
+  if (e == hipSuccess && lds_rollout > 64 * 1024) {
+    // only the generic kernel takes obstacle tables this large (M > 256)
+#define PMAF_LDS(L) if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rollout<L>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rollout);
+    PMAF_LDS(1) PMAF_LDS(2) PMAF_LDS(4) PMAF_LDS(8) PMAF_LDS(16) PMAF_LDS(32) PMAF_LDS(64)
+#undef PMAF_LDS
+  }
+  return e;
+}

@@ -1,0 +1,297 @@
+// pmaf_k_w64.hip -- k_rollout_w64<TILES, MATH>: the wave-per-agent rollout kernel (latency shape: C1, C2, C3) and its
+// launcher. Compiled once per arithmetic policy (-DPMAF_W64_MATH=0|1|2, csrc/build.sh) so the three policies build in
+// parallel; each object defines pmaf_k_launch_w64_m<policy>, pmaf_k_launch_w64 (pmaf_k_misc.hip) dispatches.
+#include <hip/hip_runtime.h>
+
+#include "pmaf_types.hpp"
+#include "pmaf_device.hpp"
+#include "pmaf_rollout_w64.hpp"
+#include "pmaf_rollout_grp.hpp"
+
+using namespace pmaf;
+
+// ---------------------------------------------------------------------------
+// k_rollout_w64<TILES>: one wave64 per agent (see pmaf_rollout_w64.hpp)
+// ---------------------------------------------------------------------------
+// the step loop, specialised on the agent's heuristic so the per-step code
+// carries no type dispatch (the type is uniform per wave)
+// SENT: 0 = the repulsive obstacle cannot come into range during this rollout (decided by the caller, one-slot kernel
+// only: the step loop then has no block for it), 1 = it can, 2 = decide here at run time (the other kernels)
+template <int TILES, int TYPE, int MATH, int SENT = 2>
+__device__ __forceinline__ void rollout_w64_body(const DevView &D, const CostParams &CP, const int lane,
+                                                 const int pop, const int a) {
+  extern __shared__ double smem[];
+  const unsigned long long t_begin = wall_clock64();
+  const int n_obs = D.n_obs;
+  const int M = n_obs - 1;
+  // Loop-invariant wave-uniform doubles (population constants, goal, gains, the exp() coefficients) are pinned
+  // into VGPRs: left to itself the compiler keeps them in the 100-odd SGPRs, runs out, and pays for the
+  // spills (v_writelane / v_readlane) in the step loop -- 163 spilled SGPRs before, C2 360 -> 344 us with this.
+  PopConst C = D.C;
+  { double *f = reinterpret_cast<double *>(&C);
+    for (int i = 0; i < (int)(sizeof(PopConst) / sizeof(double)); i++) asm volatile("" : "+v"(f[i])); }
+  // (two and four slots per lane have no VGPRs to spare for the exp coefficients: measured)
+  const ExpK EK = (TILES >= 2) ? exp_consts() : exp_consts_in_vgprs();
+  const size_t pa = (size_t)pop * D.N + a;
+  const double *src = D.obs_start + (size_t)pop * 7 * n_obs;
+  const int32_t *ks = D.known_start + (size_t)pop * n_obs;
+  double *rot_g = D.rot + pa * 3 * n_obs;
+  const double *rnd_g = D.rnd + pa * 3 * n_obs;
+
+  LaneObstacles<TILES> O;
+  unsigned known_bits = 0u;
+#pragma unroll
+  for (int t = 0; t < TILES; t++) {
+    int i = t * 64 + lane;
+    bool valid = i < M;
+    int ii = valid ? i : 0;
+    O.p[t] = mk(src[ii], src[n_obs + ii], src[2 * n_obs + ii]);
+    O.v[t] = mk(src[3 * n_obs + ii], src[4 * n_obs + ii], src[5 * n_obs + ii]);
+    O.r[t] = src[6 * n_obs + ii];
+    O.rx[t] = rot_g[ii]; O.ry[t] = rot_g[n_obs + ii]; O.rz[t] = rot_g[2 * n_obs + ii];
+    if (TYPE == T_RANDOM) { O.qx[t] = rnd_g[ii]; O.qy[t] = rnd_g[n_obs + ii]; O.qz[t] = rnd_g[2 * n_obs + ii]; }
+    else { O.qx[t] = 0.0; O.qy[t] = 0.0; O.qz[t] = 0.0; }
+    if (valid && ks[ii]) known_bits |= (1u << t);
+  }
+  // trailing repulsive obstacle, wave-uniform
+  V3 sent_p = mk(src[M], src[n_obs + M], src[2 * n_obs + M]);
+  const V3 sent_v = mk(src[3 * n_obs + M], src[4 * n_obs + M], src[5 * n_obs + M]);
+  const double sent_r = src[6 * n_obs + M];
+
+  V3 goal = mk(D.goal[pop * 3], D.goal[pop * 3 + 1], D.goal[pop * 3 + 2]);
+  V3 init_pos = mk(D.agent_init_pos[pop * 3], D.agent_init_pos[pop * 3 + 1], D.agent_init_pos[pop * 3 + 2]);
+  asm volatile("" : "+v"(goal.x), "+v"(goal.y), "+v"(goal.z), "+v"(init_pos.x), "+v"(init_pos.y), "+v"(init_pos.z));
+  V3 p = mk(D.start_pos[pop * 3], D.start_pos[pop * 3 + 1], D.start_pos[pop * 3 + 2]);
+  V3 v = mk(D.start_vel[pop * 3], D.start_vel[pop * 3 + 1], D.start_vel[pop * 3 + 2]);
+  double k_attr = D.k_attr[pa], k_circ = D.k_circ[pa], k_repel = D.k_repel[pa], k_damp = D.k_damp[pa];
+  asm volatile("" : "+v"(k_attr), "+v"(k_circ), "+v"(k_repel), "+v"(k_damp));
+  double *path = D.paths + pa * (size_t)D.cap * 3;
+
+  // LDS list of the step's non-zero circular-field terms (after the obstacle table)
+  int clist_off = 7 * n_obs + (n_obs + 1) / 2;
+  clist_off += clist_off & 1;
+  double *clist = smem + clist_off;
+
+  double lane_min = C.shell;  // per-lane running min_obs_dist_, reduced once after the loop
+  int n = 1;
+  bool ran = false;
+  if (lane == 0) { path[0] = p.x; path[1] = p.y; path[2] = p.z; }
+
+  // Everything the next step needs from the new state -- goal distance (loop
+  // guard / gate), goal direction, squared speed, squared start distance and
+  // attractorForce's velocity error (B/src/cf_agent.cpp:188-192) -- is computed
+  // at the END of the step in one basic block with the velocity clamp and the
+  // path-length norm: five independent sqrt / divide chains that the in-order
+  // issue of a lone wave can only overlap inside one block.
+  typedef Mth<MATH> MT;
+  V3 g = goal - p;
+  double dg = MT::norm(g);
+  double zv = sqn(v);
+  double z_init = sqn(p - init_pos);
+  V3 gn = (dg > 0.0) ? MT::div3(g, dg) : g;  // goal_vec.normalized()
+  // One slot per lane (M <= 61; the host sends 62..64 obstacles to the two-slot kernel): the sweep's |ro| /
+  // ro.normalized() of the NEXT step are computed at the end of this step, and the lanes that have no obstacle carry
+  // the tail's other norms through the same instructions -- lane 63 the goal (distance and direction), lane 62 the
+  // speed clamp, lane 61 attractorForce's speed limit -- instead of three more sqrt / reciprocal / divide sequences.
+  constexpr bool PRE = (TILES == 1);
+  double s_pre = 0.0;
+  V3 ron_pre = mk(0.0, 0.0, 0.0);
+  if (PRE) {
+    if (lane == 63) { O.p[0] = goal; O.v[0] = mk(0.0, 0.0, 0.0); }
+    MT::norm_unit(O.p[0] - p, s_pre, ron_pre);
+  }
+  V3 verr = attractor_velocity_error<MATH>(v, g, C, k_attr, k_damp);
+  const double zsent_lt = D.zsent_lt[pop];
+  const bool sent_reachable = (SENT == 2) ? sentinel_reachable(p, sent_p, sent_v, zsent_lt, C, D.cap) : (SENT == 1);
+  bool moving = false;  // any field obstacle with a non-zero (or NaN) velocity component
+#pragma unroll
+  for (int t = 0; t < TILES; t++) moving = moving || !(O.v[t].x == 0.0 && O.v[t].y == 0.0 && O.v[t].z == 0.0);
+  moving = __any(moving);
+  bool advance = true;
+  V3 repel = mk(0.0, 0.0, 0.0);  // repelForce of the coming step (depends on the step's start state only)
+  if (sent_reachable) repel = sentinel_repel(p, C, k_repel, sent_p, sent_r, zsent_lt);
+  SecTimers ST;
+#ifdef PMAF_SECTION_TIMERS
+  ST.start();
+#endif
+  while ((dg > 0.1) && (n < D.cap)) {  // wave-uniform guard, B/src/cf_agent.cpp:310-311
+    // gate, :315-317
+    // |v| < 0.5 vmax and |p - init| < 0.2 on exact squared thresholds
+    const bool gate = !(dg < C.approach || (zv < C.zvhalf_lt && z_init < C.zinit_lt));
+    V3 F = mk(0.0, 0.0, 0.0);
+    double scale = 1.0;
+    PMAF_SEC(ST, 0);
+    // (called with the gate closed too: the sweep's few compares then find no obstacle -- one branch less in the step)
+    if (PRE || (gate && !(D.ablate & 8)))
+      circ_and_scale_w64<TILES, TYPE, MATH, PRE>(lane, p, v, zv, goal, g, dg, gn, C, k_circ, n_obs, rot_g, known_bits,
+                                                 O, clist, lane_min, F, scale, ST, EK, D.ablate, 0, s_pre, ron_pre,
+                                                 gate);
+    PMAF_SEC(ST, 5);
+    // attractorForce (:183-193), updatePositionAndVelocity (:253-268)
+    // repelForce (:159-181): `repel` was evaluated for this step's start state at the end of the previous step; it is
+    // +0.0 when the obstacle cannot come into range, and F -- a sum that started from +0.0 -- is never -0.0, so the
+    // unconditional addition is exact (no masked block between the force sum and the tail)
+    F = F + (mk(0.0, 0.0, 0.0) + repel);
+    // attractorForce (:183-193), updatePositionAndVelocity (:253-258): a = F / mass, |a| <= 13
+    V3 acc;
+    if (PRE) {
+      // one slot per lane: as few blocks as possible between the force sum and the tail -- the k_attr == 0 case is a
+      // select, and unit mass without clamp (the common case) skips ONE rare block instead of two
+      const V3 Fa = F + (scale * k_damp) * verr;
+      const bool attr = (k_attr != 0.0);
+      F.x = attr ? Fa.x : F.x; F.y = attr ? Fa.y : F.y; F.z = attr ? Fa.z : F.z;
+      acc = F;
+      double az = sqn(F);
+      if ((C.mass != 1.0) || (az >= C.zacc_gt)) {
+        if (C.mass != 1.0) { acc = F / C.mass; az = sqn(acc); }
+        if (az >= C.zacc_gt) acc = acc * (13.0 / __builtin_sqrt(az));  // norm(acc) > 13.0
+      }
+    } else {
+      if (k_attr != 0.0) F = F + (scale * k_damp) * verr;
+      acc = F;
+      if (C.mass != 1.0) acc = F / C.mass;
+      const double az = sqn(acc);
+      if (az >= C.zacc_gt) acc = acc * (13.0 / __builtin_sqrt(az));  // norm(acc) > 13.0 (rare)
+    }
+    PMAF_SEC(ST, 6);
+    // ---- one block: integrate, clamp the speed, the next step's norms ----
+    const V3 half = ((0.5 * acc) * C.dt) * C.dt;
+    const V3 new_pos = (p + half) + (v * C.dt);
+    const V3 nv = v + acc * C.dt;
+    p = new_pos;
+    g = goal - p;
+    // predictObstacles, B/src/cf_agent.cpp:270-276, in registers. Obstacles at
+    // rest: p + (+-0) dt is idempotent after its first application (which turns
+    // a -0.0 coordinate into +0.0), so later steps skip it. (Lane 63 of the one-slot kernel holds the goal with
+    // velocity 0: a -0.0 goal coordinate turns into +0.0 there, which can only change the sign of a zero component
+    // of gn, and gn only enters dot(ron, gn) < -0.01; g itself is computed from the goal directly.)
+    // (one slot per lane: unconditionally -- for obstacles at rest every further application is the identity, and
+    // three multiply-adds are cheaper than a branch in the middle of the tail)
+    if (PRE) O.p[0] = O.p[0] + O.v[0] * C.dt;
+    {
+      // ONE sqrt / reciprocal / divide sequence for the whole tail: lane 63 goal distance and direction (|g|,
+      // g.normalized()), lane 62 the speed clamp (|nv|, vel_max / |nv|), lane 61 attractorForce's limit
+      // (vel_max / |vel_des|) and, in the one-slot kernel, lanes 0..M-1 the next step's |ro| and ro.normalized():
+      // the same operations on the same operands as separate sequences, read back with v_readlane.
+      const V3 vel_des = (k_attr / k_damp) * g;
+      const bool l_nv = (lane == 62), l_des = (lane == 61);
+      const V3 other = PRE ? (O.p[0] - p) : g;   // one-slot kernel: lane 63 holds the goal, O.p - p = g there
+      const V3 vec = l_nv ? nv : (l_des ? vel_des : other);
+      V3 num = vec;
+      num.x = (l_nv || l_des) ? C.vel_max : vec.x;
+      double s, rs;
+      MT::norm_rcp(vec, s, rs);
+      const V3 q = MT::div3_n(num, s, rs);
+      const V3 u = (sqn(vec) > 0.0) ? q : vec;  // normalized(): the vector itself unless squaredNorm > 0
+      if (PRE) { s_pre = s; ron_pre = u; }
+      const double vn = readlane_d(s, 62), f_nv = readlane_d(q.x, 62), f_des = readlane_d(q.x, 61);
+      v = (vn > C.vel_max) ? nv * f_nv : nv;
+      dg = readlane_d(s, 63);
+      gn = readlane_v3(u, 63);
+      verr = vel_des * smin(1.0, f_des) - v;
+    }
+    zv = sqn(v);
+    z_init = sqn(p - init_pos);
+    // every lane stores the (wave-uniform) point to the same address: one transaction, and no exec-masked block
+    // in the middle of the tail
+    path[n * 3] = p.x; path[n * 3 + 1] = p.y; path[n * 3 + 2] = p.z;
+    n++;
+    ran = true;
+    if (!PRE && advance) {
+#pragma unroll
+      for (int t = 0; t < TILES; t++) O.p[t] = O.p[t] + O.v[t] * C.dt;
+      advance = moving;
+    }
+    if (sent_reachable) {  // the only masked block of the step for the repulsive obstacle: advance it, next step's repelForce
+      sent_p = sent_p + sent_v * C.dt;
+      repel = sentinel_repel(p, C, k_repel, sent_p, sent_r, zsent_lt);
+    }
+    PMAF_SEC(ST, 7);
+  }
+#ifdef PMAF_SECTION_TIMERS
+  if (lane == 0 && pop == 0 && a < 7)
+    printf("agent %d type %d steps %d | verr+gate %llu sweep %llu scale %llu circ %llu sum %llu (skip) %llu finish %llu tail %llu | "
+           "in-shell steps %llu terms %llu\n", a, TYPE, n - 1, ST.acc[0], ST.acc[1], ST.acc[2], ST.acc[3], ST.acc[4],
+           ST.acc[5], ST.acc[6], ST.acc[7], ST.cnt[0], ST.cnt[1]);
+#endif
+
+  double cost_ws, path_len;
+  path_cost_terms_w64<MATH>(lane, path, n, CP.ws, CP.k_workspace, clist, cost_ws, path_len);
+
+  const double min_obs = wave_min64(lane_min);
+  int32_t *ko = D.known_out + pa * n_obs;
+#pragma unroll
+  for (int t = 0; t < TILES; t++) {
+    int i = t * 64 + lane;
+    if (i < M) ko[i] = (int32_t)((known_bits >> t) & 1u);
+  }
+  if (lane == 0) {
+    ko[M] = ks[M];
+    D.n_points[pa] = n;
+    D.agent_vel[pa * 3] = v.x; D.agent_vel[pa * 3 + 1] = v.y; D.agent_vel[pa * 3 + 2] = v.z;
+    D.min_obs[pa] = min_obs;
+    D.cost_ws[pa] = cost_ws;
+    D.path_len[pa] = path_len;
+    D.goal_dist[pa] = dg;
+    if (ran) D.reached[pa] = dg < 0.100001;  // B/src/cf_agent.cpp:330-337
+    atomicAdd(D.step_counter, (unsigned long long)(n - 1));
+    D.pred_ticks[pa] = wall_clock64() - t_begin;
+  }
+}
+
+template <int TILES, int MATH>
+__global__ __launch_bounds__(64) void k_rollout_w64(DevView D, CostParams CP) {
+  const int lane = threadIdx.x;
+  const int pop = blockIdx.y;
+  const int a = blockIdx.x;  // grid.x == N
+  if (TILES == 1) {
+    // one slot per lane: the repulsive obstacle's reachability (per rollout, see sentinel_reachable) picks a loop
+    // without any code for it -- in the shipped scenes it sits 170 m away
+    const int n_obs = D.n_obs, M = n_obs - 1;
+    const double *src = D.obs_start + (size_t)pop * 7 * n_obs;
+    const V3 sp = mk(src[M], src[n_obs + M], src[2 * n_obs + M]);
+    const V3 sv = mk(src[3 * n_obs + M], src[4 * n_obs + M], src[5 * n_obs + M]);
+    const V3 p0 = mk(D.start_pos[pop * 3], D.start_pos[pop * 3 + 1], D.start_pos[pop * 3 + 2]);
+    const PopConst C0 = D.C;
+    const bool reach = sentinel_reachable(p0, sp, sv, D.zsent_lt[pop], C0, D.cap);
+#define PMAF_BODY(T) \
+    if (reach) rollout_w64_body<TILES, T, MATH, 1>(D, CP, lane, pop, a); \
+    else rollout_w64_body<TILES, T, MATH, 0>(D, CP, lane, pop, a)
+    switch (D.types[a]) {
+      case T_GOAL: PMAF_BODY(T_GOAL); break;
+      case T_OBST: PMAF_BODY(T_OBST); break;
+      case T_GOALOBST: PMAF_BODY(T_GOALOBST); break;
+      case T_VEL: PMAF_BODY(T_VEL); break;
+      case T_RANDOM: PMAF_BODY(T_RANDOM); break;
+      case T_HAD: PMAF_BODY(T_HAD); break;
+      default: break;
+    }
+#undef PMAF_BODY
+    return;
+  }
+  switch (D.types[a]) {
+    case T_GOAL: rollout_w64_body<TILES, T_GOAL, MATH>(D, CP, lane, pop, a); break;
+    case T_OBST: rollout_w64_body<TILES, T_OBST, MATH>(D, CP, lane, pop, a); break;
+    case T_GOALOBST: rollout_w64_body<TILES, T_GOALOBST, MATH>(D, CP, lane, pop, a); break;
+    case T_VEL: rollout_w64_body<TILES, T_VEL, MATH>(D, CP, lane, pop, a); break;
+    case T_RANDOM: rollout_w64_body<TILES, T_RANDOM, MATH>(D, CP, lane, pop, a); break;
+    case T_HAD: rollout_w64_body<TILES, T_HAD, MATH>(D, CP, lane, pop, a); break;
+    default: break;
+  }
+}
+
+
+#ifndef PMAF_W64_MATH
+#error "compile with -DPMAF_W64_MATH=0|1|2"
+#endif
+#define PMAF_CAT2(a, b) a##b
+#define PMAF_CAT(a, b) PMAF_CAT2(a, b)
+bool PMAF_CAT(pmaf_k_launch_w64_m, PMAF_W64_MATH)(const DevView &D, const CostParams &cp, int tiles, size_t lds,
+                                                  hipStream_t s) {
+  const dim3 g64((unsigned)D.N, (unsigned)D.P), block(64);
+  if (tiles <= 1) hipLaunchKernelGGL((k_rollout_w64<1, PMAF_W64_MATH>), g64, block, lds, s, D, cp);
+  else if (tiles == 2) hipLaunchKernelGGL((k_rollout_w64<2, PMAF_W64_MATH>), g64, block, lds, s, D, cp);
+  else if (tiles <= 4) hipLaunchKernelGGL((k_rollout_w64<4, PMAF_W64_MATH>), g64, block, lds, s, D, cp);
+  else return false;
+  return true;
+}

@@ -131,6 +131,26 @@ __device__ __forceinline__ V3 sentinel_repel(V3 p, const PopConst &C, double k_r
   return repel;
 }
 
+// repelForce for the REAL agent's step (RealCfAgent::cfPlanner -> CfAgent::repelForce, B/src/cf_agent.cpp:159-181):
+// the live obstacle list is the caller's, so its last radius may differ from the create-time one the host-computed
+// squared boundary (zsent_lt) was derived from -- the range test is the reference's own `d < shell` on the live radius.
+// Once per tick: the square root does not matter here.
+__device__ __forceinline__ V3 sentinel_repel_live(V3 p, const PopConst &C, double k_repel, V3 sent_pos,
+                                                  double sent_rad) {
+  const V3 ro = sent_pos - p;
+  const V3 dist_vec = -ro;
+  V3 repel = mk(0.0, 0.0, 0.0);
+  double d = norm(dist_vec) - (C.rad + sent_rad);
+  d = smax(d, 1e-5);
+  if (d < C.shell) {
+    const V3 otr = normalized(p - sent_pos);
+    const double t = 1.0 / d - 1.0 / C.shell;
+    const double dd = d * d;
+    repel = ((k_repel * otr) * t) / dd;
+  }
+  return repel;
+}
+
 // wave-level ordering of LDS accesses: DS instructions of one wave execute in
 // order, so only the compiler has to be kept from reordering them.
 __device__ __forceinline__ void wave_lds_fence() {

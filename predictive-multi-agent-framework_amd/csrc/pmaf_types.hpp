@@ -1,0 +1,118 @@
+// pmaf_types.hpp -- plain structs shared by the host side (pmaf_host.cpp, compiled by g++) and the kernel
+// translation units (pmaf_k_*.hip, compiled by hipcc), and the launch interface between them. No device code here.
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include <stddef.h>
+#include <stdint.h>
+
+// doubles in front of the path of a winner record (include/pmaf.h: pmaf_winner_record_doubles)
+#define PMAF_WINNER_HDR 8
+
+namespace pmaf {
+
+// arithmetic policy of the tuned rollout kernels (see pmaf_device.hpp "arithmetic policy")
+enum : int { MATH_IEEE = 0, MATH_FAST = 1, MATH_XACT = 2 };
+
+struct PopConst {
+  double dt, vel_max, approach, shell, mass, rad;
+  // exact squared thresholds (computed on the host, pmaf_hip.hip:sq_gt/sq_ge):
+  // for every z >= 0   sqrt(z) > 1e-5  <=>  z >= zf_gt
+  //                    sqrt(z) > 13.0  <=>  z >= zacc_gt
+  //                    sqrt(z) < 0.2   <=>  z <  zinit_lt
+  // (sqrt is monotonic and correctly rounded, so each predicate has one
+  // boundary double); they let the w64 kernel skip square roots whose value
+  // is only compared, never used.
+  //                    sqrt(z) < 0.5 vmax        <=>  z < zvhalf_lt
+  //                    sqrt(z) < vmax - 0.1 vmax <=>  z < zv09_lt
+  double zf_gt, zacc_gt, zinit_lt, zvhalf_lt, zv09_lt;
+};
+
+}  // namespace pmaf
+
+// ---------------------------------------------------------------------------
+// device-side views
+// ---------------------------------------------------------------------------
+struct DevView {
+  int P, N, n_obs, cap;
+  pmaf::PopConst C;
+  // per population
+  const double *goal;        // [P][3]
+  double *agent_init_pos;    // [P][3]  CfAgent::init_pos_ (gate)
+  double *start_pos;         // [P][3]  position all agents start the next rollout from
+  double *start_vel;         // [P][3]
+  double *obs_start;         // [P][7][n_obs] SoA: agents' private obstacle copies at rollout start
+  int32_t *known_start;      // [P][n_obs]
+  double *obs_live;          // [P][7][n_obs] SoA: live obstacles (moveRealEEAgent / resetEEAgents argument)
+  // per agent
+  const double *k_attr, *k_circ, *k_repel, *k_damp;  // [P][N]
+  const int32_t *types;      // [N]
+  double *rot;               // [P][N][3][n_obs]  field_rotation_vecs_
+  const double *rnd;         // [P][N][3][n_obs]  random_vecs_
+  double *paths;             // [P][N][cap][3]
+  int32_t *n_points;         // [P][N]
+  double *agent_vel;         // [P][N][3]
+  double *min_obs;           // [P][N]
+  double *cost_ws;           // [P][N]  sum of workspace penalties over the path
+  double *path_len;          // [P][N]
+  double *goal_dist;         // [P][N]
+  int32_t *reached;          // [P][N]
+  int32_t *known_out;        // [P][N][n_obs] known_obstacles_ after the rollout
+  double *costs;             // [P][N]
+  // real agent
+  double *real_pos, *real_vel, *real_force, *real_init_pos;  // [P][3]
+  int32_t *real_known;       // [P][n_obs]
+  double *real_rot;          // [P][3][n_obs]
+  // best agent copy
+  int32_t *has_best, *best_id, *best_type;  // [P]
+  double *best_rnd;          // [P][3][n_obs]
+  int32_t *best_idx;         // [P] last evaluate result
+  unsigned long long *step_counter;  // [1] agent-steps executed by all rollouts
+  unsigned long long *pred_ticks;    // [P][N] rollout duration in wall_clock64() ticks (CfAgent::prediction_time_)
+  const double *zsent_lt;            // [P] exact squared-distance boundary of the repel range test
+  int ablate;                        // timing experiments only (PMAF_ABLATE), 0 in production
+  int n_simds;                       // SIMDs of the device (4 per CU): a launch of more waves doubles them up
+};
+
+struct CostParams {
+  double k_goal_dist, k_path_len, k_safe_dist, k_workspace;
+  double ws[6];
+};
+
+
+struct ManagerArgs {
+  int do_select, do_move, do_reset;
+  int reset_from_real;     // 1: reset to the real agent's state, 0: reset_in
+  int rollout_follows;     // 1: the rollout kernel is launched right behind this one (pmaf_tick)
+  int tuned_real_step;     // 1: real_step_w64 (default arithmetic policy, M <= 256), 0: generic LDS-table path
+  const double *live_src;  // [P][7][n_obs] live obstacles in mapped pinned HOST memory (pmaf_tick: no copy command);
+                           // NULL: D.obs_live already holds them
+  double dt_real;
+  const int32_t *agent_id; // [P] gains index for the real step; NULL = best_idx of this launch
+  const double *reset_in;  // [P][6] pos, vel
+  double *out;             // [P][12] host-visible: best_idx, next_pos[3], next_vel[3], dist_from_goal, force[3], seq
+  double seq;              // written to out[11] after the other entries are visible to the host (0: not written)
+  double *winner_hdr;      // [P][winner_stride] winner-record headers (send buffer of the sharded runs' all-gather),
+  int winner_stride;       // written after a selection: {cost, idx, n_points, type, next_pos[3], goal_dist}; NULL: none
+};
+
+// ---------------------------------------------------------------------------
+// launch interface: implemented in pmaf_k_w64.hip / pmaf_k_grp.hip / pmaf_k_misc.hip
+// ---------------------------------------------------------------------------
+// k_rollout_w64<TILES, MATH> on grid (N, P); tiles in {1,2,4}. Returns false if this build holds no such variant.
+bool pmaf_k_launch_w64(const DevView &D, const CostParams &cp, int tiles, int math, size_t lds, hipStream_t s);
+// k_rollout_grp<LPA, TILES, MATH> on grid (n_blocks, P); lpa in {8,16,32}, tiles in {1,2,4}, math XACT or IEEE
+bool pmaf_k_launch_grp(const DevView &D, const CostParams &cp, int lpa, int tiles, int math, int n_blocks, size_t lds,
+                       hipStream_t s);
+// generic k_rollout<LPA>, any power-of-two lpa 1..64
+bool pmaf_k_launch_generic(const DevView &D, const CostParams &cp, int lpa, int n_blocks, size_t lds, hipStream_t s);
+void pmaf_k_launch_manager(const DevView &D, const CostParams &cp, const ManagerArgs &A, size_t lds, hipStream_t s);
+void pmaf_k_launch_score(const DevView &D, const CostParams &cp, hipStream_t s);
+void pmaf_k_launch_restart_paths(const DevView &D, const double *pos, hipStream_t s);
+void pmaf_k_launch_link_force(int n, const double *link_pos, const double *k_r, const double *sent, double rad,
+                              double shell, double *out, hipStream_t s);
+void pmaf_k_launch_debug_math(int op, int n, const double *a, const double *b, double *out, hipStream_t s);
+void pmaf_k_launch_winner(const DevView &D, double *dst, hipStream_t s);
+// path part of the winner records whose headers k_manager wrote into dst: the selected agents' paths out of `paths`
+void pmaf_k_launch_winner_path(const DevView &D, const double *paths, double *dst, hipStream_t s);
+// opt the kernels that take dynamic LDS into more than the 64 KB default
+hipError_t pmaf_k_set_lds_limits(size_t lds_manager, size_t lds_rollout);

@@ -71,6 +71,20 @@ SYMBOLS = {
     "pmaf_write_winner_records": (C.c_int, [_V, _V, C.c_size_t]),
     "pmaf_winner_record_doubles": (C.c_size_t, [_V]),
     "pmaf_stream": (_V, [_V]),
+    "pmaf_comm_unique_id": (C.c_int, [_V]),
+    "pmaf_comm_init_rccl": (C.c_int, [C.c_int32, C.c_int32, _V, C.c_int32, C.POINTER(_V)]),
+    "pmaf_comm_from_rccl": (C.c_int, [_V, C.c_int32, C.POINTER(_V)]),
+    "pmaf_comm_init_host": (C.c_int, [C.c_int32, C.c_int32, _V, _V, C.POINTER(_V)]),
+    "pmaf_comm_destroy": (C.c_int, [_V]),
+    "pmaf_comm_world": (C.c_int, [_V]),
+    "pmaf_comm_rank": (C.c_int, [_V]),
+    "pmaf_comm_allgather": (C.c_int, [_V, _dp, _dp, C.c_size_t]),
+    "pmaf_select_best": (C.c_int32, [_dp, C.c_int32, C.c_int32]),
+    "pmaf_allgather_winners": (C.c_int, [_V, _V, _V, C.c_size_t]),
+    "pmaf_attach_comm": (C.c_int, [_V, _V]),
+    "pmaf_winners_wait": (C.c_int, [_V, C.POINTER(_dp), C.POINTER(C.c_size_t)]),
+    "pmaf_winners_device": (_V, [_V]),
+    "pmaf_get_exchange_times_us": (C.c_int, [_V, _dp, C.c_int32, _ip]),
     "pmaf_state_size": (C.c_size_t, [_V]),
     "pmaf_save_state": (C.c_int, [_V, _V, C.c_size_t]),
     "pmaf_load_state": (C.c_int, [_V, _V, C.c_size_t]),
@@ -353,6 +367,33 @@ class PmafPlanner:
     def write_winner_records(self, device_ptr, nbytes):
         self._chk(self.L.pmaf_write_winner_records(self._h, C.c_void_p(device_ptr), nbytes))
 
+    def allgather_winners(self, comm, recv_device_ptr, nbytes):
+        """one-shot: pack + all-gather into device memory, stream-ordered on the handle's stream (RCCL)"""
+        self._chk(self.L.pmaf_allgather_winners(self._h, comm._c, C.c_void_p(recv_device_ptr), nbytes))
+
+    def attach_comm(self, comm):
+        """every tick / evaluate from now on all-gathers its winner records (comm=None detaches)"""
+        self._chk(self.L.pmaf_attach_comm(self._h, comm._c if comm is not None else None))
+        self._comm = comm  # keep it alive while attached
+
+    def winners_wait(self):
+        """[world][P][record] table of the last tick's / evaluate's exchange (a copy)"""
+        ptr = _dp()
+        n = C.c_size_t(0)
+        self._chk(self.L.pmaf_winners_wait(self._h, C.byref(ptr), C.byref(n)))
+        a = np.ctypeslib.as_array(ptr, shape=(n.value,)).copy()
+        rec = self.winner_record_doubles()
+        return a.reshape(-1, self.P, rec)
+
+    def winners_device_ptr(self):
+        return self.L.pmaf_winners_device(self._h)
+
+    def exchange_times_us(self, max_n=1 << 20):
+        out = np.zeros(max_n)
+        n = C.c_int32(0)
+        self._chk(self.L.pmaf_get_exchange_times_us(self._h, _p(out), max_n, C.byref(n)))
+        return out[:n.value].copy()
+
     def save_state(self):
         n = int(self.L.pmaf_state_size(self._h))
         buf = np.zeros(n, dtype=np.uint8)
@@ -383,3 +424,97 @@ class PmafPlanner:
         a, b, c = C.c_int32(0), C.c_int32(0), C.c_int32(0)
         self._chk(self.L.pmaf_get_launch_config(self._h, C.byref(a), C.byref(b), C.byref(c)))
         return dict(lanes_per_agent=a.value, n_blocks=b.value, lds_bytes=c.value)
+
+
+HOST_ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)
+
+
+class PmafComm:
+    """pmaf_comm: RCCL communicator (one rank per GPU) or a host-transport one
+    whose all-gather is a Python callable (gloo / MPI in tests)."""
+
+    def __init__(self):
+        self.L = load_library()
+        self._c = None
+        self._cb = None
+
+    @staticmethod
+    def unique_id():
+        L = load_library()
+        buf = (C.c_ubyte * 128)()
+        rc = L.pmaf_comm_unique_id(C.cast(buf, C.c_void_p))
+        if rc != 0:
+            raise PmafError(rc, L.pmaf_last_error().decode())
+        return bytes(buf)
+
+    @classmethod
+    def rccl(cls, world, rank, unique_id, device=-1):
+        self = cls()
+        buf = (C.c_ubyte * 128).from_buffer_copy(unique_id)
+        c = _V()
+        rc = self.L.pmaf_comm_init_rccl(world, rank, C.cast(buf, C.c_void_p), device, C.byref(c))
+        if rc != 0:
+            raise PmafError(rc, self.L.pmaf_last_error().decode())
+        self._c = c
+        return self
+
+    @classmethod
+    def host(cls, world, rank, allgather):
+        """allgather(send: np.ndarray[uint8]) -> np.ndarray[uint8] of world * len(send) bytes, rank-major"""
+        self = cls()
+
+        def _cb(ctx, send, recv, nbytes):
+            try:
+                snd = np.ctypeslib.as_array(C.cast(send, C.POINTER(C.c_ubyte)), shape=(nbytes,))
+                out = np.ascontiguousarray(allgather(snd.copy()), dtype=np.uint8).reshape(-1)
+                if out.size != nbytes * world:
+                    return 2
+                C.memmove(recv, out.ctypes.data, out.size)
+                return 0
+            except Exception:  # never unwind through the C frames
+                import traceback
+                traceback.print_exc()
+                return 1
+
+        self._cb = HOST_ALLGATHER_FN(_cb)
+        c = _V()
+        rc = self.L.pmaf_comm_init_host(world, rank, C.cast(self._cb, C.c_void_p), None, C.byref(c))
+        if rc != 0:
+            raise PmafError(rc, self.L.pmaf_last_error().decode())
+        self._c = c
+        return self
+
+    @property
+    def world(self):
+        return self.L.pmaf_comm_world(self._c)
+
+    @property
+    def rank(self):
+        return self.L.pmaf_comm_rank(self._c)
+
+    def allgather(self, a):
+        """blocking all-gather of a host float64 array; returns [world, *a.shape]"""
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        out = np.zeros((self.world,) + a.shape)
+        rc = self.L.pmaf_comm_allgather(self._c, _p(a), _p(out), a.size)
+        if rc != 0:
+            raise PmafError(rc, self.L.pmaf_last_error().decode())
+        return out
+
+    def close(self):
+        if self._c:
+            self.L.pmaf_comm_destroy(self._c)
+            self._c = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def select_best(costs, prev_best=None):
+    """pmaf_select_best: evaluateAgents' selection rule on a gathered cost vector"""
+    L = load_library()
+    c = np.ascontiguousarray(costs, dtype=np.float64)
+    return int(L.pmaf_select_best(_p(c), c.size, -1 if prev_best is None else int(prev_best)))

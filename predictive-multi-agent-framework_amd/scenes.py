@@ -179,6 +179,22 @@ def config_scene(name, scene_id=0, dynamic=False):
     return synthetic_scene(c["n_agents"], c["horizon"], c["n_field"], cid, scene_id, dynamic)
 
 
+def dual_arm_scenes(n_agents=256, horizon=200, n_field=32):
+    """BASELINE config C4 (build-defined): one population per arm,
+    2 x 256 agents, each arm's trailing repulsive obstacle = the other arm's end
+    effector (shard.DualArmCoupling). The arms start 0.24 m apart and their
+    goals are swapped in y, so the two self-collision spheres come into range
+    mid-way. Returns [scene_arm0, scene_arm1]."""
+    out = []
+    for arm, (y0, y1) in enumerate(((-0.12, 0.10), (0.12, -0.10))):
+        s = synthetic_scene(n_agents, horizon, n_field, 4, arm)
+        s["start"] = np.array([-0.45, y0, 0.7])
+        s["goal"] = np.array([0.45, y1, 0.7])
+        s["name"] = "dual_arm_%d" % arm
+        out.append(s)
+    return out
+
+
 def scene_from_record(rec, name="task", seed=0xC0FFEE00 + 9 * 256, horizon=None):
     """scene dict from a plain record (tests/golden/task_scenes.json: the
     reference's shipped task files reduced to planner inputs)"""

@@ -1,23 +1,33 @@
-"""Multi-GPU sharding of the planner tick.
+"""Multi-GPU sharding of the planner tick -- Python orchestration
+over the C-ABI's multi-GPU entry points (include/pmaf.h: pmaf_comm_*,
+pmaf_attach_comm, pmaf_winners_wait, pmaf_select_best). Used by bench.py and
+the tests; a C++ host calls the same entry points directly.
 
 The path shards by POPULATION: agents of different populations (scenes, arms,
 goal sweeps) never interact, so rank r plans the populations
-{s : s % world == r} with its own PmafPlanner and no data-path collective.
-Only when a caller needs every population's winning trajectory on every rank
-(e.g. the dual-arm extension where each arm treats the other arm's predicted
-path as its repulsive obstacle) the fixed-size winner records are exchanged
-with ONE all-gather per tick -- RCCL over xGMI when the tensors are on the GPU
-(torch.distributed backend "nccl"), gloo in the CPU tests. Records are
-(4 + 3*cap) doubles: cost, agent index, n_points, agent type, path[cap][3]
-(<= 12 KB at cap 501), so the collective is latency-bound; nothing here is
-sized by link bandwidth.
+{s : s % world == r} with its own handle and no collective on the rollout's
+data path. Only when a caller needs every population's winning trajectory on
+every rank (the dual-arm extension where each arm treats the other arm's
+end effector as its repulsive obstacle, a goal sweep's global pick) the
+fixed-size winner records are exchanged with ONE all-gather per tick --
+ncclAllGather (RCCL over xGMI) enqueued by libpmaf_hip.so on a second stream
+behind the selection kernel, overlapping the next rollout; a host-transport
+communicator (gloo / MPI callback) takes its place in the CPU tests. Records
+are (8 + 3*cap) doubles: cost, agent index, n_points, agent type, the real
+agent's next position[3], its goal distance, path[cap][3] (<= 12 KB at cap
+501), so the collective is latency-bound; nothing here is sized by link
+bandwidth.
 
 For the fallback of ONE population split by agent range, merge_agent_ranges()
-applies CfManager::evaluateAgents' selection rule (B/src/cf_manager.cpp:336-353)
-to the gathered per-rank costs: lowest cost, ties to the lowest global index,
-then the 0.9 hysteresis against the previous global best.
+applies CfManager::evaluateAgents' selection rule (B/src/cf_manager.cpp:336-353;
+pmaf_select_best) to the gathered per-rank costs: lowest cost, ties to the
+lowest global index, then the 0.9 hysteresis against the previous global best.
 """
 import numpy as np
+
+from . import planner as _planner
+
+WINNER_HDR = 8  # PMAF_WINNER_RECORD_HEADER
 
 
 def partition_populations(n_populations, world, rank):
@@ -26,66 +36,74 @@ def partition_populations(n_populations, world, rank):
 
 
 def record_doubles(cap):
-    return 4 + 3 * cap
+    return WINNER_HDR + 3 * cap
 
 
-def pack_winner_record(cost, idx, n_points, agent_type, path, cap):
-    """host-side packing of one winner record (same layout as k_winner)"""
+def pack_winner_record(cost, idx, n_points, agent_type, path, cap, next_pos=(0.0, 0.0, 0.0), goal_dist=0.0):
+    """host-side packing of one winner record (same layout as k_manager / k_winner write)"""
     rec = np.zeros(record_doubles(cap))
     rec[0], rec[1], rec[2], rec[3] = cost, idx, n_points, agent_type
-    rec[4:4 + 3 * n_points] = np.asarray(path)[:n_points].reshape(-1)
+    rec[4:7] = next_pos
+    rec[7] = goal_dist
+    rec[WINNER_HDR:WINNER_HDR + 3 * n_points] = np.asarray(path)[:n_points].reshape(-1)
     return rec
 
 
 def unpack_winner_records(flat, cap):
-    """[(cost, idx, n_points, type, path[n_points][3]), ...] from gathered records"""
+    """[dict(cost, index, n_points, type, next_pos, goal_dist, path[n_points][3]), ...] from gathered records"""
     flat = np.asarray(flat, dtype=np.float64).reshape(-1, record_doubles(cap))
     out = []
     for r in flat:
         n = int(r[2])
         out.append(dict(cost=float(r[0]), index=int(r[1]), n_points=n, type=int(r[3]),
-                        path=r[4:4 + 3 * n].reshape(n, 3).copy()))
+                        next_pos=r[4:7].copy(), goal_dist=float(r[7]),
+                        path=r[WINNER_HDR:WINNER_HDR + 3 * n].reshape(n, 3).copy()))
     return out
 
 
-def all_gather_winner_records(local_records, dist, world):
-    """local_records: torch tensor [P_local, rec] (cuda -> RCCL, cpu -> gloo),
-    same P_local on every rank. Returns [world, P_local, rec]; population s of
-    the global numbering is out[s % world, s // world]."""
-    import torch
-    local = local_records.contiguous()
-    out = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-    dist.all_gather_into_tensor(out, local)
-    return out.view((world,) + tuple(local.shape))
+def torch_host_allgather(dist):
+    """the callable of a host-transport communicator (PmafComm.host) over a
+    torch.distributed CPU process group (gloo): bytes in, world * bytes out"""
+    def allgather(send_u8):
+        import torch
+        t = torch.from_numpy(np.ascontiguousarray(send_u8))
+        out = torch.empty(dist.get_world_size() * t.numel(), dtype=torch.uint8)
+        dist.all_gather_into_tensor(out, t)
+        return out.numpy()
+    return allgather
 
 
-def gather_from_planner(planner, dist, world):
-    """winner records of a PmafPlanner straight from device memory: k_winner
-    writes into a CUDA tensor on the planner's stream, the all-gather runs after
-    a stream sync. Returns a [world, P, rec] CUDA tensor."""
-    import torch
-    rec = planner.winner_record_doubles()
-    buf = torch.empty((planner.P, rec), dtype=torch.float64, device="cuda")
-    planner.write_winner_records(buf.data_ptr(), buf.numel() * 8)
-    planner.stop()
-    return all_gather_winner_records(buf, dist, world)
+def make_comm(dist, world, rank, backend="rccl", device=-1):
+    """Communicator of a multi-process run bootstrapped over torch.distributed:
+    "rccl" -- rank 0 draws the ncclUniqueId, the 128 bytes travel through the
+    process group, every rank calls ncclCommInitRank (pmaf_comm_init_rccl);
+    "host" -- all-gathers run on the process group itself (gloo; CPU tests and
+    several ranks sharing one GPU)."""
+    if backend == "host":
+        return _planner.PmafComm.host(world, rank, torch_host_allgather(dist))
+    box = [_planner.PmafComm.unique_id() if rank == 0 else None]
+    if world > 1:
+        dist.broadcast_object_list(box, src=0)
+    return _planner.PmafComm.rccl(world, rank, box[0], device)
+
+
+def all_gather_winner_records(comm, local_records):
+    """local_records [P_local][rec] host array, same P_local on every rank ->
+    [world][P_local][rec]; population s of the global numbering is
+    out[s % world, s // world]. (Host-side exchange through the communicator;
+    handles with an attached communicator exchange on the device instead:
+    PmafPlanner.winners_wait.)"""
+    return comm.allgather(np.ascontiguousarray(local_records, dtype=np.float64))
 
 
 def merge_agent_ranges(costs_per_rank, prev_best_global):
     """Global selection for ONE population whose agents are split into
     contiguous ranges over ranks. costs_per_rank: list of 1-D arrays in rank
     order. prev_best_global: previous best global index or None. Returns the
-    new best global index (evaluateAgents semantics, cf_manager.cpp:336-353)."""
+    new best global index (evaluateAgents semantics, cf_manager.cpp:336-353,
+    evaluated by the library's pmaf_select_best)."""
     costs = np.concatenate([np.asarray(c, dtype=np.float64) for c in costs_per_rank])
-    min_idx, min_cost = 0, np.finfo(np.float64).max
-    for i, c in enumerate(costs):
-        if c < min_cost:
-            min_cost, min_idx = c, i
-    if prev_best_global is not None:
-        if costs[min_idx] < 0.9 * costs[prev_best_global]:
-            return min_idx
-        return prev_best_global
-    return min_idx
+    return _planner.select_best(costs, prev_best_global)
 
 
 class DualArmCoupling:
@@ -117,15 +135,12 @@ class DualArmCoupling:
         return obs
 
 
-def all_gather_positions(local_pos, dist, world):
-    """[P_local][3] set-points of every rank -> [world*P_local][3] (rank-major)"""
-    import torch
-    local = torch.as_tensor(np.ascontiguousarray(local_pos, dtype=np.float64))
-    out = torch.empty((world * local.shape[0], 3), dtype=torch.float64)
-    if dist is None or world == 1:
-        return local.numpy()
-    dist.all_gather_into_tensor(out, local)
-    return out.numpy()
+def all_gather_positions(local_pos, comm):
+    """[P_local][3] set-points of every rank -> [world*P_local][3] (rank-major), one small all-gather"""
+    local = np.ascontiguousarray(local_pos, dtype=np.float64).reshape(-1, 3)
+    if comm is None or comm.world == 1:
+        return local
+    return comm.allgather(local).reshape(-1, 3)
 
 
 class AgentRangeShard:
@@ -193,10 +208,35 @@ class AgentRangeShard:
         return pos
 
 
+def comm_gather(comm, max_agents_per_rank, n_obs):
+    """`gather` of sharded_tick over a communicator, ONE shard per rank: cost
+    vectors travel padded to max_agents_per_rank (padding = DBL_MAX never wins
+    the strict-< argmin and is stripped again), candidate infos as
+    (valid, type, random vectors[n_obs][3])."""
+    big = np.finfo(np.float64).max
+
+    def gather(local):
+        item = local[0]
+        if item is None or isinstance(item, tuple):  # candidate info of the winner's owner
+            buf = np.zeros(2 + 3 * n_obs)
+            if item is not None:
+                buf[0], buf[1] = 1.0, float(item[0])
+                buf[2:] = np.asarray(item[1], dtype=np.float64).reshape(-1)
+            allb = comm.allgather(buf)
+            return [(int(b[1]), b[2:].reshape(n_obs, 3).copy()) if b[0] == 1.0 else None for b in allb]
+        c = np.asarray(item, dtype=np.float64)
+        buf = np.full(1 + max_agents_per_rank, big)
+        buf[0] = c.size
+        buf[1:1 + c.size] = c
+        allb = comm.allgather(buf)
+        return [b[1:1 + int(b[0])].copy() for b in allb]
+    return gather
+
+
 def sharded_tick(shards, prev_best_global, obstacles, dt, cost_gains, ws, gather=None):
     """One planner tick of a population split over `shards` (all shards of this
-    process; with one shard per rank pass gather = an all-gather of Python
-    objects across ranks). Returns (global best index, next real position)."""
+    process; with one shard per rank pass gather = comm_gather(...), an
+    all-gather across ranks). Returns (global best index, next real position)."""
     local = [s.local_costs(cost_gains, ws) for s in shards]
     costs = gather(local) if gather is not None else local
     best = merge_agent_ranges(costs, prev_best_global)

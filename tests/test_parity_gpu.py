@@ -862,6 +862,41 @@ def test_repulsive_obstacle_moving_into_range(pmaf, oracle, scenes):
         hip.close()
 
 
+@pytest.mark.parametrize("lpa,force_generic,ieee", [(0, False, False), (0, True, False), (0, False, True)])
+def test_live_radius_of_the_repulsive_obstacle_differs_from_init(pmaf, oracle, scenes, monkeypatch, lpa, force_generic, ieee):
+    """the caller's live obstacle list may carry another radius for the last
+    (repulsive) obstacle than the list given to init -- shard.DualArmCoupling
+    rewrites it every tick. The real agent's step (RealCfAgent::cfPlanner ->
+    repelForce, cf_agent.cpp:159-181) uses the LIVE radius for both the range
+    test and the distance; the agents' private copies keep the init radius
+    (setObstacles does not copy it, cf_agent.cpp:63-70). Radii chosen so that the
+    live sphere is in range when the init sphere would not be, and vice versa."""
+    if force_generic:
+        monkeypatch.setenv("PMAF_FORCE_GENERIC", "1")
+    sc = scenes.synthetic_scene(12, 120, 8, 9, 3)
+    sc["obstacles"][-1] = [-0.6, 0.55, 0.7, 0.0, 0.0, 0.0, 0.1]     # 0.55 m beside the start: out of range at r = 0.1
+    hip, ora = make_pair(pmaf, oracle, sc, lanes_per_agent=lpa, ieee_sequences=ieee)
+    obs = sc["obstacles"].copy()
+    forces = []
+    for t in range(60):
+        live = obs.copy()
+        live[-1, 6] = (0.30, 0.02, 0.18)[t % 3] if t >= 5 else 0.1   # r = 0.30 / 0.18: in range; 0.02: out
+        bh = hip.tick(live, sc["dt"], sc["cost_gains"], sc["ws_limits"])
+        bo = ora.tick(live, sc["dt"], sc["cost_gains"], sc["ws_limits"])
+        assert bh == bo
+        for a, b in zip(hip.real_state(), ora.real_state()):
+            np.testing.assert_array_equal(a, b)
+        forces.append(hip.real_state()[2].copy())
+    hip.stop()
+    assert_state_equal(hip, ora)
+    # the repulsion was switched on and off by the live radius alone
+    fy = np.asarray(forces)[:, 1]
+    t = np.arange(fy.size)
+    assert np.all(fy[(t >= 5) & (t % 3 == 0)] < -0.4)            # r = 0.30: pushed away from the sphere
+    assert np.all(np.abs(fy[(t >= 5) & (t % 3 == 1)]) < 0.3)     # r = 0.02: out of range, attractor terms only
+    hip.close()
+
+
 def test_handle_lifecycle_does_not_leak_device_memory(pmaf, scenes):
     """create / tick / destroy in a loop: device memory returns to where it was
     (CfManager's destructor joins its threads and frees everything,

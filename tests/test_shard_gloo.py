@@ -1,7 +1,10 @@
-"""world_size-2 gloo test of the multi-GPU path (population sharding + winner
-record all-gather + agent-range merge rule). Runs on CPU: the rank-local
-planner is the oracle (test-only compute stand-in); what is under test is the
-sharding / collective logic of predictive-multi-agent-framework_amd/shard.py."""
+"""world_size-2 gloo tests of the multi-GPU path (population sharding + winner
+record all-gather + agent-range merge rule). Run on CPU: the rank-local
+planner is the oracle (test-only compute stand-in for the kernels); everything
+else is the product path -- shard.py over libpmaf_hip.so's communicator entry
+points (pmaf_comm_init_host / pmaf_comm_allgather / pmaf_select_best) with
+gloo as the host transport. The same code with an RCCL communicator and the
+HIP planner runs in tests/test_shard_gpu.py."""
 import os
 import socket
 import sys
@@ -32,6 +35,7 @@ def _worker(rank, world, port, n_scenes, ticks, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    comm = shard.make_comm(dist, world, rank, backend="host")
     mine = shard.partition_populations(n_scenes, world, rank)
     scs = [pkg.scenes.synthetic_scene(12, 60, 8, 8, s) for s in mine]
     planners = []
@@ -44,15 +48,16 @@ def _worker(rank, world, port, n_scenes, ticks, q):
     for t in range(ticks):
         recs = []
         for sc, o in zip(scs, planners):
+            o.stop()
+            paths, n = o.paths()           # the rollouts this tick's selection scores
             b = o.tick(sc["obstacles"], sc["dt"], sc["cost_gains"], sc["ws_limits"])
-            o.evaluate(sc["cost_gains"], sc["ws_limits"])  # costs of the fresh rollout
-            paths, n = o.paths()
-            bb = o.best_id() - 1
-            recs.append(shard.pack_winner_record(o.costs()[bb], bb, n[bb], o.best_type(), paths[bb], cap))
-        local = torch.from_numpy(np.stack(recs))
-        gathered = shard.all_gather_winner_records(local, dist, world)
-    q.put((rank, gathered.numpy().copy()))
+            pos = o.real_state()[0]
+            recs.append(shard.pack_winner_record(o.costs()[b], b, n[b], o.best_type(), paths[b], cap,
+                                                 next_pos=pos, goal_dist=o.dist_from_goal()))
+        gathered = shard.all_gather_winner_records(comm, np.stack(recs))
+    q.put((rank, gathered.copy()))
     dist.barrier()
+    comm.close()
     dist.destroy_process_group()
 
 
@@ -84,14 +89,14 @@ def test_population_sharding_and_winner_all_gather_world2():
         o = orc.OraclePlanner(sc, mgr_init_pos=sc["start"])
         o.set_initial_position(sc["start"])
         for t in range(ticks):
-            o.tick(sc["obstacles"], sc["dt"], sc["cost_gains"], sc["ws_limits"])
-        o.evaluate(sc["cost_gains"], sc["ws_limits"])
-        paths, n = o.paths()
-        bb = o.best_id() - 1
+            paths, n = o.paths()
+            b = o.tick(sc["obstacles"], sc["dt"], sc["cost_gains"], sc["ws_limits"])
         rec = shard.unpack_winner_records(results[0][s % world, s // world], cap)[0]
-        assert rec["index"] == bb and rec["n_points"] == n[bb] and rec["type"] == o.best_type()
-        np.testing.assert_array_equal(rec["path"], paths[bb, :n[bb]])
-        assert rec["cost"] == o.costs()[bb]
+        assert rec["index"] == b and rec["n_points"] == n[b] and rec["type"] == o.best_type()
+        np.testing.assert_array_equal(rec["path"], paths[b, :n[b]])
+        assert rec["cost"] == o.costs()[b]
+        np.testing.assert_array_equal(rec["next_pos"], o.real_state()[0])
+        assert rec["goal_dist"] == o.dist_from_goal()
 
 
 def test_agent_range_merge_equals_single_population_selection(oracle, scenes):
@@ -135,6 +140,7 @@ def _dual_worker(rank, world, port, ticks, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    comm = shard.make_comm(dist, world, rank, backend="host")
     scs = [_arm_scene(pkg, a) for a in range(2)]
     sc = scs[rank]
     o = orc.OraclePlanner(sc, mgr_init_pos=sc["start"])
@@ -145,10 +151,11 @@ def _dual_worker(rank, world, port, ticks, q):
     for t in range(ticks):
         obs = coupling.coupled_obstacles(pos)
         o.tick(obs[rank], sc["dt"], sc["cost_gains"], sc["ws_limits"])
-        pos = shard.all_gather_positions(o.real_state()[0][None, :], dist, world)  # one 3-double exchange per tick
+        pos = shard.all_gather_positions(o.real_state()[0][None, :], comm)  # one 3-double exchange per tick
         out.append(pos.copy())
     q.put((rank, np.stack(out)))
     dist.barrier()
+    comm.close()
     dist.destroy_process_group()
 
 
@@ -188,3 +195,81 @@ def test_dual_arm_one_population_per_rank_world2():
             o.tick(obs[i], scs[i]["dt"], scs[i]["cost_gains"], scs[i]["ws_limits"])
         pos = np.stack([o.real_state()[0] for o in oras])
         np.testing.assert_array_equal(results[0][t], pos)
+
+
+def _range_worker(rank, world, port, ticks, q):
+    """one agent-range shard per rank, a real cross-process gather"""
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    import __graft_entry__ as graft
+    from oracle import orc
+    pkg = graft.load_package()
+    shard = __import__("pmaf_amd.shard", fromlist=["shard"])
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    comm = shard.make_comm(dist, world, rank, backend="host")
+    sc = _range_scene(pkg)
+    cuts = [0, 9, 24]   # ragged on purpose
+    sh = shard.AgentRangeShard(orc.OraclePlanner, sc, cuts[rank], cuts[rank + 1], mgr_init_pos=sc["start"])
+    sh.planner.set_initial_position(sc["start"])
+    gather = shard.comm_gather(comm, max(b - a for a, b in zip(cuts[:-1], cuts[1:])), sc["obstacles"].shape[0])
+    prev, out = None, []
+    for t in range(ticks):
+        best, pos = shard.sharded_tick([sh], prev, sc["obstacles"], sc["dt"], sc["cost_gains"], sc["ws_limits"], gather)
+        out.append((best, pos.copy()))
+        prev = best
+    sh.planner.stop()
+    q.put((rank, out, sh.planner.paths()))
+    dist.barrier()
+    comm.close()
+    dist.destroy_process_group()
+
+
+def _range_scene(pkg):
+    import json
+    rec = dict(json.load(open(os.path.join(ROOT, "tests", "golden", "task_scenes.json")))["dual_arms_static1"])
+    rec["n_agents"] = 24
+    return pkg.scenes.scene_from_record(rec, "static1_24", horizon=400)
+
+
+@pytest.mark.timeout(300)
+def test_agent_range_shards_one_per_rank_world2():
+    """ONE population split by agent range over two processes (SURVEY 8e
+    fallback): per tick one all-gather of the cost vectors + one of the winner's
+    heuristic, global selection by pmaf_select_best on every rank; set-points,
+    best indices and paths must equal the unsharded oracle's"""
+    import torch.multiprocessing as mp
+    world, ticks = 2, 40
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_range_worker, args=(r, world, port, ticks, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=200) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    res = {r: (o, pa) for r, o, pa in got}
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as graft
+    from oracle import orc
+    pkg = graft.load_package()
+    sc = _range_scene(pkg)
+    ora = orc.OraclePlanner(sc, mgr_init_pos=sc["start"])
+    ora.set_initial_position(sc["start"])
+    seen = set()
+    for t in range(ticks):
+        bo = ora.tick(sc["obstacles"], sc["dt"], sc["cost_gains"], sc["ws_limits"])
+        for r in range(world):
+            assert res[r][0][t][0] == bo
+            np.testing.assert_array_equal(res[r][0][t][1], ora.real_state()[0])
+        seen.add(bo)
+    assert len(seen) >= 3
+    po, no = ora.paths()
+    cuts = [0, 9, 24]
+    for r in range(world):
+        ph, nh = res[r][1]
+        np.testing.assert_array_equal(nh, no[cuts[r]:cuts[r + 1]])
+        np.testing.assert_array_equal(ph, po[cuts[r]:cuts[r + 1]])

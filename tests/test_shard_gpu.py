@@ -1,0 +1,393 @@
+"""GPU tests of the multi-GPU path through the C-ABI (include/pmaf.h "multi-GPU"):
+an RCCL communicator created by libpmaf_hip.so itself (1 rank: the box has one
+GPU), the stream-ordered winner-record all-gather, the per-tick exchange that
+overlaps the rollout, and -- with two processes sharing GPU 0 over a
+host-transport communicator (RCCL refuses two ranks on one device) -- the
+population-sharded, dual-arm and agent-range layouts with the HIP planner on
+every rank."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(autouse=True)
+def _portable_exp_oracle(oracle):
+    oracle.set_exp_mode(1)
+    yield
+    oracle.set_exp_mode(0)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _scenes3(scenes):
+    return [scenes.synthetic_scene(24, 90, 12, 5, s) for s in range(3)]
+
+
+def test_rccl_one_rank_allgather_winners_stream_ordered(pmaf, scenes):
+    """tick -> evaluate -> pmaf_allgather_winners (k_winner + ncclAllGather on the
+    handle's stream, no host sync in between) with a 1-rank RCCL communicator
+    created by the library: the received records equal the host getters bit for
+    bit -- RCCL and libpmaf_hip.so share one HIP runtime in this process"""
+    torch = pytest.importorskip("torch")
+    scs = _scenes3(scenes)
+    starts = np.stack([s["start"] for s in scs])
+    hip = pmaf.PmafPlanner(scs, device=0, mgr_init_pos=starts)
+    hip.set_initial_position(starts)
+    comm = pmaf.PmafComm.rccl(1, 0, pmaf.PmafComm.unique_id(), 0)
+    assert comm.world == 1 and comm.rank == 0
+    sc = scs[0]
+    obs = np.stack([s["obstacles"] for s in scs])
+    for t in range(5):
+        hip.tick(obs, sc["dt"], sc["cost_gains"], sc["ws_limits"])
+    hip.stop()
+    best = hip.evaluate(sc["cost_gains"], sc["ws_limits"])
+    rec = hip.winner_record_doubles()
+    assert rec == 8 + 3 * sc["max_prediction_steps"]
+    buf = torch.full((1, 3, rec), -1.0, dtype=torch.float64, device="cuda:0")
+    hip.allgather_winners(comm, buf.data_ptr(), buf.numel() * 8)
+    hip.stop()   # = a stream-ordered consumer's view
+    out = pmaf.shard.unpack_winner_records(buf.cpu().numpy(), sc["max_prediction_steps"])
+    paths, n = hip.paths()
+    costs = hip.costs()
+    pos = hip.real_state()[0]
+    dg = hip.dist_from_goal()
+    for p in range(3):
+        assert out[p]["index"] == best[p] and out[p]["n_points"] == n[p, best[p]]
+        assert out[p]["cost"] == costs[p, best[p]]
+        assert out[p]["type"] == hip.best()[0][p]
+        np.testing.assert_array_equal(out[p]["path"], paths[p, best[p], :n[p, best[p]]])
+        np.testing.assert_array_equal(out[p]["next_pos"], pos[p])
+        assert out[p]["goal_dist"] == dg[p]
+    # the control-plane all-gather of host data through the same communicator
+    a = np.arange(7.0)
+    np.testing.assert_array_equal(comm.allgather(a), a[None])
+    hip.close()
+    comm.close()
+
+
+@pytest.mark.parametrize("transport", ["rccl", "host"])
+def test_attached_exchange_every_tick_matches_getters_and_oracle(pmaf, oracle, scenes, transport):
+    """pmaf_attach_comm: every pmaf_tick publishes its selection's winner records
+    and all-gathers them on the exchange stream while the next rollout runs (the
+    handle double-buffers its paths). Per tick the received table must hold the
+    selected agent's path of the rollout that was scored, its cost, the new
+    set-point; and the planner must stay bit-identical to the oracle."""
+    scs = _scenes3(scenes)
+    starts = np.stack([s["start"] for s in scs])
+    hip = pmaf.PmafPlanner(scs, device=0, mgr_init_pos=starts)
+    hip.set_initial_position(starts)
+    oras = []
+    for s in scs:
+        o = oracle.OraclePlanner(s, mgr_init_pos=s["start"])
+        o.set_initial_position(s["start"])
+        oras.append(o)
+    if transport == "rccl":
+        comm = pmaf.PmafComm.rccl(1, 0, pmaf.PmafComm.unique_id(), 0)
+    else:
+        comm = pmaf.PmafComm.host(1, 0, lambda b: b)
+    hip.attach_comm(comm)
+    sc = scs[0]
+    cap = sc["max_prediction_steps"]
+    obs = np.stack([s["obstacles"] for s in scs])
+    for t in range(30):
+        hip.stop()
+        prev_paths, prev_n = hip.paths()                   # what this tick's selection scores
+        best = hip.tick(obs, sc["dt"], sc["cost_gains"], sc["ws_limits"])
+        tab = hip.winners_wait()
+        assert tab.shape == (1, 3, 8 + 3 * cap)
+        recs = pmaf.shard.unpack_winner_records(tab[0], cap)
+        costs = hip.costs()
+        pos = hip.real_state()[0]
+        for p in range(3):
+            bo = oras[p].tick(obs[p], sc["dt"], sc["cost_gains"], sc["ws_limits"])
+            assert best[p] == bo and recs[p]["index"] == bo
+            assert recs[p]["n_points"] == prev_n[p, bo]
+            np.testing.assert_array_equal(recs[p]["path"], prev_paths[p, bo, :prev_n[p, bo]])
+            assert recs[p]["cost"] == costs[p, bo] == oras[p].costs()[bo]
+            np.testing.assert_array_equal(recs[p]["next_pos"], pos[p])
+            np.testing.assert_array_equal(pos[p], oras[p].real_state()[0])
+    hip.stop()
+    ph, nh = hip.paths()
+    for p in range(3):
+        po, no = oras[p].paths()
+        np.testing.assert_array_equal(nh[p], no)
+        np.testing.assert_array_equal(ph[p], po)
+    times = hip.exchange_times_us()
+    assert times.size == 30 and np.all(times >= 0)
+    # checkpoint with an exchange attached, restore into a plain handle: identical continuation
+    blob = hip.save_state()
+    hip2 = pmaf.PmafPlanner(scs, device=0, mgr_init_pos=starts)
+    hip2.load_state(blob)
+    for t in range(5):
+        b1 = hip.tick(obs, sc["dt"], sc["cost_gains"], sc["ws_limits"])
+        b2 = hip2.tick(obs, sc["dt"], sc["cost_gains"], sc["ws_limits"])
+        np.testing.assert_array_equal(b1, b2)
+        np.testing.assert_array_equal(hip.real_state()[0], hip2.real_state()[0])
+    # detach: back to one path buffer, still the same planner
+    hip.attach_comm(None)
+    for t in range(3):
+        np.testing.assert_array_equal(hip.tick(obs, sc["dt"], sc["cost_gains"], sc["ws_limits"]),
+                                      hip2.tick(obs, sc["dt"], sc["cost_gains"], sc["ws_limits"]))
+    hip.stop(); hip2.stop()
+    np.testing.assert_array_equal(hip.paths()[0], hip2.paths()[0])
+    with pytest.raises(pmaf.PmafError):
+        hip.winners_wait()
+    hip.close(); hip2.close(); comm.close()
+
+
+def test_step_api_exchange_after_evaluate(pmaf, scenes):
+    """stop / evaluate / move / reset / start with a communicator attached: the
+    evaluate publishes the records; reset and restart must not disturb them"""
+    scs = _scenes3(scenes)
+    starts = np.stack([s["start"] for s in scs])
+    hip = pmaf.PmafPlanner(scs, device=0, mgr_init_pos=starts)
+    hip.set_initial_position(starts)
+    comm = pmaf.PmafComm.rccl(1, 0, pmaf.PmafComm.unique_id(), 0)
+    hip.attach_comm(comm)
+    sc = scs[0]
+    cap = sc["max_prediction_steps"]
+    obs = np.stack([s["obstacles"] for s in scs])
+    hip.start()
+    for t in range(6):
+        hip.stop()
+        paths, n = hip.paths()
+        best = hip.evaluate(sc["cost_gains"], sc["ws_limits"])
+        hip.move_real(obs, sc["dt"], 1, best)
+        pos, vel, _ = hip.real_state()
+        hip.reset_agents(pos, vel, obs)
+        hip.start()
+        recs = pmaf.shard.unpack_winner_records(hip.winners_wait()[0], cap)
+        for p in range(3):
+            assert recs[p]["index"] == best[p]
+            np.testing.assert_array_equal(recs[p]["path"], paths[p, best[p], :n[p, best[p]]])
+    hip.close(); comm.close()
+
+
+# ---------------------------------------------------------------------------
+# two processes on GPU 0 (host-transport communicator over gloo)
+# ---------------------------------------------------------------------------
+def _setup_worker(rank, world, port):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch  # noqa: F401  (before libpmaf_hip.so: one HIP runtime per process)
+    import torch.distributed as dist
+    import __graft_entry__ as graft
+    pkg = graft.load_package()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    comm = pkg.shard.make_comm(dist, world, rank, backend="host")
+    return pkg, dist, comm
+
+
+def _pop_worker(rank, world, port, n_scenes, ticks, q):
+    pkg, dist, comm = _setup_worker(rank, world, port)
+    mine = pkg.shard.partition_populations(n_scenes, world, rank)
+    scs = [pkg.scenes.synthetic_scene(12, 60, 8, 8, s) for s in mine]
+    starts = np.stack([s["start"] for s in scs])
+    hip = pkg.PmafPlanner(scs, device=0, mgr_init_pos=starts)
+    hip.set_initial_position(starts)
+    hip.attach_comm(comm)
+    sc = scs[0]
+    obs = np.stack([s["obstacles"] for s in scs])
+    tab = None
+    for t in range(ticks):
+        hip.tick(obs, sc["dt"], sc["cost_gains"], sc["ws_limits"])
+        tab = hip.winners_wait()
+    q.put((rank, tab.copy()))
+    dist.barrier()
+    hip.close()
+    comm.close()
+    dist.destroy_process_group()
+
+
+def _spawn(target, world, *args):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=target, args=(r, world, port) + args + (q,)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=280) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    return got
+
+
+@pytest.mark.timeout(400)
+def test_population_sharding_two_ranks_hip_planner(pmaf, oracle, scenes):
+    """4 scenes over 2 ranks, HIP planner + attached exchange on every rank:
+    both ranks end with the same table and it equals the unsharded oracles'"""
+    world, n_scenes, ticks = 2, 4, 6
+    res = dict(_spawn(_pop_worker, world, n_scenes, ticks))
+    np.testing.assert_array_equal(res[0], res[1])
+    cap = 61
+    for s in range(n_scenes):
+        sc = scenes.synthetic_scene(12, 60, 8, 8, s)
+        o = oracle.OraclePlanner(sc, mgr_init_pos=sc["start"])
+        o.set_initial_position(sc["start"])
+        for t in range(ticks):
+            paths, n = o.paths()
+            b = o.tick(sc["obstacles"], sc["dt"], sc["cost_gains"], sc["ws_limits"])
+        rec = pmaf.shard.unpack_winner_records(res[0][s % world, s // world], cap)[0]
+        assert rec["index"] == b and rec["n_points"] == n[b] and rec["type"] == o.best_type()
+        np.testing.assert_array_equal(rec["path"], paths[b, :n[b]])
+        assert rec["cost"] == o.costs()[b]
+        np.testing.assert_array_equal(rec["next_pos"], o.real_state()[0])
+
+
+def _dual_worker(rank, world, port, ticks, q):
+    pkg, dist, comm = _setup_worker(rank, world, port)
+    arms = pkg.scenes.dual_arm_scenes(64, 150, 24)
+    sc = arms[rank]
+    hip = pkg.PmafPlanner(sc, device=0, mgr_init_pos=sc["start"])
+    hip.set_initial_position(sc["start"])
+    hip.attach_comm(comm)
+    coupling = pkg.shard.DualArmCoupling(np.stack([s["obstacles"] for s in arms]), 0.1)
+    pos = np.stack([s["start"] for s in arms])
+    out = []
+    for t in range(ticks):
+        o = coupling.coupled_obstacles(pos)
+        hip.tick(o[rank], sc["dt"], sc["cost_gains"], sc["ws_limits"])
+        pos = hip.winners_wait()[:, 0, 4:7].copy()     # both arms' set-points out of the winner records
+        out.append(pos.copy())
+    q.put((rank, np.stack(out)))
+    dist.barrier()
+    hip.close()
+    comm.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(400)
+def test_c4_dual_arm_one_arm_per_rank_hip_planner(pmaf, oracle, scenes):
+    """BASELINE config 4 layout: arm r on rank r, the set-points travel in the
+    per-tick winner records; equals two coupled oracles in one process"""
+    world, ticks = 2, 200
+    res = dict(_spawn(_dual_worker, world, ticks))
+    np.testing.assert_array_equal(res[0], res[1])
+    arms = scenes.dual_arm_scenes(64, 150, 24)
+    oras = []
+    for s in arms:
+        o = oracle.OraclePlanner(s, mgr_init_pos=s["start"])
+        o.set_initial_position(s["start"])
+        oras.append(o)
+    coupling = pmaf.shard.DualArmCoupling(np.stack([s["obstacles"] for s in arms]), 0.1)
+    pos = np.stack([s["start"] for s in arms])
+    min_gap = 1e9
+    for t in range(ticks):
+        obs = coupling.coupled_obstacles(pos)
+        for i, o in enumerate(oras):
+            o.tick(obs[i], arms[i]["dt"], arms[i]["cost_gains"], arms[i]["ws_limits"])
+        pos = np.stack([o.real_state()[0] for o in oras])
+        np.testing.assert_array_equal(res[0][t], pos)
+        min_gap = min(min_gap, np.linalg.norm(pos[0] - pos[1]))
+    assert min_gap < arms[0]["detect_shell_rad"] + 0.15   # the spheres came into range: the coupling was exercised
+
+
+def _range_scene(pkg):
+    import json
+    rec = dict(json.load(open(os.path.join(ROOT, "tests", "golden", "task_scenes.json")))["dual_arms_static1"])
+    rec["n_agents"] = 24
+    return pkg.scenes.scene_from_record(rec, "static1_24", horizon=400)
+
+
+def _range_worker(rank, world, port, ticks, q):
+    pkg, dist, comm = _setup_worker(rank, world, port)
+    sc = _range_scene(pkg)
+    cuts = [0, 9, 24]
+    sh = pkg.shard.AgentRangeShard(pkg.PmafPlanner, sc, cuts[rank], cuts[rank + 1], device=0, mgr_init_pos=sc["start"])
+    sh.planner.set_initial_position(sc["start"])
+    gather = pkg.shard.comm_gather(comm, 15, sc["obstacles"].shape[0])
+    prev, out = None, []
+    for t in range(ticks):
+        best, pos = pkg.shard.sharded_tick([sh], prev, sc["obstacles"], sc["dt"], sc["cost_gains"], sc["ws_limits"], gather)
+        out.append((best, np.asarray(pos).copy()))
+        prev = best
+    sh.planner.stop()
+    q.put((rank, out, sh.planner.paths()))
+    dist.barrier()
+    sh.planner.close()
+    comm.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(400)
+def test_agent_range_shards_two_ranks_hip_planner(pmaf, oracle, scenes):
+    """ONE population split by agent range over two processes with the HIP
+    planner on each: set-points, best indices, paths equal the unsharded oracle"""
+    world, ticks = 2, 40
+    got = _spawn(_range_worker, world, ticks)
+    res = {r: (o, pa) for r, o, pa in got}
+    sc = _range_scene(pmaf)
+    ora = oracle.OraclePlanner(sc, mgr_init_pos=sc["start"])
+    ora.set_initial_position(sc["start"])
+    seen = set()
+    for t in range(ticks):
+        bo = ora.tick(sc["obstacles"], sc["dt"], sc["cost_gains"], sc["ws_limits"])
+        for r in range(world):
+            assert res[r][0][t][0] == bo
+            np.testing.assert_array_equal(res[r][0][t][1], ora.real_state()[0])
+        seen.add(bo)
+    assert len(seen) >= 3
+    po, no = ora.paths()
+    cuts = [0, 9, 24]
+    for r in range(world):
+        ph, nh = res[r][1]
+        np.testing.assert_array_equal(nh, no[cuts[r]:cuts[r + 1]])
+        np.testing.assert_array_equal(ph, po[cuts[r]:cuts[r + 1]])
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("args,n_ranks", [
+    ([], 2),                                   # default multi-GPU workload: C2 per rank + winner all-gather
+    (["--config", "C5", "--shard", "--total-populations", "4"], 2),
+    (["--config", "C4"], 2),
+])
+def test_bench_multi_rank_modes_on_one_gpu(args, n_ranks):
+    """bench.py's N > 1 workloads, run as 2 ranks sharing GPU 0 with the host
+    transport (test hooks PMAF_BENCH_BACKEND=gloo / PMAF_BENCH_SINGLE_DEVICE=1):
+    the JSON line carries the collective's timing and per-rank tick times"""
+    import json
+    import subprocess
+    env = dict(os.environ, PMAF_BENCH_BACKEND="gloo", PMAF_BENCH_SINGLE_DEVICE="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_ranks),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"),
+           "--gpus", str(n_ranks), "--steps", "12", "--warmup", "3", "--min-seconds", "0.05", "--flop-ticks", "0"] + args
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=500, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == n_ranks and out["value"] > 0
+    assert out["allgather_us"]["n"] >= 12 and out["allgather_us"]["median"] is not None
+    assert len(out["tick_latency_us"]["per_rank_median"]) == n_ranks
+    assert out["h_eff"] == out["config"]["horizon"]
+
+
+@pytest.mark.timeout(600)
+def test_bench_single_rank_rccl_exchange():
+    """bench.py with PMAF_BENCH_FORCE_DIST=1: one rank, torch.distributed (nccl)
+    plus the library's own RCCL communicator and the per-tick exchange"""
+    import json
+    import subprocess
+    env = dict(os.environ, PMAF_BENCH_FORCE_DIST="1", MASTER_PORT=str(_free_port()))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "5",
+                        "--min-seconds", "0.1", "--cpu-seconds", "0", "--flop-ticks", "0"],
+                       capture_output=True, text=True, timeout=500, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["allgather_us"]["n"] >= 20 and "RCCL" in out["config"]["workload"]

@@ -14,8 +14,14 @@
 //  * Random agents draw their vectors from a seeded generator
 //    (setRandomSeed) instead of std::random_device
 //    (B/src/helper_functions.cpp:7-13).
-//  * moveAgent / moveAgents / moveAgentsPar (no callers in the reference,
-//    B/src/cf_manager.cpp:265-291) throw std::logic_error.
+//  * moveAgent / moveAgents / moveAgentsPar / setEEAgentPositions /
+//    setEEAgentPosAndVels (no callers in the reference, B/src/cf_manager.cpp:220-291)
+//    run on the device with fixed-size path buffers (max_prediction_steps points).
+//  * the class is movable but not copyable (the reference declares its copy
+//    operations defaulted, which the compiler deletes: unique_ptr / std::thread
+//    members, cf_manager.h:19-21,34,52-55).
+//  * getPredictedPaths() returns a const reference to a cached copy instead of a
+//    new copy per call (source compatible with the node's uses).
 //  * errors of the device layer surface as std::runtime_error.
 //
 // Vector type: Eigen::Vector3d when PMAF_USE_EIGEN is defined (a ROS box),
@@ -28,6 +34,7 @@
 #include <random>
 #include <stdexcept>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "bimanual_planning_ros/obstacle.h"
@@ -61,6 +68,12 @@ class CfManager {
   std::vector<double> best_rand_;         // [n_obs][3]
   uint64_t seed_ = 0x9E3779B97F4A7C15ull;
   int device_ = -1;
+  // getPredictedPaths() is called 3 x N times per tick by the reference's node when
+  // visualize_predicted_paths is on (B/src/panda_bimanual_control.cpp:341-344): the
+  // converted paths are kept until a call that changes them
+  std::vector<std::vector<Vector3d>> paths_cache_;
+  bool paths_cached_ = false;
+  void touch() { paths_cached_ = false; }
 
   static void check(int rc, const char *what) {
     if (rc != PMAF_OK) throw std::runtime_error(std::string(what) + ": " + pmaf_last_error());
@@ -107,8 +120,26 @@ class CfManager {
          approach_dist, detect_shell_rad);
   }
   ~CfManager() { if (h_) pmaf_destroy(h_); }
-  CfManager(const CfManager &) = delete;
+  CfManager(const CfManager &) = delete;             // implicitly deleted in the reference too (see header comment)
   CfManager &operator=(const CfManager &) = delete;
+  CfManager(CfManager &&o) noexcept { *this = std::move(o); }    // cf_manager.h:53
+  CfManager &operator=(CfManager &&o) noexcept {                 // cf_manager.h:55
+    if (this != &o) {
+      if (h_) pmaf_destroy(h_);
+      h_ = o.h_; o.h_ = nullptr;
+      n_agents_ = o.n_agents_; n_obs_ = o.n_obs_; cap_ = o.cap_;
+      init_pos_ = o.init_pos_; goal_pos_ = o.goal_pos_;
+      k_r_force_ = std::move(o.k_r_force_);
+      random_vecs_ = std::move(o.random_vecs_);
+      best_id_ = o.best_id_; best_type_ = o.best_type_;
+      best_rand_ = std::move(o.best_rand_);
+      seed_ = o.seed_; device_ = o.device_;
+      paths_cache_ = std::move(o.paths_cache_);
+      paths_cached_ = o.paths_cached_; o.paths_cached_ = false;
+      random_vecs_override_ = std::move(o.random_vecs_override_);
+    }
+    return *this;
+  }
 
   // ---- build-specific knobs (no reference equivalent) ----
   void setRandomSeed(uint64_t seed) { seed_ = seed; }
@@ -130,6 +161,7 @@ class CfManager {
           (k_c_ee.size() == k_manip.size()) && (k_d_ee.size() == k_a_ee.size())))
       throw std::invalid_argument("CfManager::init: gain vectors must have equal sizes");  // assert, :50
     remember_best();
+    touch();
     if (h_) { pmaf_destroy(h_); h_ = nullptr; }
     goal_pos_ = goal_pos;
     k_r_force_ = k_r_force;
@@ -184,25 +216,33 @@ class CfManager {
     }
   }
 
-  void startPrediction() { require(); check(pmaf_start(h_), "startPrediction"); }   // cf_manager.h:57-61
+  void startPrediction() { require(); touch(); check(pmaf_start(h_), "startPrediction"); }   // cf_manager.h:57-61
   void stopPrediction() { require(); check(pmaf_stop(h_), "stopPrediction"); }      // cf_manager.cpp:126-140
   void shutdownAllAgents() {}                                                       // no threads to stop
   void joinPredictionThreads() { if (h_) check(pmaf_stop(h_), "joinPredictionThreads"); }
 
-  std::vector<std::vector<Vector3d>> getPredictedPaths() {                          // cf_manager.cpp:184-190
+  // cf_manager.cpp:184-190. Returned by const reference to the cached conversion (the reference returns a fresh
+  // copy each time): `getPredictedPaths().size()`, `.at(i)`, `auto p = getPredictedPaths();` compile unchanged and
+  // the node's 3 N + 1 calls per tick cost nothing. Valid until the next call that changes the predicted paths.
+  const std::vector<std::vector<Vector3d>> &getPredictedPaths() {
     require();
-    std::vector<double> p((size_t)n_agents_ * cap_ * 3);
-    std::vector<int32_t> n(n_agents_);
-    check(pmaf_get_paths(h_, p.data(), n.data()), "getPredictedPaths");
-    std::vector<std::vector<Vector3d>> out(n_agents_);
-    for (int a = 0; a < n_agents_; ++a) {
-      out[a].reserve(n[a]);
-      for (int k = 0; k < n[a]; ++k) {
-        const double *q = &p[((size_t)a * cap_ + k) * 3];
-        out[a].push_back(Vector3d(q[0], q[1], q[2]));
+    if (!paths_cached_) {
+      const double *p = nullptr;
+      const int32_t *n = nullptr;
+      check(pmaf_view_paths(h_, &p, &n), "getPredictedPaths");   // the handle's host mirror: one D2H per rollout
+      paths_cache_.resize(n_agents_);
+      for (int a = 0; a < n_agents_; ++a) {
+        std::vector<Vector3d> &out = paths_cache_[a];
+        out.clear();
+        out.reserve(n[a]);
+        for (int k = 0; k < n[a]; ++k) {
+          const double *q = &p[((size_t)a * cap_ + k) * 3];
+          out.push_back(Vector3d(q[0], q[1], q[2]));
+        }
       }
+      paths_cached_ = true;
     }
-    return out;
+    return paths_cache_;
   }
   std::vector<double> getPredictedPathLengths() {                                   // :192-198
     require();
@@ -251,9 +291,10 @@ class CfManager {
   Vector3d getGoalPosition() const { return goal_pos_; }                            // :80
   int getNumPredictionSteps(int agent_id) {                                         // :81-83
     require();
-    std::vector<int32_t> n(n_agents_);
-    check(pmaf_get_paths(h_, nullptr, n.data()), "getNumPredictionSteps");
-    return n.at(agent_id);
+    if (agent_id < 0 || agent_id >= n_agents_) throw std::out_of_range("getNumPredictionSteps: agent index");
+    const int32_t *n = nullptr;
+    check(pmaf_view_paths(h_, nullptr, &n), "getNumPredictionSteps");
+    return n[agent_id];
   }
   int getRealNumPredictionSteps() {                                                 // :84-86
     require();
@@ -288,6 +329,7 @@ class CfManager {
     for (size_t i = 0; i < link_positions.size(); ++i) {
       lp[i * 3] = link_positions[i].x(); lp[i * 3 + 1] = link_positions[i].y(); lp[i * 3 + 2] = link_positions[i].z();
     }
+    if ((int)obstacles.size() != n_obs_) throw std::out_of_range("getLinkForce: obstacle count changed");  // obstacles.back()
     const std::vector<double> obs = flat(obstacles);
     check(pmaf_link_force(h_, 0, (int32_t)link_positions.size(), lp.data(), k_r_force_.data(), obs.data(), out.data()),
           "getLinkForce");
@@ -308,6 +350,7 @@ class CfManager {
   }
   void setInitialEEPositions(const Vector3d &position) {                            // :231-236
     if (!h_) return;  // default-constructed manager: no agents yet (empty loops in the reference)
+    touch();
     const double p[3] = {position.x(), position.y(), position.z()};
     check(pmaf_set_initial_position(h_, p), "setInitialPosition");
   }
@@ -318,6 +361,7 @@ class CfManager {
     const double v[3] = {velocity.x(), velocity.y(), velocity.z()};
     const std::vector<double> obs = flat(obstacles);
     if ((int)obstacles.size() != n_obs_) throw std::out_of_range("resetEEAgents: obstacle count changed");  // .at(), cf_agent.cpp:66
+    touch();
     check(pmaf_reset_agents(h_, p, v, obs.data()), "resetEEAgents");
   }
   // CfManager::moveRealEEAgent, :257-263
@@ -347,6 +391,8 @@ class CfManager {
                const double k_path_len, const double k_safe_dist, const double k_workspace,
                const Vector6d des_ws_limits, Vector3d *next_position = nullptr) {
     require();
+    if ((int)obstacles.size() != n_obs_) throw std::out_of_range("planTick: obstacle count changed");
+    touch();
     const std::vector<double> obs = flat(obstacles);
     const double gains[4] = {k_goal_dist, k_path_len, k_safe_dist, k_workspace};
     double ws[6];
@@ -358,12 +404,51 @@ class CfManager {
     return best;
   }
 
-  // no callers in the reference (B/src/cf_manager.cpp:220-224, 238-244, 265-291); not on the accelerated path
-  void setEEAgentPositions(const Vector3d &) { throw std::logic_error("setEEAgentPositions: not supported"); }
-  void setEEAgentPosAndVels(const Vector3d &, const Vector3d &) { throw std::logic_error("setEEAgentPosAndVels: not supported"); }
-  void moveAgent(const std::vector<Obstacle> &, const double, const int, const int) { throw std::logic_error("moveAgent: not supported"); }
-  void moveAgents(const std::vector<Obstacle> &, const double, const int = 1) { throw std::logic_error("moveAgents: not supported"); }
-  void moveAgentsPar(const std::vector<Obstacle> &, const double, const int = 1) { throw std::logic_error("moveAgentsPar: not supported"); }
+  // ---- synchronous stepping API (no callers in the reference; B/src/cf_manager.cpp:220-224, 238-244, 265-291) ----
+  void setEEAgentPositions(const Vector3d &position) {                              // :220-224
+    require();
+    touch();
+    const double p[3] = {position.x(), position.y(), position.z()};
+    check(pmaf_set_agent_positions(h_, p), "setEEAgentPositions");
+  }
+  void setEEAgentPosAndVels(const Vector3d &position, const Vector3d &velocity) {   // :238-244
+    require();
+    touch();
+    const double p[3] = {position.x(), position.y(), position.z()};
+    const double v[3] = {velocity.x(), velocity.y(), velocity.z()};
+    check(pmaf_set_agent_pos_and_vels(h_, p, v), "setEEAgentPosAndVels");
+  }
+  // moveAgent (:265-272): cfPlanner(steps) while the agent is farther than 0.05 from the goal -- bounded here by
+  // the path buffer (max_prediction_steps points)
+  void moveAgent(const std::vector<Obstacle> &obstacles, const double delta_t, const int steps, const int id) {
+    require();
+    if ((int)obstacles.size() != n_obs_) throw std::out_of_range("moveAgent: obstacle count changed");
+    if (id < 0 || id >= n_agents_) throw std::out_of_range("moveAgent: agent index");
+    touch();
+    const std::vector<double> obs = flat(obstacles);
+    const int32_t a = id;
+    check(pmaf_move_agent(h_, obs.data(), delta_t, steps, &a, 0x7fffffff, nullptr), "moveAgent");
+  }
+  void moveAgents(const std::vector<Obstacle> &obstacles, const double delta_t, const int steps = 1) {  // :274-282
+    require();
+    if ((int)obstacles.size() != n_obs_) throw std::out_of_range("moveAgents: obstacle count changed");
+    touch();
+    const std::vector<double> obs = flat(obstacles);
+    check(pmaf_move_agents(h_, obs.data(), delta_t, steps), "moveAgents");
+  }
+  void moveAgentsPar(const std::vector<Obstacle> &obstacles, const double delta_t, const int steps = 1) {  // :284-291
+    moveAgents(obstacles, delta_t, steps);  // every agent is its own wave / lane group on the device anyway
+  }
+  // CfAgent::evalObstacleDistance (B/src/cf_agent.cpp:146-157) of every predicted agent (the reference exposes it
+  // per agent object; the agents live on the device here)
+  std::vector<double> evalObstacleDistances(const std::vector<Obstacle> &obstacles) {
+    require();
+    if ((int)obstacles.size() != n_obs_) throw std::out_of_range("evalObstacleDistances: obstacle count changed");
+    const std::vector<double> obs = flat(obstacles);
+    std::vector<double> out(n_agents_);
+    check(pmaf_eval_obstacle_distance(h_, obs.data(), out.data()), "evalObstacleDistances");
+    return out;
+  }
 
  private:
   std::vector<double> random_vecs_override_;

@@ -17,8 +17,14 @@
 //                               (B/src/dynamic_obstacle_node.cpp:352-383):
 //                               cur_pos += cur_vel / frequency for the first M
 //                               obstacles, published as an Obstacles message;
-//   validateSetPoint            what the consumer accepts
-//                               (B/src/costp_controller.cpp:289-344: finite,
+//   SetPointConsumer            (setpoint_consumer.h) the receiving side of the
+//                               "goals" topic: TrajectoryBuffer + the trajectory
+//                               half of CoSTPController::followTrajectory
+//                               (B/src/costp_controller.cpp:289-344,
+//                               B/src/trajectory_buffer.cpp:13-64) and the
+//                               hand-over loop of VrepController
+//                               (B/src/vrep_controller.cpp:100-115);
+//   validateSetPoint            the stateless part of that contract (finite,
 //                               >= 1e-6 m from the previous point).
 // B/ = reference src/bimanual_planning_ros/. No ROS types: topics become plain
 // function calls so the loop can run head-less (tools/plan_task.cpp).
@@ -35,6 +41,7 @@
 #include <vector>
 
 #include "bimanual_planning_ros/cf_manager.h"
+#include "bimanual_planning_ros/setpoint_consumer.h"
 
 namespace ghostplanner {
 namespace cfplanner {
@@ -350,7 +357,8 @@ class PlannerNode {
   bool reached() const { return cf_manager_.getDistFromGoal() < 0.01; }
   void finishGoal() { planning_active_ = false; }     // :583-587
   double goalDistance() const { return cf_manager_.getDistFromGoal(); }  // "goal_distance" topic, :358-360
-  std::vector<std::vector<Vector3d>> predictedPaths() { return cf_manager_.getPredictedPaths(); }  // :340-347
+  const std::vector<std::vector<Vector3d>> &predictedPaths() { return cf_manager_.getPredictedPaths(); }  // :340-347
+  double velocity() const { return prm_.velocity; }
   const std::vector<Vector3d> &commandedPath() const { return commanded_path_; }                   // :361-363
 };
 

@@ -149,6 +149,32 @@ int pmaf_tick(pmaf_planner *h, const double *obstacles, double dt,
               const double *cost_gains, const double *ws, int32_t *best_idx,
               double *next_pos, double *next_vel);
 
+/* ---- synchronous stepping API of the class surface (no callers in the reference) ----
+ * CfManager::moveAgents / moveAgentsPar (B/src/cf_manager.cpp:274-291) ->
+ * CfAgent::cfPlanner (B/src/cf_agent.cpp:278-300): every agent takes `steps`
+ * steps of length dt from its CURRENT state through the caller's obstacle list
+ * [P][n_obstacles][7] (positions, velocities and radii as given; no obstacle
+ * advance, no loop guard). Paths are bounded by max_prediction_steps here
+ * (PMAF_ERR_STATE if a path would outgrow it; the reference's grow without
+ * bound). After a stepping call pmaf_start needs a pmaf_reset_agents /
+ * pmaf_set_* first (rollouts start from the population's reset state). */
+int pmaf_move_agents(pmaf_planner *h, const double *obstacles, double dt, int32_t steps);
+/* CfManager::moveAgent (B/src/cf_manager.cpp:265-272): agent agent_id[p] repeats
+ * cfPlanner(steps) while it is farther than 0.05 from the goal -- at most
+ * max_calls times and while the path buffer has room; calls [P] (may be NULL)
+ * = cfPlanner calls made. */
+int pmaf_move_agent(pmaf_planner *h, const double *obstacles, double dt, int32_t steps,
+                    const int32_t *agent_id, int32_t max_calls, int32_t *calls);
+/* CfManager::setEEAgentPositions (B/src/cf_manager.cpp:220-224): every agent's
+ * path restarts at pos [P][3]; velocities stay. */
+int pmaf_set_agent_positions(pmaf_planner *h, const double *pos);
+/* CfManager::setEEAgentPosAndVels (B/src/cf_manager.cpp:238-244): pos, vel [P][3]
+ * (velocity clamped to velocity_max, CfAgent::setVelocity). */
+int pmaf_set_agent_pos_and_vels(pmaf_planner *h, const double *pos, const double *vel);
+/* CfAgent::evalObstacleDistance (B/src/cf_agent.cpp:146-157) of every agent at
+ * its latest position against obstacles [P][n_obstacles][7]; out [P][N]. */
+int pmaf_eval_obstacle_distance(pmaf_planner *h, const double *obstacles, double *out);
+
 /* CfManager::getLinkForce -> CfAgent::bodyForce, B/src/cf_manager.cpp:169-182,
  * B/src/cf_agent.cpp:229-234: repel-only force of population `pop`'s last
  * obstacle at n link points. link_pos [n][3], k_r_force [n], out [n][3]. */
@@ -163,6 +189,14 @@ int pmaf_link_force(pmaf_planner *h, int32_t pop, int32_t n,
  * from host copies and return at once, like the reference's. */
 /* getPredictedPaths / getNumPredictionSteps: paths [P][N][cap][3], n_points [P][N] */
 int pmaf_get_paths(pmaf_planner *h, double *paths, int32_t *n_points);
+/* The same data without the copy: *paths [P][N][cap][3] (entries past a path's
+ * end are zero) and *n_points [P][N] point into the handle's pinned host mirror,
+ * refreshed by ONE device-to-host copy per rollout generation however often the
+ * getters are called (the reference's node calls getPredictedPaths() 3 x N
+ * times per tick, B/src/panda_bimanual_control.cpp:341-344). Valid until the
+ * next call that changes the predicted paths (start / tick / reset / set_* /
+ * move_agents / load_state / attach). Either pointer may be NULL. */
+int pmaf_view_paths(pmaf_planner *h, const double **paths, const int32_t **n_points);
 /* costs of the last pmaf_evaluate / pmaf_tick, [P][N] */
 int pmaf_get_costs(pmaf_planner *h, double *costs);
 /* getPredictedPathLengths, B/src/cf_manager.cpp:192-198, [P][N] */

@@ -7,6 +7,8 @@
 // ("flops_per_agent_step_measured"), and the fraction of agent-steps with at least one in-shell obstacle.
 // System headers are included BEFORE the macro below so that only the oracle's own code sees the counting type.
 #include <math.h>
+
+#include <cmath>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -37,6 +39,7 @@ PMAF_CMP(<) PMAF_CMP(>) PMAF_CMP(<=) PMAF_CMP(>=) PMAF_CMP(==) PMAF_CMP(!=)
 static inline cdouble sqrt(cdouble a) { g_flops++; return cdouble(sqrt(a.v)); }
 static inline cdouble exp(cdouble a) { g_flops++; return cdouble(exp(a.v)); }
 static inline cdouble fabs(cdouble a) { return cdouble(fabs(a.v)); }
+static inline bool isnan(cdouble a) { return std::isnan(a.v); }
 
 #define PMAF_FLOPCOUNT 1
 #define double cdouble

@@ -81,6 +81,54 @@ def lib():
     return _LIB
 
 
+class OracleConsumer:
+    """the oracle's restatement of the set-point consumer (orc_consumer_*)"""
+
+    def __init__(self):
+        L = lib()
+        L.orc_consumer_create.restype = C.c_void_p
+        L.orc_consumer_destroy.argtypes = [C.c_void_p]
+        L.orc_consumer_reset.argtypes = [C.c_void_p, _dp]
+        L.orc_consumer_ready.argtypes = [C.c_void_p]
+        L.orc_consumer_fill.argtypes = [C.c_void_p, _dp]
+        L.orc_consumer_update.argtypes = [C.c_void_p, C.c_double, _dp]
+        L.orc_consumer_deliver.restype = C.c_long
+        L.orc_consumer_deliver.argtypes = [C.c_void_p, _dp, C.c_double, C.c_long]
+        L.orc_consumer_state.argtypes = [C.c_void_p, _dp, C.POINTER(C.c_long)]
+        self._L = L
+        self._h = L.orc_consumer_create()
+
+    def reset(self, pos):
+        self._L.orc_consumer_reset(self._h, _d(pos)[1])
+
+    def ready(self):
+        return bool(self._L.orc_consumer_ready(self._h))
+
+    def fill(self, goal):
+        return bool(self._L.orc_consumer_fill(self._h, _d(goal)[1]))
+
+    def update(self, v_max):
+        out = np.zeros(3)
+        self._L.orc_consumer_update(self._h, float(v_max), out.ctypes.data_as(_dp))
+        return out
+
+    def deliver(self, set_point, velocity, max_cycles=1000000):
+        return self._L.orc_consumer_deliver(self._h, _d(set_point)[1], float(velocity), int(max_cycles))
+
+    def state(self):
+        st = np.zeros(15)
+        cn = (C.c_long * 6)()
+        self._L.orc_consumer_state(self._h, st.ctypes.data_as(_dp), cn)
+        return st, list(cn)
+
+    def close(self):
+        if self._h:
+            self._L.orc_consumer_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+
 def set_exp_mode(mode):
     """0 = libm exp (reference-faithful), 1 = portable exp shared with the HIP kernels"""
     lib().orc_set_exp_mode(int(mode))

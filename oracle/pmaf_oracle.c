@@ -834,3 +834,137 @@ double orc_dist_from_goal(const orc_planner *p) { return vnorm(vsub(p->goal, lat
 int orc_best_type(const orc_planner *p) { return p->has_best ? p->best_type : -1; }
 int orc_best_id(const orc_planner *p) { return p->has_best ? p->best_id : 0; }
 int64_t orc_agent_steps(const orc_planner *p) { return p->agent_steps; }
+
+
+/* ------------------------------------------------------------------ */
+/* Set-point consumer: the 3-vector half of the controller that receives the planner's
+ * set-points -- TrajectoryBuffer (B/src/trajectory_buffer.cpp:13-64, size 1: B/src/costp_controller.cpp:25) and
+ * CoSTPController::reset (:88-109), fillBuffer (:289-297), followTrajectory's trajectory logic (:299-340),
+ * absolutePositionControl's speed ramp (:193-201), getInstantaneousGoal (:144-155), getCurrentNominalGoal
+ * (:138-142). The joint-space control behind it (dqrobotics) is out of scope. */
+struct orc_consumer {
+  /* TrajectoryBuffer(1) */
+  v3 buf[1];
+  int size, head, tail, full;
+  int ready;
+  v3 lg, cg, current_ng, last_ng, next_ig, current_ig;
+  double next_ng, v_act, v_goal, reserve, min_motion;
+  long accepted, refused, n_nan, too_close, inconsistent, updates;
+};
+
+orc_consumer *orc_consumer_create(void) {
+  orc_consumer *c = (orc_consumer *)calloc(1, sizeof(*c));
+  c->size = 1;
+  c->reserve = 0.1;        /* costp_controller.h:79 */
+  c->min_motion = 2e-6;    /* costp_controller.cpp:301 */
+  return c;
+}
+void orc_consumer_destroy(orc_consumer *c) { free(c); }
+
+/* CoSTPController::reset, :88-109 */
+void orc_consumer_reset(orc_consumer *c, const double *ee_pos) {
+  c->ready = 1;
+  c->head = c->tail; c->full = 0;                       /* tb_->clear() */
+  c->buf[(c->tail + 0) % c->size] = V(ee_pos[0], ee_pos[1], ee_pos[2]);
+  c->lg = c->buf[(c->tail + 0) % c->size];
+  c->next_ig = c->lg; c->cg = c->lg; c->current_ng = c->lg; c->last_ng = c->lg;
+  c->next_ng = 0;
+  c->current_ig = c->lg;
+  c->v_act = 0;
+  c->v_goal = 0;
+}
+int orc_consumer_ready(const orc_consumer *c) { return c->ready; }
+
+/* CoSTPController::fillBuffer, :289-297; TrajectoryBuffer::put, trajectory_buffer.cpp:45-53 */
+int orc_consumer_fill(orc_consumer *c, const double *goal) {
+  int ok = 1;
+  if (c->full) { ok = 0; c->refused++; }
+  else {
+    c->buf[c->head] = V(goal[0], goal[1], goal[2]);
+    c->head = (c->head + 1) % c->size;
+    c->full = c->head == c->tail;
+  }
+  if (c->full) c->ready = 0;
+  return ok;
+}
+
+/* one 1 kHz cycle: followTrajectory :299-340, absolutePositionControl :193-201, getInstantaneousGoal :144-155;
+ * out = the instantaneous goal */
+void orc_consumer_update(orc_consumer *c, double v_max, double *out) {
+  c->updates++;
+  if (c->next_ng >= 1 || (c->v_act == 0 && c->next_ng == 0)) {
+    int got_point = 0;
+    c->lg = c->cg;
+    if (!(!c->full && c->head == c->tail)) {            /* !tb_->empty() */
+      c->cg = c->buf[c->tail];                          /* tb_->get() */
+      c->full = 0;
+      c->tail = (c->tail + 1) % c->size;
+      got_point = 1;
+    } else {
+      c->next_ng = 0;
+      c->v_act = 0;
+    }
+    c->ready = 1;
+    if (got_point) {
+      c->accepted++;
+      if (isnan(c->cg.x) || isnan(c->cg.y) || isnan(c->cg.z)) c->n_nan++;
+      if (vnorm(vsub(c->cg, c->lg)) < 1e-6) {
+        c->too_close++;
+        c->cg.z += c->min_motion;
+        c->min_motion = -c->min_motion;
+      }
+      const double v = v_max * (1 - c->reserve);
+      c->v_goal = dmin(vnorm(vsub(c->cg, c->lg)) * 100, v);
+      double acos_gamma = vdot(vnormalized(vsub(c->cg, c->lg)), vsub(c->current_ng, c->lg));
+      double e = c->v_goal * 0.001;
+      double l = vnorm(vsub(c->lg, c->current_ng));
+      double radicand = (acos_gamma * acos_gamma + e * e) - l * l;
+      double b;
+      if (radicand >= 0) b = acos_gamma + sqrt(radicand);
+      else { b = 0; c->inconsistent++; }
+      c->next_ng = b / vnorm(vsub(c->cg, c->lg));
+    }
+  }
+  if (c->v_goal > c->v_act) {
+    c->v_act += 0.001 * 0.05;
+    if (c->v_act > c->v_goal) c->v_act = c->v_goal;
+  } else {
+    c->v_act = c->v_goal;
+  }
+  /* getInstantaneousGoal */
+  v3 current_ig = c->next_ig;
+  if (vnorm(vsub(c->current_ng, current_ig)) < c->v_act * 0.001) {
+    c->last_ng = c->current_ng;                          /* getCurrentNominalGoal */
+    c->current_ng = vadd(c->lg, vscale(c->next_ng, vsub(c->cg, c->lg)));
+    c->next_ng += c->v_goal * 0.001 / vnorm(vsub(c->cg, c->lg));
+  }
+  c->next_ig = vadd(current_ig, vscale(c->v_act * 0.001, vnormalized(vsub(c->current_ng, current_ig))));
+  c->current_ig = vadd(vscale(0.9, c->current_ig), vscale(0.1, current_ig));
+  if (out) { out[0] = c->current_ig.x; out[1] = c->current_ig.y; out[2] = c->current_ig.z; }
+}
+
+/* VrepController::targetPoseCallback, B/src/vrep_controller.cpp:100-115 (v_max = velocity / 0.9, :291-292) */
+long orc_consumer_deliver(orc_consumer *c, const double *set_point, double velocity, long max_cycles) {
+  orc_consumer_fill(c, set_point);
+  long n = 0;
+  while (n < max_cycles) {
+    orc_consumer_update(c, velocity / 0.9, NULL);
+    n++;
+    if (c->ready) break;
+  }
+  return n;
+}
+
+/* state = {v_goal, v_act, next_ng, cg[3], lg[3], current_ng[3], current_ig[3]} (15), counters = {accepted, refused,
+ * nan, too_close, inconsistent, updates} (6) */
+void orc_consumer_state(const orc_consumer *c, double *state, long *counters) {
+  if (state) {
+    state[0] = c->v_goal; state[1] = c->v_act; state[2] = c->next_ng;
+    memcpy(state + 3, &c->cg, sizeof(v3)); memcpy(state + 6, &c->lg, sizeof(v3));
+    memcpy(state + 9, &c->current_ng, sizeof(v3)); memcpy(state + 12, &c->current_ig, sizeof(v3));
+  }
+  if (counters) {
+    counters[0] = c->accepted; counters[1] = c->refused; counters[2] = c->n_nan;
+    counters[3] = c->too_close; counters[4] = c->inconsistent; counters[5] = c->updates;
+  }
+}

@@ -141,6 +141,19 @@ int orc_best_id(const orc_planner *p);   /* 1-based agent ID, 0 if none */
 /* total agent-steps executed by orc_rollout calls so far (for timing) */
 int64_t orc_agent_steps(const orc_planner *p);
 
+/* Set-point consumer: TrajectoryBuffer(1) (B/src/trajectory_buffer.cpp:13-64) + the
+ * trajectory half of CoSTPController (B/src/costp_controller.cpp:88-109, 138-155, 193-201, 289-340) + the
+ * hand-over loop of VrepController::targetPoseCallback (B/src/vrep_controller.cpp:100-115). */
+typedef struct orc_consumer orc_consumer;
+orc_consumer *orc_consumer_create(void);
+void orc_consumer_destroy(orc_consumer *c);
+void orc_consumer_reset(orc_consumer *c, const double *ee_pos);
+int orc_consumer_ready(const orc_consumer *c);
+int orc_consumer_fill(orc_consumer *c, const double *goal);           /* 0: the buffer refused the point */
+void orc_consumer_update(orc_consumer *c, double v_max, double *out /*[3] instantaneous goal, may be NULL*/);
+long orc_consumer_deliver(orc_consumer *c, const double *set_point, double velocity, long max_cycles);
+void orc_consumer_state(const orc_consumer *c, double *state /*[15]*/, long *counters /*[6]*/);
+
 #ifdef __cplusplus
 }
 #endif

@@ -89,6 +89,16 @@ struct pmaf_planner {
     std::vector<double> ag_us;
   } x;
   double *d_send1 = nullptr;           // send buffer of the one-shot pmaf_allgather_winners
+  // host mirror of the predicted paths (pmaf_get_paths): the reference's node calls getPredictedPaths() /
+  // getNumPredictionSteps(i) 3 x N times per tick (B/src/panda_bimanual_control.cpp:341-344) -- one D2H per
+  // rollout generation serves them all
+  uint64_t paths_gen = 1, mirror_gen = 0;   // bumped by everything that changes paths / n_points
+  double *h_paths = nullptr;                // pinned [P][N][cap][3], tails zeroed
+  int32_t *h_np = nullptr;                  // pinned [P][N]
+  double *d_plan_obs = nullptr;        // [P][7][n_obs] the stepping API's obstacle list (pmaf_move_agents ...)
+  double *d_plan_out = nullptr;        // [P][N] pmaf_eval_obstacle_distance
+  int32_t *d_plan_calls = nullptr;     // [P]
+  bool stepped = false;                // agents were moved by the stepping API: a rollout needs a reset first
   double *d_link = nullptr, *h_link = nullptr;  // pmaf_link_force scratch (device / pinned host), grown on demand
   size_t link_scratch_doubles = 0;
   double *d_reset_in = nullptr; // [P][6]
@@ -112,6 +122,15 @@ struct pmaf_planner {
     allocs.push_back(p);
     alloc_bytes.push_back(sizeof(T) * (n ? n : 1));
     HIP_CHECK(hipMemsetAsync(p, 0, sizeof(T) * (n ? n : 1), stream));
+    return static_cast<T *>(p);
+  }
+  // scratch that is not planner state (not in the checkpoint blob); freed with the handle
+  std::vector<void *> scratch;
+  template <typename T>
+  T *dalloc_untracked(size_t n) {
+    void *p = nullptr;
+    HIP_CHECK(hipMalloc(&p, sizeof(T) * (n ? n : 1)));
+    scratch.push_back(p);
     return static_cast<T *>(p);
   }
   template <typename T>
@@ -239,6 +258,7 @@ static void launch_rollout(pmaf_planner *h) {
   HIP_CHECK(hipGetLastError());
   if (h->profiling) HIP_CHECK(hipEventRecord(e1, h->stream));
   h->launches++;
+  h->paths_gen++;
   h->scores_valid = true;
   h->cp_valid = true;
   h->rollout_pending = false;
@@ -295,6 +315,7 @@ static const double *stage_live_obstacles_zero_copy(pmaf_planner *h, const doubl
 
 static void launch_manager(pmaf_planner *h, const ManagerArgs &A0) {
   ManagerArgs A = A0;
+  if (A.do_reset) h->paths_gen++;
   A.tuned_real_step = (h->math == MATH_XACT && !h->force_generic) ? 1 : 0;
   pmaf_k_launch_manager(h->D, h->cp, A, h->lds_manager, h->stream);
   HIP_CHECK(hipGetLastError());
@@ -396,6 +417,7 @@ static void begin_exchange(pmaf_planner *h, const double *scored_paths) {
 static void detach_comm(pmaf_planner *h) {
   pmaf_planner::Exchange &x = h->x;
   if (!x.c) return;
+  h->paths_gen++;
   if (x.inflight) {
     // an RCCL all-gather already enqueued completes (every rank enqueued it); a host collective not yet run is dropped
     (void)hipStreamSynchronize(x.xs);
@@ -652,8 +674,11 @@ int pmaf_destroy(pmaf_planner *h) {
   detach_comm(h);
   if (h->d_send1) (void)hipFree(h->d_send1);
   for (void *p : h->allocs) (void)hipFree(p);
+  for (void *p : h->scratch) (void)hipFree(p);
   if (h->h_out) (void)hipHostFree(h->h_out);
   if (h->h_zc) (void)hipHostFree(h->h_zc);
+  if (h->h_paths) (void)hipHostFree(h->h_paths);
+  if (h->h_np) (void)hipHostFree(h->h_np);
   if (h->d_link) (void)hipFree(h->d_link);
   if (h->h_link) (void)hipHostFree(h->h_link);
   for (int i = 0; i < pmaf_planner::kStage; i++) {
@@ -681,6 +706,7 @@ int pmaf_set_initial_position(pmaf_planner *h, const double *pos) {
     h->upload(D.real_pos, pos, P * 3);
     h->upload(D.start_pos, pos, P * 3);
     // CfAgent::setPosition = clear + push_back for every predicted agent
+    h->paths_gen++;
     pmaf_k_launch_restart_paths(D, D.start_pos, h->stream);
     HIP_CHECK(hipGetLastError());
     h->real_pos_h.assign(pos, pos + P * 3);
@@ -689,6 +715,7 @@ int pmaf_set_initial_position(pmaf_planner *h, const double *pos) {
     sync(h);
     h->scores_valid = false;
     h->rollout_pending = true;
+    h->stepped = false;
   });
 }
 
@@ -709,6 +736,9 @@ int pmaf_start(pmaf_planner *h) {
   return guarded([&] {
     REQUIRE(h, "pmaf_start: NULL handle");
     h->use_device();
+    if (h->stepped)
+      fail(PMAF_ERR_STATE, "pmaf_start: the agents were moved by pmaf_move_agent(s); call pmaf_reset_agents or "
+                           "pmaf_set_agent_* / pmaf_set_initial_position first (rollouts start from the population's reset state)");
     // a finished rollout that was not reset has nothing left to predict
     // (guard B/src/cf_agent.cpp:310-311 is already false)
     if (!h->rollout_pending) return;
@@ -803,6 +833,7 @@ int pmaf_reset_agents(pmaf_planner *h, const double *pos, const double *vel, con
     refresh_real_cache(h);
     h->scores_valid = false;
     h->rollout_pending = true;
+    h->stepped = false;
   });
 }
 
@@ -828,6 +859,7 @@ int pmaf_tick(pmaf_planner *h, const double *obstacles, double dt, const double 
     launch_manager(h, A);
     if (h->x.c) begin_exchange(h, h->D.paths);  // the paths this selection scored; the rollout below writes the other buffer
     h->rollout_pending = true;
+    h->stepped = false;
     launch_rollout(h);
     // outputs of k_manager land in mapped pinned memory; wait for them only
     // (no event between the two launches: the host polls the sequence number)
@@ -840,6 +872,124 @@ int pmaf_tick(pmaf_planner *h, const double *obstacles, double dt, const double 
       if (next_pos) { next_pos[p * 3] = o[1]; next_pos[p * 3 + 1] = o[2]; next_pos[p * 3 + 2] = o[3]; }
       if (next_vel) { next_vel[p * 3] = o[4]; next_vel[p * 3 + 1] = o[5]; next_vel[p * 3 + 2] = o[6]; }
     }
+  });
+}
+
+// ---- synchronous stepping API ----
+static const double *upload_plan_obstacles(pmaf_planner *h, const double *obstacles) {
+  const size_t n = (size_t)h->D.P * 7 * h->D.n_obs;
+  check_range(obstacles, (size_t)h->D.P * h->D.n_obs * 7, "obstacles");
+  if (!h->d_plan_obs) {
+    h->d_plan_obs = h->dalloc_untracked<double>(n);
+    h->d_plan_out = h->dalloc_untracked<double>((size_t)h->D.P * h->D.N);
+    h->d_plan_calls = h->dalloc_untracked<int32_t>((size_t)h->D.P);
+  }
+  std::vector<double> soa(n);
+  aos_to_soa(obstacles, soa.data(), h->D.P, h->D.n_obs);
+  h->upload(h->d_plan_obs, soa.data(), n);
+  return h->d_plan_obs;
+}
+
+static void plan_steps(pmaf_planner *h, const double *obstacles, double dt, int steps, const int32_t *agent_id,
+                       int max_calls, int32_t *calls) {
+  check_range(&dt, 1, "dt");
+  h->use_device();
+  sync(h);
+  const DevView &D = h->D;
+  std::vector<int32_t> np((size_t)D.P * D.N);
+  h->download(np.data(), D.n_points, np.size());
+  if (!agent_id) {  // moveAgents: every path must have room for `steps` more points
+    int mx = 0;
+    for (int32_t v : np) mx = v > mx ? v : mx;
+    if ((long)mx + steps > (long)D.cap)
+      fail(PMAF_ERR_STATE, "pmaf_move_agents: a path would outgrow max_prediction_steps (the path buffers are fixed-size)");
+  }
+  PlanArgs A{};
+  A.obs = upload_plan_obstacles(h, obstacles);
+  A.dt = dt;
+  A.steps = steps;
+  A.max_calls = agent_id ? max_calls : 1;
+  A.until_goal = agent_id ? 1 : 0;
+  if (agent_id) {
+    for (int p = 0; p < D.P; p++) REQUIRE(agent_id[p] >= 0 && agent_id[p] < D.N, "pmaf_move_agent: agent_id out of range");
+    h->upload(h->d_agent_id, agent_id, D.P);
+    A.only = h->d_agent_id;
+    A.calls_out = h->d_plan_calls;
+    HIP_CHECK(hipMemsetAsync(h->d_plan_calls, 0, sizeof(int32_t) * D.P, h->stream));
+  }
+  h->paths_gen++;
+  if (!pmaf_k_launch_plan_steps(D, A, h->lpa, h->n_blocks, h->lds_rollout, h->stream)) fail(PMAF_ERR_INVALID, "bad lanes_per_agent");
+  HIP_CHECK(hipGetLastError());
+  sync(h);
+  if (agent_id && calls) h->download(calls, h->d_plan_calls, D.P);
+  h->scores_valid = false;     // path costs are re-scored on demand (k_score)
+  h->rollout_pending = false;
+  h->stepped = true;
+}
+
+int pmaf_move_agents(pmaf_planner *h, const double *obstacles, double dt, int32_t steps) {
+  return guarded([&] {
+    REQUIRE(h && obstacles, "pmaf_move_agents: NULL argument");
+    REQUIRE(steps >= 0, "pmaf_move_agents: steps must be >= 0");
+    plan_steps(h, obstacles, dt, steps, nullptr, 1, nullptr);
+  });
+}
+
+int pmaf_move_agent(pmaf_planner *h, const double *obstacles, double dt, int32_t steps, const int32_t *agent_id,
+                    int32_t max_calls, int32_t *calls) {
+  return guarded([&] {
+    REQUIRE(h && obstacles && agent_id, "pmaf_move_agent: NULL argument");
+    REQUIRE(steps >= 1 && max_calls >= 0, "pmaf_move_agent: need steps >= 1 and max_calls >= 0");
+    plan_steps(h, obstacles, dt, steps, agent_id, max_calls, calls);
+  });
+}
+
+static void set_agents(pmaf_planner *h, const double *pos, const double *vel) {
+  const int P = h->D.P;
+  check_range(pos, (size_t)P * 3, "pos");
+  if (vel) check_range(vel, (size_t)P * 3, "vel");
+  h->use_device();
+  sync(h);
+  std::vector<double> in((size_t)P * 6, 0.0);
+  for (int p = 0; p < P; p++)
+    for (int c = 0; c < 3; c++) { in[p * 6 + c] = pos[p * 3 + c]; if (vel) in[p * 6 + 3 + c] = vel[p * 3 + c]; }
+  // d_reset_in holds [P][6]; the kernel takes two [P][3] arrays: repack
+  std::vector<double> pk((size_t)P * 6);
+  for (int p = 0; p < P; p++)
+    for (int c = 0; c < 3; c++) { pk[p * 3 + c] = in[p * 6 + c]; pk[(size_t)P * 3 + p * 3 + c] = in[p * 6 + 3 + c]; }
+  h->upload(h->d_reset_in, pk.data(), pk.size());
+  h->paths_gen++;
+  pmaf_k_launch_set_agents(h->D, h->d_reset_in, vel ? h->d_reset_in + (size_t)P * 3 : nullptr, h->stream);
+  HIP_CHECK(hipGetLastError());
+  sync(h);
+  h->scores_valid = false;
+  h->rollout_pending = true;
+  h->stepped = false;
+}
+
+int pmaf_set_agent_positions(pmaf_planner *h, const double *pos) {
+  return guarded([&] {
+    REQUIRE(h && pos, "pmaf_set_agent_positions: NULL argument");
+    set_agents(h, pos, nullptr);
+  });
+}
+
+int pmaf_set_agent_pos_and_vels(pmaf_planner *h, const double *pos, const double *vel) {
+  return guarded([&] {
+    REQUIRE(h && pos && vel, "pmaf_set_agent_pos_and_vels: NULL argument");
+    set_agents(h, pos, vel);
+  });
+}
+
+int pmaf_eval_obstacle_distance(pmaf_planner *h, const double *obstacles, double *out) {
+  return guarded([&] {
+    REQUIRE(h && obstacles && out, "pmaf_eval_obstacle_distance: NULL argument");
+    h->use_device();
+    sync(h);
+    const double *d_obs = upload_plan_obstacles(h, obstacles);
+    pmaf_k_launch_eval_obstacle_distance(h->D, d_obs, h->d_plan_out, h->stream);
+    HIP_CHECK(hipGetLastError());
+    h->download(out, h->d_plan_out, (size_t)h->D.P * h->D.N);
   });
 }
 
@@ -887,18 +1037,40 @@ int pmaf_link_force(pmaf_planner *h, int32_t pop, int32_t n, const double *link_
   const size_t PN = (size_t)D.P * D.N;           \
   (void)PN;
 
+// bring the host mirror of paths / n_points up to date (one D2H per rollout generation)
+static void refresh_paths_mirror(pmaf_planner *h) {
+  if (h->mirror_gen == h->paths_gen) return;
+  const DevView &D = h->D;
+  const size_t PN = (size_t)D.P * D.N;
+  if (!h->h_paths) {
+    HIP_CHECK(hipHostMalloc((void **)&h->h_paths, sizeof(double) * PN * (size_t)D.cap * 3, hipHostMallocDefault));
+    HIP_CHECK(hipHostMalloc((void **)&h->h_np, sizeof(int32_t) * PN, hipHostMallocDefault));
+  }
+  HIP_CHECK(hipMemcpyAsync(h->h_np, D.n_points, sizeof(int32_t) * PN, hipMemcpyDeviceToHost, h->stream));
+  HIP_CHECK(hipMemcpyAsync(h->h_paths, D.paths, sizeof(double) * PN * (size_t)D.cap * 3, hipMemcpyDeviceToHost, h->stream));
+  HIP_CHECK(hipStreamSynchronize(h->stream));
+  // entries past an agent's path end are stale device memory: report zeros
+  for (size_t pa = 0; pa < PN; pa++)
+    std::memset(h->h_paths + (pa * D.cap + h->h_np[pa]) * 3, 0, sizeof(double) * 3 * (size_t)(D.cap - h->h_np[pa]));
+  h->mirror_gen = h->paths_gen;
+}
+
 int pmaf_get_paths(pmaf_planner *h, double *paths, int32_t *n_points) {
   return guarded([&] {
     GETTER_PROLOGUE("pmaf_get_paths")
-    std::vector<int32_t> np(PN);
-    h->download(np.data(), D.n_points, PN);
-    if (paths) {
-      h->download(paths, D.paths, PN * (size_t)D.cap * 3);
-      // entries past an agent's path end are stale device memory: report zeros
-      for (size_t pa = 0; pa < PN; pa++)
-        std::memset(paths + (pa * D.cap + np[pa]) * 3, 0, sizeof(double) * 3 * (size_t)(D.cap - np[pa]));
-    }
-    if (n_points) std::memcpy(n_points, np.data(), sizeof(int32_t) * PN);
+    refresh_paths_mirror(h);
+    if (paths) std::memcpy(paths, h->h_paths, sizeof(double) * PN * (size_t)D.cap * 3);
+    if (n_points) std::memcpy(n_points, h->h_np, sizeof(int32_t) * PN);
+  });
+}
+// zero-copy view of the same mirror: *paths [P][N][cap][3] and *n_points [P][N] stay valid until the next call that
+// changes the predicted paths (start / tick / reset / set_* / move_agents / load_state)
+int pmaf_view_paths(pmaf_planner *h, const double **paths, const int32_t **n_points) {
+  return guarded([&] {
+    GETTER_PROLOGUE("pmaf_view_paths")
+    refresh_paths_mirror(h);
+    if (paths) *paths = h->h_paths;
+    if (n_points) *n_points = h->h_np;
   });
 }
 int pmaf_get_costs(pmaf_planner *h, double *costs) {
@@ -1111,6 +1283,7 @@ int pmaf_attach_comm(pmaf_planner *h, pmaf_comm *c) {
       std::memset(x.h_recv, 0, sizeof(double) * n_local * (size_t)c->world);
       x.paths_a = h->D.paths;
       x.c = c;
+      h->paths_gen++;
     } catch (...) {
       x.c = c;  // so that detach_comm releases what was created
       x.paths_a = h->D.paths;
@@ -1250,6 +1423,7 @@ int pmaf_load_state(pmaf_planner *h, const void *blob, size_t bytes) {
       rp.assign(reinterpret_cast<const double *>(r), reinterpret_cast<const double *>(r) + n);
       r += sizeof(double) * n;
     }
+    h->paths_gen++;
     h->cp_valid = hd.cp_valid != 0;
     h->scores_valid = hd.scores_valid != 0;
     h->rollout_pending = hd.rollout_pending != 0;

@@ -530,6 +530,139 @@ __global__ void k_winner_path(DevView D, const double *paths, double *dst) {
 }
 
 // ---------------------------------------------------------------------------
+// synchronous stepping API (no callers in the reference, kept for the class surface)
+// ---------------------------------------------------------------------------
+// CfAgent::cfPlanner, B/src/cf_agent.cpp:278-300, for every agent (CfManager::moveAgents / moveAgentsPar,
+// B/src/cf_manager.cpp:274-291) or one agent until it is within 0.05 of the goal (moveAgent, :265-272): `steps`
+// steps from the agent's CURRENT state (last path point, its own velocity, known flags, rotation vectors,
+// min_obs_dist_) through the caller's obstacle list -- no loop guard, no obstacle advance, the call's delta_t.
+// Same lanes-per-agent mapping and device functions as the generic rollout kernel.
+template <int LPA>
+__global__ __launch_bounds__(64) void k_plan_steps(DevView D, PlanArgs A) {
+  extern __shared__ double smem[];
+  const int lane = threadIdx.x;
+  const int pop = blockIdx.y;
+  constexpr int APW = 64 / LPA;
+  const int sub = lane % LPA;
+  const int grp = lane / LPA;
+  const int a = blockIdx.x * APW + grp;
+  const bool exists = a < D.N;
+  const int aa = exists ? a : 0;
+  const bool chosen = exists && (A.only == nullptr || A.only[pop] == a);
+  const int n_obs = D.n_obs;
+  const PopConst C = D.C;
+  ObsTab T = carve_obstab(smem, n_obs);
+  {
+    const double *src = A.obs + (size_t)pop * 7 * n_obs;
+    for (int i = lane; i < 7 * n_obs; i += 64) smem[i] = src[i];
+  }
+  __syncthreads();
+  const size_t pa = (size_t)pop * D.N + aa;
+  const V3 goal = mk(D.goal[pop * 3], D.goal[pop * 3 + 1], D.goal[pop * 3 + 2]);
+  const V3 init_pos = mk(D.agent_init_pos[pop * 3], D.agent_init_pos[pop * 3 + 1], D.agent_init_pos[pop * 3 + 2]);
+  const double k_attr = D.k_attr[pa], k_circ = D.k_circ[pa], k_repel = D.k_repel[pa], k_damp = D.k_damp[pa];
+  const int type = D.types[aa];
+  double *rot_g = D.rot + pa * 3 * n_obs;
+  const double *rnd_g = D.rnd + pa * 3 * n_obs;
+  double *path = D.paths + pa * (size_t)D.cap * 3;
+  int32_t *ko = D.known_out + pa * n_obs;
+  int n = D.n_points[pa];
+  V3 p = mk(path[(n - 1) * 3], path[(n - 1) * 3 + 1], path[(n - 1) * 3 + 2]);
+  V3 v = mk(D.agent_vel[pa * 3], D.agent_vel[pa * 3 + 1], D.agent_vel[pa * 3 + 2]);
+  double min_obs = D.min_obs[pa];
+  const int M = n_obs - 1;
+  const int ntiles = (M + LPA - 1) / LPA;
+  unsigned long long known_bits = 0ull;
+  for (int t = 0; t < ntiles; t++) {
+    int i = t * LPA + sub;
+    if (i < M && ko[i]) known_bits |= (1ull << t);
+  }
+  int calls = 0;
+  bool active = chosen;
+  for (int call = 0; call < A.max_calls; call++) {
+    // moveAgent: `while (run_prediction_ && getDistFromGoal() > 0.05)`, cf_manager.cpp:267; the path buffer bounds it
+    if (A.until_goal) active = active && (norm(goal - p) > 0.05);
+    active = active && (n + A.steps <= D.cap);
+    if (!__any(active)) break;
+    if (active) calls++;
+    for (int s = 0; s < A.steps; s++) {
+      const V3 g = goal - p;
+      const double dg = norm(g);
+      const bool gate = !(dg < C.approach || (norm(v) < 0.5 * C.vel_max && norm(p - init_pos) < 0.2));  // :285-289
+      V3 F = mk(0.0, 0.0, 0.0);
+      double scale = 1.0;
+      circ_and_scale<LPA, false>(active && gate, sub, grp, type, p, v, goal, g, C, k_circ, T, n_obs, rot_g, rnd_g,
+                                 known_bits, min_obs, F, scale);
+      V3 new_pos;
+      V3 nv = v;
+      finish_step(p, nv, g, F, scale, C, k_attr, k_repel, k_damp, A.dt, T.pos(n_obs - 1), T.r[n_obs - 1], new_pos);
+      if (active) {
+        p = new_pos;
+        v = nv;
+        if (sub == 0) { path[n * 3] = p.x; path[n * 3 + 1] = p.y; path[n * 3 + 2] = p.z; }
+        n++;
+      }
+    }
+  }
+  if (chosen) {
+    for (int t = 0; t < ntiles; t++) {
+      int i = t * LPA + sub;
+      if (i < M) ko[i] = (int32_t)((known_bits >> t) & 1ull);
+    }
+    if (sub == 0) {
+      D.n_points[pa] = n;
+      D.agent_vel[pa * 3] = v.x; D.agent_vel[pa * 3 + 1] = v.y; D.agent_vel[pa * 3 + 2] = v.z;
+      D.min_obs[pa] = min_obs;
+      D.goal_dist[pa] = norm(goal - p);
+      if (A.calls_out && A.only) A.calls_out[pop] = calls;
+    }
+  }
+}
+
+// CfManager::setEEAgentPositions (B/src/cf_manager.cpp:220-224) / setEEAgentPosAndVels (:238-244): every agent's
+// path restarts at pos (CfAgent::setPosition = clear + push_back); with vel, CfAgent::setVelocity's clamp (:54-61).
+// The population-wide rollout start state follows (the next startPrediction rolls out from there).
+__global__ void k_set_agents(DevView D, const double *pos, const double *vel) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= D.P * D.N) return;
+  const int pop = idx / D.N;
+  const V3 q = mk(pos[pop * 3], pos[pop * 3 + 1], pos[pop * 3 + 2]);
+  double *path = D.paths + (size_t)idx * D.cap * 3;
+  path[0] = q.x; path[1] = q.y; path[2] = q.z;
+  D.n_points[idx] = 1;
+  V3 w = mk(0.0, 0.0, 0.0);
+  if (vel) {
+    w = mk(vel[pop * 3], vel[pop * 3 + 1], vel[pop * 3 + 2]);
+    const double vn = norm(w);
+    if (vn > D.C.vel_max) w = (D.C.vel_max / vn) * w;
+    D.agent_vel[idx * 3] = w.x; D.agent_vel[idx * 3 + 1] = w.y; D.agent_vel[idx * 3 + 2] = w.z;
+  }
+  if (idx % D.N == 0) {
+    D.start_pos[pop * 3] = q.x; D.start_pos[pop * 3 + 1] = q.y; D.start_pos[pop * 3 + 2] = q.z;
+    if (vel) { D.start_vel[pop * 3] = w.x; D.start_vel[pop * 3 + 1] = w.y; D.start_vel[pop * 3 + 2] = w.z; }
+  }
+}
+
+// CfAgent::evalObstacleDistance, B/src/cf_agent.cpp:146-157, one thread per agent: min over ALL obstacles of the
+// unclamped surface distance from the agent's latest position, starting from the shell radius
+__global__ void k_eval_obstacle_distance(DevView D, const double *obs, double *out) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= D.P * D.N) return;
+  const int pop = idx / D.N;
+  const int n_obs = D.n_obs;
+  const double *o = obs + (size_t)pop * 7 * n_obs;
+  const double *path = D.paths + (size_t)idx * D.cap * 3;
+  const int n = D.n_points[idx];
+  const V3 p = mk(path[(n - 1) * 3], path[(n - 1) * 3 + 1], path[(n - 1) * 3 + 2]);
+  double min_dist = D.C.shell;
+  for (int k = 0; k < n_obs; k++) {
+    const double d = norm(p - mk(o[k], o[n_obs + k], o[2 * n_obs + k])) - (D.C.rad + o[6 * n_obs + k]);
+    if (min_dist > d) min_dist = d;
+  }
+  out[idx] = min_dist;
+}
+
+// ---------------------------------------------------------------------------
 // launch interface (pmaf_types.hpp)
 // ---------------------------------------------------------------------------
 bool pmaf_k_launch_w64_m0(const DevView &, const CostParams &, int, size_t, hipStream_t);
@@ -591,6 +724,25 @@ void pmaf_k_launch_winner_path(const DevView &D, const double *paths, double *ds
   hipLaunchKernelGGL(k_winner_path, dim3((unsigned)D.P), dim3(256), 0, s, D, paths, dst);
 }
 
+bool pmaf_k_launch_plan_steps(const DevView &D, const PlanArgs &A, int lpa, int n_blocks, size_t lds, hipStream_t s) {
+  const dim3 grid((unsigned)n_blocks, (unsigned)D.P), block(64);
+  switch (lpa) {
+#define PMAF_CASE(L) case L: hipLaunchKernelGGL((k_plan_steps<L>), grid, block, lds, s, D, A); break;
+    PMAF_CASE(1) PMAF_CASE(2) PMAF_CASE(4) PMAF_CASE(8) PMAF_CASE(16) PMAF_CASE(32) PMAF_CASE(64)
+#undef PMAF_CASE
+    default: return false;
+  }
+  return true;
+}
+
+void pmaf_k_launch_set_agents(const DevView &D, const double *pos, const double *vel, hipStream_t s) {
+  hipLaunchKernelGGL(k_set_agents, dim3((D.P * D.N + 255) / 256), dim3(256), 0, s, D, pos, vel);
+}
+
+void pmaf_k_launch_eval_obstacle_distance(const DevView &D, const double *obs, double *out, hipStream_t s) {
+  hipLaunchKernelGGL(k_eval_obstacle_distance, dim3((D.P * D.N + 255) / 256), dim3(256), 0, s, D, obs, out);
+}
+
 hipError_t pmaf_k_set_lds_limits(size_t lds_manager, size_t lds_rollout) {
   hipError_t e = hipSuccess;
   if (lds_manager > 64 * 1024)
@@ -598,7 +750,8 @@ hipError_t pmaf_k_set_lds_limits(size_t lds_manager, size_t lds_rollout) {
                             (int)lds_manager);
   if (e == hipSuccess && lds_rollout > 64 * 1024) {
     // only the generic kernel takes obstacle tables this large (M > 256)
-#define PMAF_LDS(L) if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rollout<L>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rollout);
+#define PMAF_LDS(L) if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rollout<L>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rollout); \
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_plan_steps<L>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rollout);
     PMAF_LDS(1) PMAF_LDS(2) PMAF_LDS(4) PMAF_LDS(8) PMAF_LDS(16) PMAF_LDS(32) PMAF_LDS(64)
 #undef PMAF_LDS
   }

@@ -95,6 +95,17 @@ struct ManagerArgs {
   int winner_stride;       // written after a selection: {cost, idx, n_points, type, next_pos[3], goal_dist}; NULL: none
 };
 
+// synchronous stepping (CfAgent::cfPlanner, B/src/cf_agent.cpp:278-300): k_plan_steps
+struct PlanArgs {
+  const double *obs;       // [P][7][n_obs] SoA: the CALLER's obstacle list (positions, velocities, radii), not advanced
+  double dt;               // the call's delta_t
+  int steps;               // steps per cfPlanner call
+  const int32_t *only;     // [P] agent index to step (CfManager::moveAgent), NULL: every agent (moveAgents)
+  int max_calls;           // moveAgent: repeat cfPlanner(steps) while distGoal > 0.05, at most this often; 1 otherwise
+  int until_goal;          // 1: moveAgent's loop condition applies
+  int32_t *calls_out;      // [P] cfPlanner calls made for the `only` agent (moveAgent), may be NULL
+};
+
 // ---------------------------------------------------------------------------
 // launch interface: implemented in pmaf_k_w64.hip / pmaf_k_grp.hip / pmaf_k_misc.hip
 // ---------------------------------------------------------------------------
@@ -114,5 +125,11 @@ void pmaf_k_launch_debug_math(int op, int n, const double *a, const double *b, d
 void pmaf_k_launch_winner(const DevView &D, double *dst, hipStream_t s);
 // path part of the winner records whose headers k_manager wrote into dst: the selected agents' paths out of `paths`
 void pmaf_k_launch_winner_path(const DevView &D, const double *paths, double *dst, hipStream_t s);
+// CfManager::moveAgents / moveAgent (synchronous stepping), any power-of-two lpa 1..64
+bool pmaf_k_launch_plan_steps(const DevView &D, const PlanArgs &A, int lpa, int n_blocks, size_t lds, hipStream_t s);
+// CfManager::setEEAgentPositions / setEEAgentPosAndVels: pos [P][3], vel [P][3] or NULL
+void pmaf_k_launch_set_agents(const DevView &D, const double *pos, const double *vel, hipStream_t s);
+// CfAgent::evalObstacleDistance for every agent: obs [P][7][n_obs] SoA, out [P][N]
+void pmaf_k_launch_eval_obstacle_distance(const DevView &D, const double *obs, double *out, hipStream_t s);
 // opt the kernels that take dynamic LDS into more than the 64 KB default
 hipError_t pmaf_k_set_lds_limits(size_t lds_manager, size_t lds_rollout);

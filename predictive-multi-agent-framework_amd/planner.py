@@ -54,7 +54,13 @@ SYMBOLS = {
     "pmaf_reset_agents": (C.c_int, [_V, _dp, _dp, _dp]),
     "pmaf_tick": (C.c_int, [_V, _dp, C.c_double, _dp, _dp, _ip, _dp, _dp]),
     "pmaf_link_force": (C.c_int, [_V, C.c_int32, C.c_int32, _dp, _dp, _dp, _dp]),
+    "pmaf_move_agents": (C.c_int, [_V, _dp, C.c_double, C.c_int32]),
+    "pmaf_move_agent": (C.c_int, [_V, _dp, C.c_double, C.c_int32, _ip, C.c_int32, _ip]),
+    "pmaf_set_agent_positions": (C.c_int, [_V, _dp]),
+    "pmaf_set_agent_pos_and_vels": (C.c_int, [_V, _dp, _dp]),
+    "pmaf_eval_obstacle_distance": (C.c_int, [_V, _dp, _dp]),
     "pmaf_get_paths": (C.c_int, [_V, _dp, _ip]),
+    "pmaf_view_paths": (C.c_int, [_V, C.POINTER(_dp), C.POINTER(_ip)]),
     "pmaf_get_costs": (C.c_int, [_V, _dp]),
     "pmaf_get_path_lengths": (C.c_int, [_V, _dp]),
     "pmaf_get_min_obs_dist": (C.c_int, [_V, _dp]),
@@ -267,6 +273,28 @@ class PmafPlanner:
         self._chk(self.L.pmaf_tick(self._h, _p(o), float(dt), _p(g), _p(w), _pi(best), _p(npos), _p(nvel)))
         self.last_next_pos, self.last_next_vel = npos, nvel
         return int(best[0]) if self.P == 1 else best
+
+    # -- synchronous stepping API (a18) --
+    def move_agents(self, obstacles, dt, steps):
+        self._chk(self.L.pmaf_move_agents(self._h, _p(self._obs(obstacles)), float(dt), int(steps)))
+
+    def move_agent(self, obstacles, dt, steps, agent_id, max_calls=1 << 30):
+        ids = np.ascontiguousarray(np.broadcast_to(np.asarray(agent_id, dtype=np.int32), (self.P,)))
+        calls = np.zeros(self.P, dtype=np.int32)
+        self._chk(self.L.pmaf_move_agent(self._h, _p(self._obs(obstacles)), float(dt), int(steps), _pi(ids),
+                                         int(min(max_calls, 2**31 - 1)), _pi(calls)))
+        return int(calls[0]) if self.P == 1 else calls
+
+    def set_agent_positions(self, pos):
+        self._chk(self.L.pmaf_set_agent_positions(self._h, _p(_d(pos, (self.P, 3)))))
+
+    def set_agent_pos_and_vels(self, pos, vel):
+        self._chk(self.L.pmaf_set_agent_pos_and_vels(self._h, _p(_d(pos, (self.P, 3))), _p(_d(vel, (self.P, 3)))))
+
+    def eval_obstacle_distance(self, obstacles):
+        out = np.zeros((self.P, self.N))
+        self._chk(self.L.pmaf_eval_obstacle_distance(self._h, _p(self._obs(obstacles)), _p(out)))
+        return self._sq(out)
 
     def link_force(self, link_pos, k_r_force, obstacles, pop=0):
         lp, k, o = _d(link_pos), _d(k_r_force), self._obs(obstacles)

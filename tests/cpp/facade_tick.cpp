@@ -3,9 +3,16 @@
 // (B/src/panda_bimanual_control.cpp:463-471, 501-510, 329-369) on the static1
 // task scene and prints, per tick, best index / type and the next set-point.
 // tests/test_facade.py compares the output with the oracle.
-//   usage: facade_tick <n_agents> <max_prediction_steps> <n_ticks> <random_vecs.bin>
+//   usage: facade_tick <n_agents> <max_prediction_steps> <n_ticks> <random_vecs.bin> [viz]
+// With `viz` the node's visualize_predicted_paths loop (B/src/panda_bimanual_control.cpp:340-347: 3 N + 1
+// getPredictedPaths() calls per tick) runs in every tick and the last lines report the median tick time with and
+// without it ("V <us with viz> <us without> <path points visited>"); it also exercises the move operations.
+#include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <utility>
 #include <vector>
 
 #include "bimanual_planning_ros/cf_manager.h"
@@ -32,8 +39,15 @@ int main(int argc, char **argv) {
   const double wsv[6] = {1.0, -1.0, 0.3, -0.3, 1.1, 0.2};
   for (int i = 0; i < 6; ++i) ws(i) = wsv[i];
 
-  CfManager cf_manager_;
-  cf_manager_.setInitialPosition(start);  // planCallback while planning is not active
+  const bool viz = argc > 5 && !strcmp(argv[5], "viz");
+  CfManager moved_from;
+  moved_from.setInitialPosition(start);   // planCallback while planning is not active
+  CfManager cf_manager_ = std::move(moved_from);   // cf_manager.h:53 (move construction keeps the state)
+  {
+    CfManager tmp;
+    tmp = std::move(cf_manager_);                  // :55 (move assignment), and back
+    cf_manager_ = std::move(tmp);
+  }
   cf_manager_.setRandomVectors(rv);
   auto do_init = [&] {
     cf_manager_.init(goal, dt, obstacles, std::vector<double>(N, 4.0), std::vector<double>(N, 0.025),
@@ -44,13 +58,34 @@ int main(int argc, char **argv) {
   Vector3d current_pos = start;
   do_init();                               // taskCallback PLAN, :501-509
   cf_manager_.setInitialPosition(current_pos);
+  std::vector<double> us_viz, us_plain;
+  size_t visited = 0;
+  double sink = 0.0;
+  auto visualize_predicted_path = [&](const std::vector<Vector3d> &poses, int agent, int best_agent) {  // :390-427
+    (void)agent; (void)best_agent;
+    for (const auto &pose : poses) { sink += pose.x() + pose.y() + pose.z(); ++visited; }
+  };
   for (int t = 0; t < ticks; ++t) {        // planCallback, :336-352
+    const bool with_viz = viz && (t % 2 == 0);
+    const auto t0 = std::chrono::steady_clock::now();
     cf_manager_.stopPrediction();
     int best = cf_manager_.evaluateAgents(obstacles, 100.0, 10.0, 0.001, 1.0, ws);
+    if (with_viz) {                          // :340-347, verbatim call pattern
+      for (int i = 0; i < (int)cf_manager_.getPredictedPaths().size(); i++) {
+        if (cf_manager_.getPredictedPaths().at(i).size() > 2) {
+          visualize_predicted_path(cf_manager_.getPredictedPaths().at(i), i, best);
+        }
+      }
+    }
     cf_manager_.moveRealEEAgent(obstacles, dt, 1, best);
     cf_manager_.resetEEAgents(cf_manager_.getNextPosition(), cf_manager_.getNextVelocity(), obstacles);
     cf_manager_.startPrediction();
     Vector3d np = cf_manager_.getNextPosition();
+    if (viz) {
+      cf_manager_.stopPrediction();          // whole tick incl. its rollout, so the two variants are comparable
+      const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+      (with_viz ? us_viz : us_plain).push_back(us);
+    }
     printf("%d %d %d %.17g %.17g %.17g %.17g\n", t, best, cf_manager_.getBestAgentType(), np.x(), np.y(), np.z(),
            cf_manager_.getDistFromGoal());
   }
@@ -61,5 +96,10 @@ int main(int argc, char **argv) {
     printf("P %zu %zu %.17g %.17g %.17g %.17g\n", a, paths[a].size(), paths[a].back().x(), paths[a].back().y(),
            paths[a].back().z(), lens[a]);
   printf("T %zu\n", cf_manager_.getPlannedTrajectory().size());
+  if (viz && !us_viz.empty() && !us_plain.empty()) {
+    std::sort(us_viz.begin(), us_viz.end());
+    std::sort(us_plain.begin(), us_plain.end());
+    printf("V %.1f %.1f %zu %g\n", us_viz[us_viz.size() / 2], us_plain[us_plain.size() / 2], visited, sink);
+  }
   return 0;
 }

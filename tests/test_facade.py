@@ -49,3 +49,36 @@ def test_facade_node_sequence_matches_oracle(pmaf, oracle, scenes, tmp_path, hip
         assert lines[ticks + N].split() == ["T", str(len(ora.real_path()))]
     finally:
         oracle.set_exp_mode(0)
+
+
+def test_facade_compiles_against_real_eigen_if_present():
+    """the PMAF_USE_EIGEN branch (a ROS box): compile-only, skipped where no
+    Eigen3 is installed (this image has none)"""
+    import glob
+    cands = [d for d in ("/usr/include/eigen3", "/usr/local/include/eigen3") if os.path.exists(os.path.join(d, "Eigen", "Dense"))]
+    cands += [os.path.dirname(os.path.dirname(p)) for p in glob.glob("/opt/*/include/eigen3/Eigen/Dense")]
+    if not cands:
+        pytest.skip("no Eigen3 headers in this image")
+    r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-DPMAF_USE_EIGEN", "-I" + cands[0],
+                        "-I" + os.path.dirname(cands[0]), "-I" + os.path.join(ROOT, "include"),
+                        os.path.join(ROOT, "tests", "cpp", "facade_tick.cpp")], capture_output=True)
+    assert r.returncode == 0, r.stderr.decode()
+
+
+@pytest.mark.gpu
+def test_node_visualisation_loop_does_not_dominate_the_tick(scenes, tmp_path, hip_lib):
+    """the reference node with visualize_predicted_paths: true (every shipped task)
+    calls getPredictedPaths() 3 N + 1 times per tick (panda_bimanual_control.cpp:340-347).
+    As shipped: N = 10 agents, max_prediction_steps 1500. A tick with the loop must
+    cost less than twice a tick without it (one D2H per rollout + cached conversion)."""
+    N, cap, ticks = 10, 1500, 60
+    sc = scenes.static1_scene(N, cap - 1)
+    rvf = tmp_path / "rv.bin"
+    np.ascontiguousarray(sc["random_vecs"]).tofile(rvf)
+    exe = os.path.join(ROOT, "tests", "cpp", "facade_tick")
+    out = subprocess.run([exe, str(N), str(cap), str(ticks), str(rvf), "viz"], capture_output=True, check=True).stdout.decode()
+    v = [l for l in out.strip().split("\n") if l.startswith("V ")][0].split()
+    with_viz, plain, visited = float(v[1]), float(v[2]), int(v[3])
+    print("tick with the visualisation loop %.0f us, without %.0f us (%d path points visited)" % (with_viz, plain, visited))
+    assert visited > 1000 * ticks // 2
+    assert with_viz < 2.0 * plain

@@ -283,6 +283,50 @@ def test_error_reporting(pmaf, scenes):
 # ---------------------------------------------------------------------------
 # reference-faithful oracle (libm exp): north-star tolerance on BASELINE configs
 # ---------------------------------------------------------------------------
+@pytest.mark.parametrize("dynamic", [False, True])
+def test_c3_twelve_ticks_latches_and_hysteresis(pmaf, oracle, scenes, dynamic):
+    """C3 in depth: 12 ticks (12 rollouts of 256 agents x 500 steps through 128
+    obstacles, 11 of them scored) so that rotation vectors latched in one tick
+    persist into the next, known flags travel real agent -> agents, and the
+    0.9 hysteresis is exercised at M = 128; static and moving obstacles"""
+    sc = scenes.config_scene("C3", scene_id=1, dynamic=dynamic)
+    hip, ora = run_both(pmaf, oracle, scenes, sc, 12, dynamic=dynamic)
+    # latches did persist: some agents know obstacles the real agent does not know yet
+    assert hip.known().sum() > 256 * hip.real_known()[0].sum()
+    hip.close()
+
+
+def test_c5_dynamic_obstacles_full_size(pmaf, oracle, scenes):
+    """C5 at full size with MOVING obstacles streamed per tick (group kernel,
+    2 waves per SIMD): 4 ticks, all 8192 agents' paths against 8 oracles"""
+    scs = [scenes.config_scene("C5", scene_id=s, dynamic=True) for s in range(8)]
+    starts = np.stack([s["start"] for s in scs])
+    hip = pmaf.PmafPlanner(scs, device=0, mgr_init_pos=starts)
+    hip.set_initial_position(starts)
+    oras = []
+    for s in scs:
+        o = oracle.OraclePlanner(s, mgr_init_pos=s["start"])
+        o.set_initial_position(s["start"])
+        oras.append(o)
+    obs = np.stack([s["obstacles"] for s in scs])
+    sc = scs[0]
+    for t in range(4):
+        bh = hip.tick(obs, sc["dt"], sc["cost_gains"], sc["ws_limits"])
+        bo = [o.tick(obs[i], sc["dt"], sc["cost_gains"], sc["ws_limits"]) for i, o in enumerate(oras)]
+        np.testing.assert_array_equal(bh, bo)
+        np.testing.assert_array_equal(hip.real_state()[0], np.stack([o.real_state()[0] for o in oras]))
+        obs = np.stack([scenes.advance_live_obstacles(o) for o in obs])
+    ph, nh = hip.paths()
+    rot = hip.rot_vecs()
+    for i, o in enumerate(oras):
+        po, no = o.paths()
+        np.testing.assert_array_equal(nh[i], no)
+        np.testing.assert_array_equal(ph[i], po)
+        np.testing.assert_array_equal(hip.costs()[i], o.costs())
+        np.testing.assert_array_equal(rot[i], o.rot_vecs())
+    hip.close()
+
+
 @pytest.mark.parametrize("cfg,ticks", [("C1", 30), ("C2", 30), ("C3", 2)])
 def test_libm_exp_oracle_within_north_star_tolerance(pmaf, oracle, scenes, cfg, ticks):
     oracle.set_exp_mode(0)
@@ -656,6 +700,43 @@ def test_shipped_task_scenes_closed_loop(pmaf, oracle, scenes, task):
     hip.close()
 
 
+@pytest.mark.parametrize("task", sorted(_task_records()))
+def test_shipped_task_scenes_against_libm_exp_oracle(pmaf, oracle, scenes, task):
+    """The north star's 1e-5 m at the reference's OWN operating point: every
+    shipped task scene as shipped (H = 1500 / 1200, moving obstacles, closed loop
+    until reached / 900 ticks), HIP path (portable exp) against the oracle in
+    its reference-faithful mode (mode 0: the platform libm's exp, as
+    cf_agent.cpp:220 calls it). Per scene: the set-point sequence, the first
+    tick at which the best index differs (none), and the deviation of the
+    SELECTED trajectory (the best agent's predicted path that was scored)."""
+    oracle.set_exp_mode(0)
+    sc = scenes.scene_from_record(_task_records()[task], task)
+    hip, ora = make_pair(pmaf, oracle, sc)
+    obs = sc["obstacles"].copy()
+    max_set, max_sel, first_flip, n_ticks = 0.0, 0.0, None, 0
+    for t in range(900):
+        hip.stop()
+        ph, nh = hip.paths()
+        po, no = ora.paths()
+        bh = hip.tick(obs, sc["dt"], sc["cost_gains"], sc["ws_limits"])
+        bo = ora.tick(obs, sc["dt"], sc["cost_gains"], sc["ws_limits"])
+        obs = scenes.advance_live_obstacles(obs)
+        n_ticks += 1
+        if bh != bo and first_flip is None:
+            first_flip = t
+        if first_flip is None:
+            assert nh[bh] == no[bo]
+            max_sel = max(max_sel, float(np.abs(ph[bh, :nh[bh]] - po[bo, :no[bo]]).max()))
+        max_set = max(max_set, float(np.abs(hip.real_state()[0] - ora.real_state()[0]).max()))
+        if hip.dist_from_goal() < 0.01 and ora.dist_from_goal() < 0.01:
+            break
+    print("%-24s %4d ticks | set-point dev %.3g m | selected-trajectory dev %.3g m | first best-index difference: %s"
+          % (task, n_ticks, max_set, max_sel, first_flip))
+    assert first_flip is None
+    assert max_set <= LIBM_TOL and max_sel <= LIBM_TOL
+    hip.close()
+
+
 def test_checkpoint_resume_is_bit_identical(pmaf, oracle, scenes):
     """pmaf_save_state / pmaf_load_state: a planner restored from a blob (into a
     fresh handle) continues exactly like the original and like the oracle"""
@@ -1000,3 +1081,58 @@ def test_randomised_api_sequences_bit_exact(pmaf):
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "mismatches 0" in r.stdout
+
+
+@pytest.mark.parametrize("lpa", [0, 16, 1])
+def test_synchronous_stepping_api_matches_oracle(pmaf, oracle, scenes, lpa):
+    """SURVEY a18: CfManager::moveAgents / moveAgent / setEEAgentPositions /
+    setEEAgentPosAndVels and CfAgent::evalObstacleDistance (cf_manager.cpp:220-291,
+    cf_agent.cpp:146-157, 278-300) on the device against the oracle's restatement:
+    caller-supplied obstacles incl. their radii, no obstacle advance, the call's
+    own delta_t, agents continue from their own state; then back to the tick"""
+    sc = scenes.synthetic_scene(20, 400, 14, 9, 5, dynamic=True)
+    hip, ora = make_pair(pmaf, oracle, sc, lanes_per_agent=lpa)
+    obs = sc["obstacles"].copy()
+    for t in range(3):                      # some latched rotation vectors / known flags first
+        assert hip.tick(obs, sc["dt"], sc["cost_gains"], sc["ws_limits"]) == ora.tick(obs, sc["dt"], sc["cost_gains"], sc["ws_limits"])
+    hip.stop()
+    start = hip.real_state()[0]
+    hip.set_agent_pos_and_vels(start, [0.9, 0.1, 0.0])   # clamped to vel_max
+    ora.set_agent_pos_and_vels(start, [0.9, 0.1, 0.0])
+    assert_state_equal(hip, ora)
+    with pytest.raises(pmaf.PmafError) as e:
+        hip.move_agents(obs, 0.01, 1000)                 # would outgrow the path buffers
+    assert e.value.code == -3
+    for k, (dt, steps) in enumerate(((0.01, 40), (0.02, 25), (0.005, 60))):
+        live = scenes.advance_live_obstacles(obs, 100.0 / (k + 1))
+        live[:-1, 6] *= 1.0 + 0.1 * k                    # the caller's radii count (cfPlanner uses the list as given)
+        hip.move_agents(live, dt, steps)
+        ora.move_agents(live, dt, steps)
+        assert_state_equal(hip, ora)
+        np.testing.assert_array_equal(hip.eval_obstacle_distance(live), ora.eval_obstacle_distance(live))
+    with pytest.raises(pmaf.PmafError) as e:
+        hip.start()                                       # rollouts need a reset after stepping
+    assert e.value.code == -3
+    # scoring works on the stepped paths (k_score) -- evaluate changes best_agent_ on both sides alike
+    assert hip.evaluate(sc["cost_gains"], sc["ws_limits"]) == ora.evaluate(sc["cost_gains"], sc["ws_limits"])
+    np.testing.assert_array_equal(hip.costs(), ora.costs())
+    # moveAgent: one agent until it is within 0.05 of the goal (or the buffer is full)
+    hip.set_agent_positions(sc["goal"] - np.array([0.3, 0.02, 0.0]))
+    ora.set_agent_positions(sc["goal"] - np.array([0.3, 0.02, 0.0]))
+    room = (sc["max_prediction_steps"] - 1) // 10
+    for agent in (7, 1):
+        ch = hip.move_agent(obs, 0.01, 10, agent, max_calls=room)
+        co = ora.move_agent(obs, 0.01, 10, agent, max_calls=room)
+        assert ch == co and 0 < ch
+    assert_state_equal(hip, ora)
+    assert hip.n_points()[7] > 11 and hip.n_points()[0] == 1
+    # and the ordinary tick continues from there, bit for bit
+    pos, vel, _ = hip.real_state()
+    hip.reset_agents(pos, vel, obs); ora.reset_agents(pos, vel, obs)
+    hip.start(); ora.start()
+    for t in range(4):
+        assert hip.tick(obs, sc["dt"], sc["cost_gains"], sc["ws_limits"]) == ora.tick(obs, sc["dt"], sc["cost_gains"], sc["ws_limits"])
+        obs = scenes.advance_live_obstacles(obs)
+    hip.stop()
+    assert_state_equal(hip, ora)
+    hip.close()

@@ -82,12 +82,25 @@ def test_headless_task_run_matches_oracle(pmaf, oracle, scenes, tmp_path, hip_li
         rvf = tmp_path / "rv.bin"
         np.ascontiguousarray(sc["random_vecs"]).tofile(rvf)
         cmd = [EXE, os.path.join(TASKS, task + ".yaml"), "--start"] + [repr(float(x)) for x in sc["start"]] + \
-              ["--max-ticks", "1200", "--random-vecs", str(rvf)]
+              ["--max-ticks", "1200", "--random-vecs", str(rvf), "--consumer"]
         r = subprocess.run(cmd, capture_output=True, check=True)
         lines = [l for l in r.stdout.decode().strip().split("\n")]
         rows = _oracle_node_run(oracle, scenes, sc, 1200)
-        data = [l for l in lines if not l.startswith("#")]
-        assert len(data) == len(rows)
+        data = [l for l in lines if not l.startswith("#") and not l.startswith("C ")]
+        cons = [l.split() for l in lines if l.startswith("C ")]
+        assert len(data) == len(rows) == len(cons)
+        # f4: every set-point through the oracle's restatement of the consumer (TrajectoryBuffer + followTrajectory,
+        # costp_controller.cpp:289-344): same controller cycles, v_goal, next_ng and counters per tick
+        oc = oracle.OracleConsumer()
+        oc.reset(sc["start"])
+        oc.deliver(sc["start"] + np.array([0.0, 0.0, 0.00001]), sc["velocity_max"])   # :514-518
+        for c, ro in zip(cons, rows):
+            cycles = oc.deliver(np.array(ro[2:5]), sc["velocity_max"])
+            st, cn = oc.state()
+            assert int(c[1]) == ro[0] and int(c[2]) == cycles
+            assert float(c[3]) == st[0] and float(c[4]) == st[2]
+            assert [int(x) for x in c[5:10]] == cn[:5]
+        assert cn[1] == 0 and cn[2] == 0 and cn[3] == 0   # nothing refused, no NaN, no point closer than 1e-6 m
         for l, ro in zip(data, rows):
             f = l.split()
             assert int(f[0]) == ro[0] and int(f[1]) == ro[1]

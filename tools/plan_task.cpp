@@ -3,7 +3,11 @@
 // replaced by "set-point reached" echo, obstacles move like
 // dynamic_obstacle_node. Prints one line per tick:
 //   <tick> <best index> <x> <y> <z> <goal distance>
-// usage: plan_task <task.yaml> --start x y z [--max-ticks N] [--seed S] [--random-vecs f.bin] [--dump-params]
+// With --consumer every set-point is handed to the controller-side SetPointConsumer (setpoint_consumer.h: the
+// reference's TrajectoryBuffer + followTrajectory acceptance logic, cycled at 1 kHz until it asks for the next
+// point, like VrepController::targetPoseCallback) and each tick prints a second line
+//   C <tick> <controller cycles> <v_goal> <next_ng> <accepted> <refused> <nan> <too_close> <inconsistent>
+// usage: plan_task <task.yaml> --start x y z [--max-ticks N] [--seed S] [--random-vecs f.bin] [--consumer] [--dump-params]
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -45,13 +49,14 @@ int main(int argc, char **argv) {
   double start[3] = {0, 0, 0};
   long max_ticks = 5000;
   unsigned long long seed = 1;
-  bool dump_only = false;
+  bool dump_only = false, with_consumer = false;
   const char *rv_file = nullptr;
   for (int i = 2; i < argc; ++i) {
     if (!strcmp(argv[i], "--start") && i + 3 < argc) { for (int c = 0; c < 3; ++c) start[c] = atof(argv[++i]); }
     else if (!strcmp(argv[i], "--max-ticks") && i + 1 < argc) max_ticks = atol(argv[++i]);
     else if (!strcmp(argv[i], "--seed") && i + 1 < argc) seed = strtoull(argv[++i], nullptr, 10);
     else if (!strcmp(argv[i], "--dump-params")) dump_only = true;
+    else if (!strcmp(argv[i], "--consumer")) with_consumer = true;
     else if (!strcmp(argv[i], "--random-vecs") && i + 1 < argc) rv_file = argv[++i];
   }
   try {
@@ -72,6 +77,10 @@ int main(int argc, char **argv) {
     for (const GoalSpec &goal : task.goals) {
       if (goal.type != "plan") continue;               // key / gesture / goto ...: operator or robot actions
       Position sp = node.startPlan(goal);
+      SetPointConsumer consumer;                         // the controller is reset at the start pose ...
+      consumer.reset(Vector3d(start[0], start[1], start[2]));
+      if (with_consumer)                                 // ... and receives the first published point (:514-518)
+        consumer.deliver(Vector3d(sp.data[0], sp.data[1], sp.data[2]), node.velocity());
       position = Position{{sp.data[0], sp.data[1], sp.data[2] - 0.00001}};
       Vector3d prev(position.data[0], position.data[1], position.data[2]);
       while (tick < max_ticks) {
@@ -82,6 +91,12 @@ int main(int argc, char **argv) {
         std::string why;
         if (!validateSetPoint(prev, nv, &why)) fprintf(stderr, "tick %ld: rejected by the consumer contract: %s\n", tick, why.c_str());
         printf("%ld %d %.17g %.17g %.17g %.17g\n", tick, best, next.data[0], next.data[1], next.data[2], node.goalDistance());
+        if (with_consumer) {
+          const long cycles = consumer.deliver(nv, node.velocity());
+          const SetPointConsumer::Counters &cn = consumer.counters();
+          printf("C %ld %ld %.17g %.17g %ld %ld %ld %ld %ld\n", tick, cycles, consumer.vGoal(), consumer.nextNg(),
+                 cn.accepted, cn.refused, cn.nan, cn.too_close, cn.inconsistent);
+        }
         prev = nv;
         position = next;                               // echo: the set-point is reached
         node.obstacleCallback(source.step());          // obstacle stream between ticks

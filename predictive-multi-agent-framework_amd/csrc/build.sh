@@ -20,7 +20,7 @@ cd "$(dirname "$0")"
 ROCM=${ROCM_PATH:-/opt/rocm}
 HIPCC=${HIPCC:-$ROCM/bin/hipcc}
 CXX=${CXX:-g++}
-OUT=../lib
+OUT=${PMAF_OUT:-../lib}   # PMAF_OUT: another output directory (variant / timer builds under tools/dbg)
 OBJ=$OUT/obj
 mkdir -p "$OBJ"
 # -Rpass-analysis=kernel-resource-usage: registers / occupancy of every kernel,

@@ -201,6 +201,11 @@ static int pick_lpa(int N, int P, int M) {
     long waves = ((long)N * lpa + 63) / 64 * P;
     if (waves > (lpa == 64 ? 1024 : 2048)) lpa /= 2; else break;
   }
+  // 129..256 obstacles: the lane-group kernels hold at most 4 slots per lane (M <= 128 at 32 lanes), so a narrower
+  // mapping would fall to the generic LDS-table kernel -- the four-slot wave-per-agent kernel is 2.7-3.7x faster
+  // even with several rounds of waves (measured, tools/m200time.py: 2048 agents x 300 steps, M = 200: 2.95 ms
+  // against 8.08 ms; M = 256: 3.36 ms against 12.5 ms; 4096 agents x 200 steps: 3.8 / 4.1 ms against 8.3 / 10.2 ms)
+  if (lpa < 64 && M > 128 && M <= 256) lpa = 64;
   // known-flag bitmask holds 64 tiles per lane
   while ((M + lpa - 1) / lpa > 64 && lpa < 64) lpa *= 2;
   return lpa;

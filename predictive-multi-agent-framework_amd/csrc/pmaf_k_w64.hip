@@ -216,7 +216,14 @@ __device__ __forceinline__ void rollout_w64_body(const DevView &D, const CostPar
 #endif
 
   double cost_ws, path_len;
+#ifdef PMAF_SECTION_TIMERS
+  const unsigned long long t_loop_end = wall_clock64();
+#endif
   path_cost_terms_w64<MATH>(lane, path, n, CP.ws, CP.k_workspace, clist, cost_ws, path_len);
+#ifdef PMAF_SECTION_TIMERS
+  if (lane == 0 && pop == 0 && a < 7)
+    printf("agent %d: loop %llu0 ns, path-cost pass %llu0 ns (%d points)\n", a, t_loop_end - t_begin, wall_clock64() - t_loop_end, n);
+#endif
 
   const double min_obs = wave_min64(lane_min);
   int32_t *ko = D.known_out + pa * n_obs;

@@ -416,6 +416,11 @@ __device__ __forceinline__ void circ_and_scale_w64(int lane, V3 p, V3 v, double 
 // evaluation, so the bits are the same.
 // The points were written by lane 0: the agent-scope fence + agent-scope loads
 // make them visible to the other lanes (not served from a stale L1 line).
+// Round 2 measured this pass at ~1.5 us per 64 points (C2: ~6 us of a 300 us launch) and tried to shorten it -- each
+// point fetched once with the predecessor moved by DPP wave_shr:1 (halves the pass's fetch traffic), the next block's
+// loads in flight during the sum: bit-exact, but C2 303.1 -> 305.7 us / 306.5 us (two variants, A/B on one box,
+// tools/ab.sh): the extra live values raise the kernel's SGPR spill count (191 -> 194 / 203) and the step loop pays
+// for it. Kept as it was.
 __device__ __forceinline__ double ld_agent(const double *p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }

@@ -1136,3 +1136,19 @@ def test_synchronous_stepping_api_matches_oracle(pmaf, oracle, scenes, lpa):
     hip.stop()
     assert_state_equal(hip, ora)
     hip.close()
+
+
+def test_many_agents_with_200_obstacles_stay_on_the_four_slot_kernel(pmaf, oracle, scenes):
+    """N x P > 1024 waves with 129..256 obstacles: the launch keeps the
+    wave-per-agent mapping (k_rollout_w64<4>, several rounds of waves) instead of
+    falling to the generic kernel (2.7-3.7x slower, tools/m200time.py); parity of
+    a 1200-agent population through 200 obstacles"""
+    sc = scenes.synthetic_scene(1200, 60, 200, 6, 2)
+    hip, ora = make_pair(pmaf, oracle, sc)
+    assert hip.launch_config()["lanes_per_agent"] == 64
+    for t in range(2):
+        assert hip.tick(sc["obstacles"], sc["dt"], sc["cost_gains"], sc["ws_limits"]) == \
+            ora.tick(sc["obstacles"], sc["dt"], sc["cost_gains"], sc["ws_limits"])
+    hip.stop()
+    assert_state_equal(hip, ora)
+    hip.close()

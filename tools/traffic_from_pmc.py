@@ -3,7 +3,10 @@
 (tools/gpu_prof.sh): HBM bytes per launch of the dominant kernel, corrected as
 MI355X_MICROARCH.md prescribes for gfx950 (FETCH_SIZE counts 64 B per 128-B
 request: doubled; counters are in KiB). One entry per (config, kernel):
-usage: traffic_from_pmc.py C2=r1_c2 C3=r1_c3 C5x8=r1_c5"""
+The x2 for FETCH_SIZE and x1 for WRITE_SIZE were checked on known byte counts in
+this kernel's own access patterns (8-byte loads / same-address 8-byte stores):
+tools/calib_traffic.hip, profiles/r2_traffic_calibration.txt.
+usage: traffic_from_pmc.py C2=r2_c2 C3=r2_c3 C5x8=r2_c5"""
 import json
 import re
 import sys
@@ -35,6 +38,7 @@ for arg in (sys.argv[1:] or ["C2=r1_c2"]):
             "valu_insts_per_launch": act.get(k, {}).get("SQ_INSTS_VALU"),
             "waves_per_launch": act.get(k, {}).get("SQ_WAVES"),
             "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes of `bench.py --steps 50 --warmup 5` "
-                      "(profiles/%s_pmc3.txt, _pmc4.txt); FETCH_SIZE doubled per the gfx950 note" % tag}
+                      "(profiles/%s_pmc3.txt, _pmc4.txt); FETCH_SIZE x 2, WRITE_SIZE x 1 as calibrated on known byte counts in this "
+                      "kernel's 8-byte access patterns (profiles/r2_traffic_calibration.txt)" % tag}
 json.dump(res, open("profiles/traffic.json", "w"), indent=1)
 print(json.dumps(res, indent=1))

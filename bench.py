@@ -119,7 +119,11 @@ def kernel_name_of(cfg, n_obs):
         tiles = 2
     generic = os.environ.get("PMAF_FORCE_GENERIC") == "1"
     if cfg["lanes_per_agent"] == 64 and tiles <= 4 and not generic:
-        return "k_rollout_w64<%d, 2>" % (1 if tiles <= 1 else 2 if tiles == 2 else 4)  # <TILES, MATH_XACT>
+        t = 1 if tiles <= 1 else 2 if tiles == 2 else 4
+        dpp = t > 1 or (n_obs - 1) > 20
+        if os.environ.get("PMAF_SUM"):
+            dpp = t > 1 or os.environ["PMAF_SUM"].startswith("d")
+        return "k_rollout_w64<%d, 2, %s>" % (t, "true" if dpp else "false")  # <TILES, MATH_XACT, DPPSUM>
     if cfg["lanes_per_agent"] in (8, 16, 32) and (n_obs - 2) // cfg["lanes_per_agent"] + 1 <= 4 and not generic:
         tl = (n_obs - 2) // cfg["lanes_per_agent"] + 1
         return "k_rollout_grp<%d, %d, 2>" % (cfg["lanes_per_agent"], 1 if tl <= 1 else 2 if tl == 2 else 4)

@@ -57,6 +57,7 @@ struct pmaf_planner {
   int lpa = 64;
   int math = MATH_XACT;        // arithmetic policy of the w64 rollout kernels (pmaf_device.hpp)
   bool force_generic = false;  // PMAF_FORCE_GENERIC=1: always use the generic k_rollout<LPA>
+  bool dpp_sum = true;         // w64 kernels: ordered force sum by the DPP chain (M > 20) or LDS batches
   int n_blocks = 0;
   size_t lds_rollout = 0, lds_manager = 0;
   hipStream_t stream = nullptr;
@@ -252,7 +253,9 @@ static void launch_rollout(pmaf_planner *h) {
   const int tiles64 = (M >= 62 && M <= 64) ? 2 : (M + 63) / 64;
   bool ok;
   if (h->lpa == 64 && tiles64 <= 4 && !h->force_generic)
-    ok = pmaf_k_launch_w64(h->D, h->cp, tiles64, h->math, h->lds_rollout, h->stream);
+    // ordered force sum: DPP chain from ~20 field obstacles up (lists long enough to need several LDS round trips),
+    // LDS batches below (pmaf_rollout_w64.hpp, tools/msweep.py)
+    ok = pmaf_k_launch_w64(h->D, h->cp, tiles64, h->math, h->dpp_sum, h->lds_rollout, h->stream);
   else if (!h->force_generic && (h->lpa == 32 || h->lpa == 16 || h->lpa == 8) && (M + h->lpa - 1) / h->lpa <= 4)
     // (the opt-in fast arithmetic exists for the w64 kernels only)
     ok = pmaf_k_launch_grp(h->D, h->cp, h->lpa, (M + h->lpa - 1) / h->lpa, h->math == MATH_IEEE ? MATH_IEEE : MATH_XACT,
@@ -518,6 +521,8 @@ int pmaf_create(const pmaf_params *prm, pmaf_planner **out) {
     h->lpa = lp ? lp : pick_lpa(N, P, M);
     { const char *fg = getenv("PMAF_FORCE_GENERIC"); h->force_generic = fg && fg[0] == '1'; }
     { const char *ab = getenv("PMAF_ABLATE"); D.ablate = ab ? atoi(ab) : 0; }
+    h->dpp_sum = M > 20;
+    { const char *ds = getenv("PMAF_SUM"); if (ds && ds[0]) h->dpp_sum = (ds[0] == 'd'); }  // "dpp" / "lds": tests, timing
     {
       int cus = 0;
       HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device));

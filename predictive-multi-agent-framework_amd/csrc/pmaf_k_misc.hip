@@ -665,16 +665,17 @@ __global__ void k_eval_obstacle_distance(DevView D, const double *obs, double *o
 // ---------------------------------------------------------------------------
 // launch interface (pmaf_types.hpp)
 // ---------------------------------------------------------------------------
-bool pmaf_k_launch_w64_m0(const DevView &, const CostParams &, int, size_t, hipStream_t);
-bool pmaf_k_launch_w64_m1(const DevView &, const CostParams &, int, size_t, hipStream_t);
-bool pmaf_k_launch_w64_m2(const DevView &, const CostParams &, int, size_t, hipStream_t);
+bool pmaf_k_launch_w64_m0(const DevView &, const CostParams &, int, bool, size_t, hipStream_t);
+bool pmaf_k_launch_w64_m1(const DevView &, const CostParams &, int, bool, size_t, hipStream_t);
+bool pmaf_k_launch_w64_m2(const DevView &, const CostParams &, int, bool, size_t, hipStream_t);
 bool pmaf_k_launch_grp_m0(const DevView &, const CostParams &, int, int, int, size_t, hipStream_t);
 bool pmaf_k_launch_grp_m2(const DevView &, const CostParams &, int, int, int, size_t, hipStream_t);
 
-bool pmaf_k_launch_w64(const DevView &D, const CostParams &cp, int tiles, int math, size_t lds, hipStream_t s) {
-  if (math == MATH_FAST) return pmaf_k_launch_w64_m1(D, cp, tiles, lds, s);
-  if (math == MATH_IEEE) return pmaf_k_launch_w64_m0(D, cp, tiles, lds, s);
-  return pmaf_k_launch_w64_m2(D, cp, tiles, lds, s);
+bool pmaf_k_launch_w64(const DevView &D, const CostParams &cp, int tiles, int math, bool dppsum, size_t lds,
+                       hipStream_t s) {
+  if (math == MATH_FAST) return pmaf_k_launch_w64_m1(D, cp, tiles, dppsum, lds, s);
+  if (math == MATH_IEEE) return pmaf_k_launch_w64_m0(D, cp, tiles, dppsum, lds, s);
+  return pmaf_k_launch_w64_m2(D, cp, tiles, dppsum, lds, s);
 }
 
 bool pmaf_k_launch_grp(const DevView &D, const CostParams &cp, int lpa, int tiles, int math, int n_blocks, size_t lds,

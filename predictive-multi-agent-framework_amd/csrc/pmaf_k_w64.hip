@@ -17,7 +17,7 @@ using namespace pmaf;
 // carries no type dispatch (the type is uniform per wave)
 // SENT: 0 = the repulsive obstacle cannot come into range during this rollout (decided by the caller, one-slot kernel
 // only: the step loop then has no block for it), 1 = it can, 2 = decide here at run time (the other kernels)
-template <int TILES, int TYPE, int MATH, int SENT = 2>
+template <int TILES, int TYPE, int MATH, int SENT = 2, bool DPPSUM = false>
 __device__ __forceinline__ void rollout_w64_body(const DevView &D, const CostParams &CP, const int lane,
                                                  const int pop, const int a) {
   extern __shared__ double smem[];
@@ -123,7 +123,7 @@ __device__ __forceinline__ void rollout_w64_body(const DevView &D, const CostPar
     PMAF_SEC(ST, 0);
     // (called with the gate closed too: the sweep's few compares then find no obstacle -- one branch less in the step)
     if (PRE || (gate && !(D.ablate & 8)))
-      circ_and_scale_w64<TILES, TYPE, MATH, PRE>(lane, p, v, zv, goal, g, dg, gn, C, k_circ, n_obs, rot_g, known_bits,
+      circ_and_scale_w64<TILES, TYPE, MATH, PRE, DPPSUM>(lane, p, v, zv, goal, g, dg, gn, C, k_circ, n_obs, rot_g, known_bits,
                                                  O, clist, lane_min, F, scale, ST, EK, D.ablate, 0, s_pre, ron_pre,
                                                  gate);
     PMAF_SEC(ST, 5);
@@ -219,7 +219,11 @@ __device__ __forceinline__ void rollout_w64_body(const DevView &D, const CostPar
 #ifdef PMAF_SECTION_TIMERS
   const unsigned long long t_loop_end = wall_clock64();
 #endif
+#ifdef PMAF_ABL_NOCOST     // timing experiments only: no path-cost pass after the loop
+  cost_ws = 0.0; path_len = 0.0;
+#else
   path_cost_terms_w64<MATH>(lane, path, n, CP.ws, CP.k_workspace, clist, cost_ws, path_len);
+#endif
 #ifdef PMAF_SECTION_TIMERS
   if (lane == 0 && pop == 0 && a < 7)
     printf("agent %d: loop %llu0 ns, path-cost pass %llu0 ns (%d points)\n", a, t_loop_end - t_begin, wall_clock64() - t_loop_end, n);
@@ -246,7 +250,7 @@ __device__ __forceinline__ void rollout_w64_body(const DevView &D, const CostPar
   }
 }
 
-template <int TILES, int MATH>
+template <int TILES, int MATH, bool DPPSUM>
 __global__ __launch_bounds__(64) void k_rollout_w64(DevView D, CostParams CP) {
   const int lane = threadIdx.x;
   const int pop = blockIdx.y;
@@ -262,8 +266,8 @@ __global__ __launch_bounds__(64) void k_rollout_w64(DevView D, CostParams CP) {
     const PopConst C0 = D.C;
     const bool reach = sentinel_reachable(p0, sp, sv, D.zsent_lt[pop], C0, D.cap);
 #define PMAF_BODY(T) \
-    if (reach) rollout_w64_body<TILES, T, MATH, 1>(D, CP, lane, pop, a); \
-    else rollout_w64_body<TILES, T, MATH, 0>(D, CP, lane, pop, a)
+    if (reach) rollout_w64_body<TILES, T, MATH, 1, DPPSUM>(D, CP, lane, pop, a); \
+    else rollout_w64_body<TILES, T, MATH, 0, DPPSUM>(D, CP, lane, pop, a)
     switch (D.types[a]) {
       case T_GOAL: PMAF_BODY(T_GOAL); break;
       case T_OBST: PMAF_BODY(T_OBST); break;
@@ -277,12 +281,12 @@ __global__ __launch_bounds__(64) void k_rollout_w64(DevView D, CostParams CP) {
     return;
   }
   switch (D.types[a]) {
-    case T_GOAL: rollout_w64_body<TILES, T_GOAL, MATH>(D, CP, lane, pop, a); break;
-    case T_OBST: rollout_w64_body<TILES, T_OBST, MATH>(D, CP, lane, pop, a); break;
-    case T_GOALOBST: rollout_w64_body<TILES, T_GOALOBST, MATH>(D, CP, lane, pop, a); break;
-    case T_VEL: rollout_w64_body<TILES, T_VEL, MATH>(D, CP, lane, pop, a); break;
-    case T_RANDOM: rollout_w64_body<TILES, T_RANDOM, MATH>(D, CP, lane, pop, a); break;
-    case T_HAD: rollout_w64_body<TILES, T_HAD, MATH>(D, CP, lane, pop, a); break;
+    case T_GOAL: rollout_w64_body<TILES, T_GOAL, MATH, 2, DPPSUM>(D, CP, lane, pop, a); break;
+    case T_OBST: rollout_w64_body<TILES, T_OBST, MATH, 2, DPPSUM>(D, CP, lane, pop, a); break;
+    case T_GOALOBST: rollout_w64_body<TILES, T_GOALOBST, MATH, 2, DPPSUM>(D, CP, lane, pop, a); break;
+    case T_VEL: rollout_w64_body<TILES, T_VEL, MATH, 2, DPPSUM>(D, CP, lane, pop, a); break;
+    case T_RANDOM: rollout_w64_body<TILES, T_RANDOM, MATH, 2, DPPSUM>(D, CP, lane, pop, a); break;
+    case T_HAD: rollout_w64_body<TILES, T_HAD, MATH, 2, DPPSUM>(D, CP, lane, pop, a); break;
     default: break;
   }
 }
@@ -293,12 +297,14 @@ __global__ __launch_bounds__(64) void k_rollout_w64(DevView D, CostParams CP) {
 #endif
 #define PMAF_CAT2(a, b) a##b
 #define PMAF_CAT(a, b) PMAF_CAT2(a, b)
-bool PMAF_CAT(pmaf_k_launch_w64_m, PMAF_W64_MATH)(const DevView &D, const CostParams &cp, int tiles, size_t lds,
-                                                  hipStream_t s) {
+bool PMAF_CAT(pmaf_k_launch_w64_m, PMAF_W64_MATH)(const DevView &D, const CostParams &cp, int tiles, bool dppsum,
+                                                  size_t lds, hipStream_t s) {
   const dim3 g64((unsigned)D.N, (unsigned)D.P), block(64);
-  if (tiles <= 1) hipLaunchKernelGGL((k_rollout_w64<1, PMAF_W64_MATH>), g64, block, lds, s, D, cp);
-  else if (tiles == 2) hipLaunchKernelGGL((k_rollout_w64<2, PMAF_W64_MATH>), g64, block, lds, s, D, cp);
-  else if (tiles <= 4) hipLaunchKernelGGL((k_rollout_w64<4, PMAF_W64_MATH>), g64, block, lds, s, D, cp);
+  // one slot per lane: both ordered-sum variants (the host picks by obstacle count); two / four slots: DPP only
+  if (tiles <= 1 && !dppsum) hipLaunchKernelGGL((k_rollout_w64<1, PMAF_W64_MATH, false>), g64, block, lds, s, D, cp);
+  else if (tiles <= 1) hipLaunchKernelGGL((k_rollout_w64<1, PMAF_W64_MATH, true>), g64, block, lds, s, D, cp);
+  else if (tiles == 2) hipLaunchKernelGGL((k_rollout_w64<2, PMAF_W64_MATH, true>), g64, block, lds, s, D, cp);
+  else if (tiles <= 4) hipLaunchKernelGGL((k_rollout_w64<4, PMAF_W64_MATH, true>), g64, block, lds, s, D, cp);
   else return false;
   return true;
 }

@@ -250,7 +250,12 @@ __device__ __forceinline__ V3 closest_other_w64(bool need_latch, int t, int lane
 // ordered force sum (the list is zero-padded, adding +0.0 is exact).
 // PRE: |ro| and ro.normalized() of the lane's slot were computed by the caller (s_pre, ron_pre; one slot per lane
 // only) -- the rollout does that at the end of the previous step, see rollout_w64_body.
-template <int TILES, int TYPE, int MATH, bool PRE = false>
+// DPPSUM: how the ordered force sum is evaluated -- false: LDS list read back in batches of 8 entries (one LDS round
+// trip per batch; fewer dependent adds for short lists), true: row-transposed list + DPP row_newbcast chain (one
+// ds_read per 16 entries, one dependent add per entry for all three components). Measured crossover at M ~ 20
+// field obstacles (tools/msweep.py, 64 agents x 200 steps): M = 16 274 vs 282 us, M = 32 301 vs 287 us, M = 61 353 vs
+// 326 us; C3 (M = 128, ~57 terms per step) 1603 -> 1322 us. The host picks per launch (pmaf_host.cpp).
+template <int TILES, int TYPE, int MATH, bool PRE = false, bool DPPSUM = false>
 __device__ __forceinline__ void circ_and_scale_w64(int lane, V3 p, V3 v, double zv, V3 goal, V3 g, double dg, V3 gn,
                                                    const PopConst &C, double k_circ,
                                                    int n_obs, double *rot_g, unsigned &known_bits,
@@ -265,6 +270,8 @@ __device__ __forceinline__ void circ_and_scale_w64(int lane, V3 p, V3 v, double 
   const int type = (TYPE == T_REAL) ? rtype : TYPE;
   constexpr int BATCH = 8;                 // list entries summed per LDS round trip (10, 12, 16 measured: no gain)
   constexpr int SCRATCH = 64 * TILES + BATCH;
+  constexpr int SUM_SCRATCH = (4 * TILES + 1) * 64;  // PMAF_SUM_DPP: 4 TILES chunks of 64 doubles + the padding chunk
+  (void)SCRATCH; (void)SUM_SCRATCH;
   const int M = n_obs - 1;
   double best_d = C.shell;
   double best_s = 0.0, best_gr = 0.0;  // |ro| and g.ro of the lane's closest obstacle
@@ -333,16 +340,33 @@ __device__ __forceinline__ void circ_and_scale_w64(int lane, V3 p, V3 v, double 
     MT::norm_rcp(rv, vn, rvn);
     const V3 nv = MT::div3_n(rv, vn, rvn);
     const V3 cur = current_vector<MATH>(type, rv, g, ron_t[t], rot);
+#ifdef PMAF_ABL_NOCIRC   // timing experiments only (tools/ablate.sh): no circular-term arithmetic, list traffic kept
+    const V3 c = rv; (void)nv; (void)cur; (void)rot;
+#else
     const V3 c = MT::div(k_circ, d_t[t] * d_t[t]) * cross(nv, cross(cur, nv));
+#endif
     const bool has_c = in_t[t] && (vn != 0);
     // compact the contributing terms, ascending obstacle index
     const unsigned long long m = __ballot(has_c);
-    const int slot = has_c ? (count + lane_rank(m)) : (SCRATCH + lane);
-    double *e = clist + (size_t)slot * 4;
-    e[0] = c.x; e[1] = c.y; e[2] = c.z;
+    if (DPPSUM) {
+      // row-transposed list: 16 entries per chunk of 64 doubles, [x0..x15 | y0..y15 | z0..z15 | -], so that ONE
+      // conflict-free ds_read hands lane 16 r + k component r of entry k (see the sum below); lanes without a term
+      // store to a scratch area behind the list
+      const int sl = count + lane_rank(m);
+      const int idx = has_c ? (((sl >> 4) << 6) + (sl & 15)) : (SUM_SCRATCH + lane);
+      const int st = has_c ? 16 : 64;
+      clist[idx] = c.x; clist[idx + st] = c.y; clist[idx + 2 * st] = c.z;
+    } else {
+      const int slot = has_c ? (count + lane_rank(m)) : (SCRATCH + lane);
+      double *e = clist + (size_t)slot * 4;
+      e[0] = c.x; e[1] = c.y; e[2] = c.z;
+    }
     count += __popcll(m);
   }
-  {  // zero padding behind the list (8 distinct entries, written by all lanes)
+  if (DPPSUM) {
+    // zero padding: the rest of the list's last chunk (the whole next chunk when the list ends on a chunk boundary)
+    if ((lane & 15) >= (count & 15)) clist[((count >> 4) << 6) + lane] = 0.0;
+  } else {  // zero padding behind the list (8 distinct entries, written by all lanes)
     double *e = clist + (size_t)(count + (lane % BATCH)) * 4;
     e[0] = 0.0; e[1] = 0.0; e[2] = 0.0;
   }
@@ -350,6 +374,9 @@ __device__ __forceinline__ void circ_and_scale_w64(int lane, V3 p, V3 v, double 
 
   // ---- attractorForceScaling value (:212-226), branchless ----
   double sc;
+#ifdef PMAF_ABL_NOSCALE    // timing experiments only: no attractor-scaling chain
+  sc = 1.0;
+#else
   {
     const double m = wave_min64(best_d);
     const bool cand = (best_i != 0x7fffffff) && (best_d == m);
@@ -371,6 +398,7 @@ __device__ __forceinline__ void circ_and_scale_w64(int lane, V3 p, V3 v, double 
     const double w = w1 * w2;
     sc = (bi == 0x7fffffff) ? 1.0 : (stall ? 0.0 : w);
   }
+#endif
 
   // ---- F = ((0 + c_0) + c_1) + ... front to back; every lane reads the same
   // address (LDS broadcast), so every lane ends with the same F. The list is
@@ -380,6 +408,27 @@ __device__ __forceinline__ void circ_and_scale_w64(int lane, V3 p, V3 v, double 
   // accesses for the COMPILER -- without them it may reorder or forward its own
   // LDS accesses (observed: wrong sums); the hardware executes a wave's DS
   // instructions in order, so no instruction is emitted for them.
+#ifndef PMAF_ABL_NOSUM     // (timing experiments only: without the ordered sum F stays 0)
+  if (DPPSUM) {
+  // F = ((0 + c_0) + c_1) + ... in ascending obstacle index, WITHOUT an LDS round trip per batch: one ds_read per 16
+  // entries puts x_k / y_k / z_k of entry k into lane k of rows 0 / 1 / 2, and one DPP row_newbcast:k move per entry
+  // feeds a single v_add_f64 that advances all three component sums at once (row 0 sums x, row 1 y, row 2 z). The
+  // moves do not depend on the accumulator, so the dependent chain is ONE add per entry; entries past the end of the
+  // list are +0.0 (exact no-op; skipping them in groups of 4 or 8 costs more in branches than the adds: measured).
+  wave_lds_fence();
+  {
+    double acc = 0.0;
+    for (int c16 = 0; c16 < count; c16 += 16) {
+      const double e = clist[(c16 << 2) + lane];
+#define PMAF_BC(K) acc = acc + __builtin_amdgcn_update_dpp(e, e, 0x150 + K, 0xf, 0xf, true);
+      PMAF_BC(0) PMAF_BC(1) PMAF_BC(2) PMAF_BC(3) PMAF_BC(4) PMAF_BC(5) PMAF_BC(6) PMAF_BC(7)
+      PMAF_BC(8) PMAF_BC(9) PMAF_BC(10) PMAF_BC(11) PMAF_BC(12) PMAF_BC(13) PMAF_BC(14) PMAF_BC(15)
+#undef PMAF_BC
+    }
+    F = mk(readlane_d(acc, 0), readlane_d(acc, 16), readlane_d(acc, 32));
+  }
+  wave_lds_fence();
+  } else {
   wave_lds_fence();
   // Two or more slots per lane (long lists, C3: ~57 terms = 8 round trips per step): only lane 0 reads and adds --
   // a broadcast ds_read still returns 64 lanes' worth of data, with one active lane the round trip is shorter
@@ -400,6 +449,8 @@ __device__ __forceinline__ void circ_and_scale_w64(int lane, V3 p, V3 v, double 
   }
   if (TILES > 1) F = readlane_v3(F, 0);
   wave_lds_fence();
+  }
+#endif
   PMAF_SEC(ST, 3);
   scale = (sqn(F) >= C.zf_gt) ? sc : scale;  // norm(F) > 1e-5
   PMAF_SEC(ST, 4);

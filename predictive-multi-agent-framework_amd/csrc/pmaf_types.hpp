@@ -109,8 +109,10 @@ struct PlanArgs {
 // ---------------------------------------------------------------------------
 // launch interface: implemented in pmaf_k_w64.hip / pmaf_k_grp.hip / pmaf_k_misc.hip
 // ---------------------------------------------------------------------------
-// k_rollout_w64<TILES, MATH> on grid (N, P); tiles in {1,2,4}. Returns false if this build holds no such variant.
-bool pmaf_k_launch_w64(const DevView &D, const CostParams &cp, int tiles, int math, size_t lds, hipStream_t s);
+// k_rollout_w64<TILES, MATH, DPPSUM> on grid (N, P); tiles in {1,2,4}; dppsum: the ordered force sum by the DPP
+// row-broadcast chain (always for tiles >= 2) or by LDS batches. Returns false if this build holds no such variant.
+bool pmaf_k_launch_w64(const DevView &D, const CostParams &cp, int tiles, int math, bool dppsum, size_t lds,
+                       hipStream_t s);
 // k_rollout_grp<LPA, TILES, MATH> on grid (n_blocks, P); lpa in {8,16,32}, tiles in {1,2,4}, math XACT or IEEE
 bool pmaf_k_launch_grp(const DevView &D, const CostParams &cp, int lpa, int tiles, int math, int n_blocks, size_t lds,
                        hipStream_t s);

@@ -1152,3 +1152,26 @@ def test_many_agents_with_200_obstacles_stay_on_the_four_slot_kernel(pmaf, oracl
     hip.stop()
     assert_state_equal(hip, ora)
     hip.close()
+
+
+@pytest.mark.parametrize("mode", ["lds", "dpp"])
+@pytest.mark.parametrize("cfg,ticks,dynamic", [("C1", 12, False), ("C2", 10, True)])
+def test_both_ordered_sum_variants_of_the_one_slot_kernel(pmaf, oracle, scenes, monkeypatch, mode, cfg, ticks, dynamic):
+    """the ordered force sum of the wave-per-agent kernel exists in two variants
+    (LDS batches for short lists, DPP row_newbcast chain for long ones; the host
+    picks by obstacle count): both on both configs, bit-exact, plus a dense scene
+    with up to 61 in-shell terms (4 chunks of 16, chunk-boundary padding)"""
+    monkeypatch.setenv("PMAF_SUM", mode)
+    sc = scenes.config_scene(cfg, dynamic=dynamic) if cfg != "C1" else scenes.config_scene(cfg)
+    hip, _ = run_both(pmaf, oracle, scenes, sc, ticks, dynamic=dynamic)
+    hip.close()
+    # every obstacle within the shell of the start: lists of 16, 32, 48 and 61 entries
+    for m in (16, 32, 48, 61):
+        sc = scenes.synthetic_scene(8, 60, m, 7, m)
+        rng = scenes.SplitMix64(99 + m)
+        u = rng.uniform(3 * m).reshape(m, 3)
+        sc["obstacles"][:m, 0:3] = sc["start"] + 0.12 + 0.1 * u          # a cluster 0.2-0.35 m from the start
+        sc["obstacles"][:m, 6] = 0.02
+        sc["detect_shell_rad"] = 0.6
+        hip, _ = run_both(pmaf, oracle, scenes, sc, 3)
+        hip.close()

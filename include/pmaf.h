@@ -335,7 +335,10 @@ int pmaf_get_launch_config(pmaf_planner *h, int32_t *lanes_per_agent,
 /* Self-test of the device arithmetic the parity argument rests on: evaluates
  * op over n elements ON THE GPU (0: a/b, 1: sqrt(a), 2: the kernels' portable exp(a), 3: a*b,
  * 4: a+b; 5: the kernels' guarded sqrt, 6: guarded divide, 7 / 8: vector /
- * scalar through the guarded / the compiler's divide). Tests compare the
+ * scalar through the guarded / the compiler's divide; 9 / 10: a / sqrt(b)
+ * through the kernels' shared-reciprocal sequence / the compiler; 11 / 12: the
+ * fixup-free a / b and a / sqrt(b) used where the divisor is a positive
+ * normal). Tests compare the
  * results bitwise with the host's IEEE results. */
 int pmaf_debug_math(int32_t op, int32_t n, const double *a, const double *b, double *out);
 

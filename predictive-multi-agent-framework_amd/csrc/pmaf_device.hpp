@@ -92,6 +92,10 @@ template <> struct Mth<MATH_IEEE> {
   static __device__ __forceinline__ void norm_rcp(V3 a, double &s, double &rs) { s = __builtin_sqrt(sqn(a)); rs = 0.0; }
   static __device__ __forceinline__ double div_n(double x, double s, double) { return x / s; }
   static __device__ __forceinline__ V3 div3_n(V3 a, double s, double) { return a / s; }
+  // (the *_pos variants of the default policy are plain divisions here)
+  static __device__ __forceinline__ double div_pos(double a, double b) { return a / b; }
+  static __device__ __forceinline__ double div_n_pos(double x, double s, double) { return x / s; }
+  static __device__ __forceinline__ V3 div3_n_pos(V3 a, double s, double) { return a / s; }
   // s = |a|, u = a.normalized()
   template <bool TP = false>
   static __device__ __forceinline__ void norm_unit(V3 a, double &s, V3 &u) {
@@ -132,6 +136,22 @@ template <> struct Mth<MATH_XACT> {
     return __builtin_amdgcn_div_fixup(q, b, a);
   }
   static __device__ __forceinline__ double div(double a, double b) { return div_r(a, b, rcp_refined(b)); }
+  // a / b WITHOUT the v_div_fixup, for the sites where it could only pass q through: b positive, finite and normal
+  // (a norm behind a `squaredNorm > 0` select, a clamped squared distance, 2 - c in exp) or the quotient is discarded
+  // whenever b is not (the selects say so at each call site), and a finite (a NaN stays a NaN). The residual is
+  // formed as -(b q - a) instead of (a - b q) -- the same value, both negations are operand modifiers -- so that a
+  // zero numerator keeps its sign through the refinement: (-0) / b = -0, as IEEE and the fixup give it
+  // ((+0) + (-0) = +0 would turn it into +0). One instruction less per division on the step's dependent chains.
+  static __device__ __forceinline__ double div_r_pos(double a, double b, double r) {
+    double q = a * r;
+    const double e = __builtin_fma(b, q, -a);
+    return __builtin_fma(-e, r, q);
+  }
+  static __device__ __forceinline__ double div_pos(double a, double b) { return div_r_pos(a, b, rcp_refined(b)); }
+  static __device__ __forceinline__ double div_n_pos(double x, double s, double rs) { return div_r_pos(x, s, rs); }
+  static __device__ __forceinline__ V3 div3_n_pos(V3 a, double s, double rs) {
+    return mk(div_r_pos(a.x, s, rs), div_r_pos(a.y, s, rs), div_r_pos(a.z, s, rs));
+  }
   static __device__ __forceinline__ V3 div3(V3 a, double s) {
     const double r = rcp_refined(s);
     return mk(div_r(a.x, s, r), div_r(a.y, s, r), div_r(a.z, s, r));
@@ -158,11 +178,13 @@ template <> struct Mth<MATH_XACT> {
     double z = sqn(a);
     s = sqrt(z);
     const double rs = rcp_refined(s);
+    // (fixup-free divisions: the quotient is only used when squaredNorm > 0 -- then s is a positive normal and
+    // |a_i| <= s -- or the divisor is the exact 1.0)
     if (TP) {
       const bool pos = z > 0.0;
-      u = div3_n(a, pos ? s : 1.0, pos ? rs : 1.0);
+      u = div3_n_pos(a, pos ? s : 1.0, pos ? rs : 1.0);
     } else {
-      V3 q = div3_n(a, s, rs);
+      V3 q = div3_n_pos(a, s, rs);
       u = (z > 0.0) ? q : a;
     }
   }
@@ -197,6 +219,9 @@ template <> struct Mth<MATH_FAST> {
   static __device__ __forceinline__ void norm_rcp(V3 a, double &s, double &rs) { sqrt_rsqrt(sqn(a), s, rs); }
   static __device__ __forceinline__ double div_n(double x, double, double rs) { return x * rs; }
   static __device__ __forceinline__ V3 div3_n(V3 a, double, double rs) { return a * rs; }
+  static __device__ __forceinline__ double div_pos(double a, double b) { return a * rcp(b); }
+  static __device__ __forceinline__ double div_n_pos(double x, double, double rs) { return x * rs; }
+  static __device__ __forceinline__ V3 div3_n_pos(V3 a, double, double rs) { return a * rs; }
   template <bool TP = false>
   static __device__ __forceinline__ void norm_unit(V3 a, double &s, V3 &u) {
     double y;
@@ -250,7 +275,7 @@ __device__ __forceinline__ double portable_exp(double x, const ExpK &K) {
   const double r = hi - lo;
   const double r2 = r * r;
   const double c = r - r2 * (K.P1 + r2 * (K.P2 + r2 * (K.P3 + r2 * (K.P4 + r2 * K.P5))));
-  const double y = 1.0 - ((lo - Mth<MATH>::div(r * c, 2.0 - c)) - hi);
+  const double y = 1.0 - ((lo - Mth<MATH>::div_pos(r * c, 2.0 - c)) - hi);  // |r| <= 0.35: 2 - c >= 1.6
   const double res = y * __longlong_as_double((long long)(1023 + k) << 52);
   const double special = big ? ((x > 0) ? __builtin_huge_val() : 0.0) : (1.0 + x);
   return (big || tiny) ? special : res;

@@ -1476,7 +1476,7 @@ int pmaf_reset_kernel_stats(pmaf_planner *h) {
 }
 int pmaf_debug_math(int32_t op, int32_t n, const double *a, const double *b, double *out) {
   return guarded([&] {
-    REQUIRE(a && b && out && n > 0 && op >= 0 && op <= 10, "pmaf_debug_math: bad argument");
+    REQUIRE(a && b && out && n > 0 && op >= 0 && op <= 12, "pmaf_debug_math: bad argument");
     double *da = nullptr, *db = nullptr, *dout = nullptr;
     HIP_CHECK(hipMalloc((void **)&da, sizeof(double) * n));
     HIP_CHECK(hipMalloc((void **)&db, sizeof(double) * n));

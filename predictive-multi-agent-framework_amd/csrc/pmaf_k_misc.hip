@@ -490,6 +490,8 @@ __global__ void k_debug_math(int op, int n, const double *a, const double *b, do
     case 8: { V3 q = mk(a[i], b[i], a[i] * 0.5) / (b[i] + a[i]); r = (q.x + q.y) + q.z; } break;
     case 9: { double sq = Mth<MATH_XACT>::sqrt(b[i]); r = Mth<MATH_XACT>::div_r(a[i], sq, Mth<MATH_XACT>::rcp_refined(sq)); } break;  // a / sqrt(b)
     case 10: r = a[i] / __builtin_sqrt(b[i]); break;
+    case 11: r = Mth<MATH_XACT>::div_pos(a[i], b[i]); break;                      // fixup-free a / b, b > 0 normal
+    case 12: { double sq = Mth<MATH_XACT>::sqrt(b[i]); r = Mth<MATH_XACT>::div_r_pos(a[i], sq, Mth<MATH_XACT>::rcp_refined(sq)); } break;  // a / sqrt(b)
   }
   out[i] = r;
 }

@@ -181,7 +181,9 @@ __device__ __forceinline__ void rollout_w64_body(const DevView &D, const CostPar
       num.x = (l_nv || l_des) ? C.vel_max : vec.x;
       double s, rs;
       MT::norm_rcp(vec, s, rs);
-      const V3 q = MT::div3_n(num, s, rs);
+      // (y and z: direction components only, behind the squaredNorm > 0 select; x also carries the riders'
+      // vel_max / |.| quotients, whose IEEE value for a zero norm the fixup supplies)
+      const V3 q = mk(MT::div_n(num.x, s, rs), MT::div_n_pos(num.y, s, rs), MT::div_n_pos(num.z, s, rs));
       const V3 u = (sqn(vec) > 0.0) ? q : vec;  // normalized(): the vector itself unless squaredNorm > 0
       if (PRE) { s_pre = s; ron_pre = u; }
       const double vn = readlane_d(s, 62), f_nv = readlane_d(q.x, 62), f_des = readlane_d(q.x, 61);

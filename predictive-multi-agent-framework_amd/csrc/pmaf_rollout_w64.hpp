@@ -89,7 +89,7 @@ __device__ __forceinline__ void finish_step_w64(V3 p, V3 &v, V3 verr, V3 F, doub
   V3 nv = v + acc * C.dt;
   double vn, rvn;
   Mth<MATH>::norm_rcp(nv, vn, rvn);
-  const double f = Mth<MATH>::div_n(C.vel_max, vn, rvn);
+  const double f = Mth<MATH>::div_n_pos(C.vel_max, vn, rvn);  // only used when vn > vel_max
   const V3 cl = nv * f;
   v = (vn > C.vel_max) ? cl : nv;
 }
@@ -338,12 +338,12 @@ __device__ __forceinline__ void circ_and_scale_w64(int lane, V3 p, V3 v, double 
     const V3 rv = rv_t[t];
     double vn, rvn;
     MT::norm_rcp(rv, vn, rvn);
-    const V3 nv = MT::div3_n(rv, vn, rvn);
+    const V3 nv = MT::div3_n_pos(rv, vn, rvn);  // only used when vn != 0 (has_c below)
     const V3 cur = current_vector<MATH>(type, rv, g, ron_t[t], rot);
 #ifdef PMAF_ABL_NOCIRC   // timing experiments only (tools/ablate.sh): no circular-term arithmetic, list traffic kept
     const V3 c = rv; (void)nv; (void)cur; (void)rot;
 #else
-    const V3 c = MT::div(k_circ, d_t[t] * d_t[t]) * cross(nv, cross(cur, nv));
+    const V3 c = MT::div_pos(k_circ, d_t[t] * d_t[t]) * cross(nv, cross(cur, nv));  // d >= 1e-5
 #endif
     const bool has_c = in_t[t] && (vn != 0);
     // compact the contributing terms, ascending obstacle index
@@ -388,7 +388,8 @@ __device__ __forceinline__ void circ_and_scale_w64(int lane, V3 p, V3 v, double 
       bi = wave_min64_i(cand ? best_i : 0x7fffffff);
     }
     const bool stall = (dot(g, v) <= 0.0) && (zv < C.zv09_lt) && (dg > 0.15);  // norm(v) < vmax - 0.1 vmax
-    const double w1 = 1 - portable_exp<MATH>(-MT::div(MT::sqrt(m), C.shell), EK);
+    // (shell == 0: nothing is ever inside it, bi stays "none" and w is discarded)
+    const double w1 = 1 - portable_exp<MATH>(-MT::div_pos(MT::sqrt(m), C.shell), EK);
     // |ro| and g.ro of the closest obstacle were computed by the lane that
     // owns it (same operands, same bits as recomputing them here)
     const int bl = bi & 63;

@@ -597,6 +597,26 @@ def test_xact_sequences_match_ieee(pmaf):
             r0 = base * (1.0 + kk * 2.0 ** -52)
             for zN in (r0 * r0, np.nextafter(r0 * r0, np.inf), np.nextafter(r0 * r0, 0.0), r0):
                 assert (pmaf.debug_math(5, zN) == np.sqrt(zN)).all()
+        # the fixup-free variants (ops 11 / 12: divisor a positive normal -- a norm behind a squaredNorm > 0
+        # select, a clamped squared distance): same bits as IEEE incl. the sign of a zero numerator
+        pb = np.abs(b)
+        for (x, y) in ((a, pb), (wa, np.abs(wb)), (np.where(rng.uniform(size=n) < 0.01, -0.0, a), pb)):
+            got = pmaf.debug_math(11, x, y)
+            assert (got == x / y).all() and (np.signbit(got) == np.signbit(x / y)).all()
+            got = pmaf.debug_math(12, x, y)
+            assert (got == x / np.sqrt(y)).all() and (np.signbit(got) == np.signbit(x / np.sqrt(y))).all()
+        zz = np.array([0.0, -0.0, 1.0, -1.0, 2.0 ** -300, -(2.0 ** -300)])
+        for y in (1.0, 2.0 ** -200, 3.7, 2.0 ** 200):
+            got = pmaf.debug_math(11, zz, np.full_like(zz, y))
+            assert (got == zz / y).all() and (np.signbit(got) == np.signbit(zz / y)).all()
+        assert (pmaf.debug_math(12, v[:, 1], z) == v[:, 1] / np.sqrt(z)).all()
+        for base in (1.0, 0.5, 2.0):
+            sN = base * (1.0 + k * 2.0 ** -53)
+            for num in (2.0 ** -55, 3.0 * 2.0 ** -55, 1.0, 0.3, 1.0 + 2.0 ** -52, -(2.0 ** -55), -0.7):
+                aN = np.full_like(sN, num)
+                assert (pmaf.debug_math(11, aN, sN) == aN / sN).all()
+                assert (pmaf.debug_math(12, aN, sN * sN) == aN / np.sqrt(sN * sN)).all()
+        assert np.isnan(pmaf.debug_math(11, np.array([np.nan]), np.array([2.0]))).all()
         special = np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 1.0, -1.0, 3.0, 2.0 ** -250, 2.0 ** 250, -7.5])
         A, B = [x.ravel() for x in np.meshgrid(special, special)]
         for op, ref in ((5, np.sqrt(A)), (6, A / B), (9, A / np.sqrt(B))):

@@ -79,7 +79,6 @@ struct pmaf_planner {
   struct Exchange {
     pmaf_comm *c = nullptr;
     hipStream_t xs = nullptr;          // exchange stream: pack + all-gather overlap the next rollout
-    hipEvent_t ev_sel = nullptr;       // selection (k_manager) done on the handle's stream
     hipEvent_t ev_pack = nullptr;      // k_winner_path has read the scored paths
     hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;  // around ncclAllGather (timing)
     hipEvent_t ev_done = nullptr;      // table on the host
@@ -242,8 +241,7 @@ static void launch_rollout(pmaf_planner *h) {
     e0 = h->ev_free.back().first;
     e1 = h->ev_free.back().second;
     h->ev_free.pop_back();
-    h->ev_inflight.emplace_back(e0, e1);
-    HIP_CHECK(hipEventRecord(e0, h->stream));
+    h->ev_inflight.emplace_back(e0, e1);   // both events ride on the rollout kernel's own dispatch (no marker packets)
   }
   // with a communicator attached the rollout writes the OTHER path buffer: the exchange of the selection just made
   // may still be packing the path it scored (the getters follow D.paths)
@@ -255,16 +253,15 @@ static void launch_rollout(pmaf_planner *h) {
   if (h->lpa == 64 && tiles64 <= 4 && !h->force_generic)
     // ordered force sum: DPP chain from ~20 field obstacles up (lists long enough to need several LDS round trips),
     // LDS batches below (pmaf_rollout_w64.hpp, tools/msweep.py)
-    ok = pmaf_k_launch_w64(h->D, h->cp, tiles64, h->math, h->dpp_sum, h->lds_rollout, h->stream);
+    ok = pmaf_k_launch_w64(h->D, h->cp, tiles64, h->math, h->dpp_sum, h->lds_rollout, h->stream, e0, e1);
   else if (!h->force_generic && (h->lpa == 32 || h->lpa == 16 || h->lpa == 8) && (M + h->lpa - 1) / h->lpa <= 4)
     // (the opt-in fast arithmetic exists for the w64 kernels only)
     ok = pmaf_k_launch_grp(h->D, h->cp, h->lpa, (M + h->lpa - 1) / h->lpa, h->math == MATH_IEEE ? MATH_IEEE : MATH_XACT,
-                           h->n_blocks, h->lds_rollout, h->stream);
+                           h->n_blocks, h->lds_rollout, h->stream, e0, e1);
   else
-    ok = pmaf_k_launch_generic(h->D, h->cp, h->lpa, h->n_blocks, h->lds_rollout, h->stream);
+    ok = pmaf_k_launch_generic(h->D, h->cp, h->lpa, h->n_blocks, h->lds_rollout, h->stream, e0, e1);
   if (!ok) fail(PMAF_ERR_INVALID, "bad lanes_per_agent");
   HIP_CHECK(hipGetLastError());
-  if (h->profiling) HIP_CHECK(hipEventRecord(e1, h->stream));
   h->launches++;
   h->paths_gen++;
   h->scores_valid = true;
@@ -321,11 +318,11 @@ static const double *stage_live_obstacles_zero_copy(pmaf_planner *h, const doubl
   return h->d_zc;
 }
 
-static void launch_manager(pmaf_planner *h, const ManagerArgs &A0) {
+static void launch_manager(pmaf_planner *h, const ManagerArgs &A0, hipEvent_t done = nullptr) {
   ManagerArgs A = A0;
   if (A.do_reset) h->paths_gen++;
   A.tuned_real_step = (h->math == MATH_XACT && !h->force_generic) ? 1 : 0;
-  pmaf_k_launch_manager(h->D, h->cp, A, h->lds_manager, h->stream);
+  pmaf_k_launch_manager(h->D, h->cp, A, h->lds_manager, h->stream, done);
   HIP_CHECK(hipGetLastError());
 }
 
@@ -381,7 +378,19 @@ static size_t winner_rec(const pmaf_planner *h) { return PMAF_WINNER_HDR + (size
 static void finish_exchange(pmaf_planner *h) {
   pmaf_planner::Exchange &x = h->x;
   if (!x.inflight) return;
-  HIP_CHECK(hipEventSynchronize(x.ev_done));
+  {
+    // normally long through; poll instead of a blocking wait (whose wake-up latency would land on the next tick's
+    // enqueue when the exchange is still in flight)
+    hipError_t e;
+    unsigned spins = 0;
+    while ((e = hipEventQuery(x.ev_done)) == hipErrorNotReady) {
+#if defined(__x86_64__) || defined(__i386__)
+      __builtin_ia32_pause();
+#endif
+      if ((++spins & 0xfffffu) == 0) std::this_thread::yield();
+    }
+    if (e != hipSuccess) throw HipError{e, "hipEventQuery (winner exchange)", __LINE__};
+  }
   const size_t n_local = (size_t)h->D.P * winner_rec(h);
   if (x.c->rccl) {
     float ms = 0.f;
@@ -399,13 +408,15 @@ static void finish_exchange(pmaf_planner *h) {
   x.inflight = false;
 }
 
-// after k_manager (which wrote the record headers into d_send) has been enqueued on the handle's stream: pack the
-// selected agents' paths out of `scored_paths` and all-gather the records, all on the exchange stream
+// pack the selected agents' paths out of `scored_paths` behind the headers k_manager wrote into d_send and all-gather
+// the records, all on the exchange stream
+// Called once the HOST knows that k_manager has written the record headers (pmaf_tick: the mailbox's sequence number
+// has arrived, and the headers are stored before it behind a system-scope fence; pmaf_evaluate: the stream is
+// synchronised): the exchange stream then needs no event from the handle's stream -- a cross-stream event between
+// the manager and the rollout cost 4-7 us per tick (measured), this costs the rollout nothing.
 static void begin_exchange(pmaf_planner *h, const double *scored_paths) {
   pmaf_planner::Exchange &x = h->x;
   const size_t n_local = (size_t)h->D.P * winner_rec(h);
-  HIP_CHECK(hipEventRecord(x.ev_sel, h->stream));
-  HIP_CHECK(hipStreamWaitEvent(x.xs, x.ev_sel, 0));
   pmaf_k_launch_winner_path(h->D, scored_paths, x.d_send, x.xs);
   HIP_CHECK(hipGetLastError());
   HIP_CHECK(hipEventRecord(x.ev_pack, x.xs));
@@ -441,7 +452,7 @@ static void detach_comm(pmaf_planner *h) {
   if (x.d_recv) (void)hipFree(x.d_recv);
   if (x.h_send) (void)hipHostFree(x.h_send);
   if (x.h_recv) (void)hipHostFree(x.h_recv);
-  for (hipEvent_t e : {x.ev_sel, x.ev_pack, x.ev_t0, x.ev_t1, x.ev_done}) if (e) (void)hipEventDestroy(e);
+  for (hipEvent_t e : {x.ev_pack, x.ev_t0, x.ev_t1, x.ev_done}) if (e) (void)hipEventDestroy(e);
   if (x.xs) (void)hipStreamDestroy(x.xs);
   x = pmaf_planner::Exchange{};
 }
@@ -787,8 +798,8 @@ int pmaf_evaluate(pmaf_planner *h, const double *cost_gains, const double *ws, i
       A.winner_stride = (int)winner_rec(h);
     }
     launch_manager(h, A);
-    if (h->x.c) begin_exchange(h, h->D.paths);
     HIP_CHECK(hipStreamSynchronize(h->stream));
+    if (h->x.c) begin_exchange(h, h->D.paths);
     if (!h->ev_inflight.empty()) drain_events(h, true);
     refresh_real_cache(h);
     if (best_idx)
@@ -867,13 +878,14 @@ int pmaf_tick(pmaf_planner *h, const double *obstacles, double dt, const double 
       A.winner_stride = (int)winner_rec(h);
     }
     launch_manager(h, A);
-    if (h->x.c) begin_exchange(h, h->D.paths);  // the paths this selection scored; the rollout below writes the other buffer
+    const double *scored = h->D.paths;  // the paths this selection scored; the rollout below writes the other buffer
     h->rollout_pending = true;
     h->stepped = false;
     launch_rollout(h);
     // outputs of k_manager land in mapped pinned memory; wait for them only
     // (no event between the two launches: the host polls the sequence number)
     wait_mailbox(h, A.seq);
+    if (h->x.c) begin_exchange(h, scored);  // pack + all-gather on the exchange stream, beside the rollout
     refresh_real_cache(h);
     append_real_path(h);
     for (int p = 0; p < h->D.P; p++) {
@@ -1277,8 +1289,14 @@ int pmaf_attach_comm(pmaf_planner *h, pmaf_comm *c) {
     const size_t n_local = (size_t)h->D.P * winner_rec(h);
     const size_t path_bytes = sizeof(double) * (size_t)h->D.P * h->D.N * h->D.cap * 3;
     try {
-      HIP_CHECK(hipStreamCreateWithFlags(&x.xs, hipStreamNonBlocking));
-      HIP_CHECK(hipEventCreateWithFlags(&x.ev_sel, hipEventDisableTiming));
+      {
+        // a high-priority stream: its own hardware queue, so the pack kernel and the all-gather are dispatched beside
+        // the rollout instead of queueing with it (streams of equal priority may share a hardware queue: measured
+        // +48 us per C2 tick with the exchange on a default-priority stream)
+        int lo = 0, hi = 0;
+        HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        HIP_CHECK(hipStreamCreateWithPriority(&x.xs, hipStreamNonBlocking, hi));
+      }
       HIP_CHECK(hipEventCreateWithFlags(&x.ev_pack, hipEventDisableTiming));
       HIP_CHECK(hipEventCreate(&x.ev_t0));
       HIP_CHECK(hipEventCreate(&x.ev_t1));

@@ -1,6 +1,7 @@
 // pmaf_k_grp.hip -- k_rollout_grp<LPA, TILES, MATH>: 8/16/32 lanes per agent (throughput shape: C5) and its launcher.
 // Compiled once per arithmetic policy (-DPMAF_GRP_MATH=0|2; the opt-in fast arithmetic exists for the w64 kernels only).
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include "pmaf_types.hpp"
 #include "pmaf_device.hpp"
@@ -172,9 +173,9 @@ __global__ __launch_bounds__(64) void k_rollout_grp(DevView D, CostParams CP) {
 #define PMAF_CAT2(a, b) a##b
 #define PMAF_CAT(a, b) PMAF_CAT2(a, b)
 bool PMAF_CAT(pmaf_k_launch_grp_m, PMAF_GRP_MATH)(const DevView &D, const CostParams &cp, int lpa, int tiles,
-                                                  int n_blocks, size_t lds, hipStream_t s) {
+                                                  int n_blocks, size_t lds, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
   const dim3 grid((unsigned)n_blocks, (unsigned)D.P), block(64);
-#define PMAF_GRP(L, T) hipLaunchKernelGGL((k_rollout_grp<L, T, PMAF_GRP_MATH>), grid, block, lds, s, D, cp)
+#define PMAF_GRP(L, T) hipExtLaunchKernelGGL((k_rollout_grp<L, T, PMAF_GRP_MATH>), grid, block, (unsigned)lds, s, e0, e1, 0, D, cp)
 #define PMAF_GRP_T(L) do { if (tiles <= 1) PMAF_GRP(L, 1); else if (tiles == 2) PMAF_GRP(L, 2); else PMAF_GRP(L, 4); } while (0)
   if (tiles > 4) return false;
   if (lpa == 32) PMAF_GRP_T(32);

@@ -8,6 +8,7 @@
 //   k_link_force    CfAgent::bodyForce (B/src/cf_agent.cpp:229-234).
 //   k_winner        packs winner records for sharded runs.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include "pmaf_types.hpp"
 #include "pmaf_device.hpp"
@@ -367,6 +368,21 @@ __global__ __launch_bounds__(64) void k_manager(DevView D, CostParams CP, Manage
     }
   }
 
+  // header of this population's winner record (sharded runs): the selection just made, with the path length the
+  // selected agent's rollout had when it was scored and the set-point the real agent moves to. Written BEFORE the
+  // mailbox's sequence number (system-scope fence below): once the host has seen that number the header is visible
+  // device-wide, and the host may enqueue the pack kernel + all-gather on another stream with no event in between
+  if (lane == 0 && A.winner_hdr && A.do_select) {
+    double *w = A.winner_hdr + (size_t)pop * A.winner_stride;
+    const size_t pb = (size_t)pop * N + best;
+    w[0] = s_cost[best];
+    w[1] = (double)best;
+    w[2] = (double)D.n_points[pb];
+    w[3] = (double)D.types[best];
+    w[4] = rp.x; w[5] = rp.y; w[6] = rp.z;
+    w[7] = norm(goal - rp);
+  }
+
   // host-visible outputs first: the caller waits for these only
   if (lane == 0 && A.out) {
     double *o = A.out + pop * 12;
@@ -379,19 +395,6 @@ __global__ __launch_bounds__(64) void k_manager(DevView D, CostParams CP, Manage
       __threadfence_system();  // entries 0..10 visible to the host before the sequence number
       *reinterpret_cast<volatile double *>(o + 11) = A.seq;
     }
-  }
-
-  // header of this population's winner record (sharded runs): the selection just made, with the path length the
-  // selected agent's rollout had when it was scored and the set-point the real agent moves to
-  if (lane == 0 && A.winner_hdr && A.do_select) {
-    double *w = A.winner_hdr + (size_t)pop * A.winner_stride;
-    const size_t pb = (size_t)pop * N + best;
-    w[0] = s_cost[best];
-    w[1] = (double)best;
-    w[2] = (double)D.n_points[pb];
-    w[3] = (double)D.types[best];
-    w[4] = rp.x; w[5] = rp.y; w[6] = rp.z;
-    w[7] = norm(goal - rp);
   }
 
   if (A.do_reset) {
@@ -667,29 +670,30 @@ __global__ void k_eval_obstacle_distance(DevView D, const double *obs, double *o
 // ---------------------------------------------------------------------------
 // launch interface (pmaf_types.hpp)
 // ---------------------------------------------------------------------------
-bool pmaf_k_launch_w64_m0(const DevView &, const CostParams &, int, bool, size_t, hipStream_t);
-bool pmaf_k_launch_w64_m1(const DevView &, const CostParams &, int, bool, size_t, hipStream_t);
-bool pmaf_k_launch_w64_m2(const DevView &, const CostParams &, int, bool, size_t, hipStream_t);
-bool pmaf_k_launch_grp_m0(const DevView &, const CostParams &, int, int, int, size_t, hipStream_t);
-bool pmaf_k_launch_grp_m2(const DevView &, const CostParams &, int, int, int, size_t, hipStream_t);
+bool pmaf_k_launch_w64_m0(const DevView &, const CostParams &, int, bool, size_t, hipStream_t, hipEvent_t, hipEvent_t);
+bool pmaf_k_launch_w64_m1(const DevView &, const CostParams &, int, bool, size_t, hipStream_t, hipEvent_t, hipEvent_t);
+bool pmaf_k_launch_w64_m2(const DevView &, const CostParams &, int, bool, size_t, hipStream_t, hipEvent_t, hipEvent_t);
+bool pmaf_k_launch_grp_m0(const DevView &, const CostParams &, int, int, int, size_t, hipStream_t, hipEvent_t, hipEvent_t);
+bool pmaf_k_launch_grp_m2(const DevView &, const CostParams &, int, int, int, size_t, hipStream_t, hipEvent_t, hipEvent_t);
 
 bool pmaf_k_launch_w64(const DevView &D, const CostParams &cp, int tiles, int math, bool dppsum, size_t lds,
-                       hipStream_t s) {
-  if (math == MATH_FAST) return pmaf_k_launch_w64_m1(D, cp, tiles, dppsum, lds, s);
-  if (math == MATH_IEEE) return pmaf_k_launch_w64_m0(D, cp, tiles, dppsum, lds, s);
-  return pmaf_k_launch_w64_m2(D, cp, tiles, dppsum, lds, s);
+                       hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
+  if (math == MATH_FAST) return pmaf_k_launch_w64_m1(D, cp, tiles, dppsum, lds, s, e0, e1);
+  if (math == MATH_IEEE) return pmaf_k_launch_w64_m0(D, cp, tiles, dppsum, lds, s, e0, e1);
+  return pmaf_k_launch_w64_m2(D, cp, tiles, dppsum, lds, s, e0, e1);
 }
 
 bool pmaf_k_launch_grp(const DevView &D, const CostParams &cp, int lpa, int tiles, int math, int n_blocks, size_t lds,
-                       hipStream_t s) {
-  if (math == MATH_IEEE) return pmaf_k_launch_grp_m0(D, cp, lpa, tiles, n_blocks, lds, s);
-  return pmaf_k_launch_grp_m2(D, cp, lpa, tiles, n_blocks, lds, s);
+                       hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
+  if (math == MATH_IEEE) return pmaf_k_launch_grp_m0(D, cp, lpa, tiles, n_blocks, lds, s, e0, e1);
+  return pmaf_k_launch_grp_m2(D, cp, lpa, tiles, n_blocks, lds, s, e0, e1);
 }
 
-bool pmaf_k_launch_generic(const DevView &D, const CostParams &cp, int lpa, int n_blocks, size_t lds, hipStream_t s) {
+bool pmaf_k_launch_generic(const DevView &D, const CostParams &cp, int lpa, int n_blocks, size_t lds, hipStream_t s,
+                           hipEvent_t e0, hipEvent_t e1) {
   const dim3 grid((unsigned)n_blocks, (unsigned)D.P), block(64);
   switch (lpa) {
-#define PMAF_CASE(L) case L: hipLaunchKernelGGL((k_rollout<L>), grid, block, lds, s, D, cp); break;
+#define PMAF_CASE(L) case L: hipExtLaunchKernelGGL((k_rollout<L>), grid, block, (unsigned)lds, s, e0, e1, 0, D, cp); break;
     PMAF_CASE(1) PMAF_CASE(2) PMAF_CASE(4) PMAF_CASE(8) PMAF_CASE(16) PMAF_CASE(32) PMAF_CASE(64)
 #undef PMAF_CASE
     default: return false;
@@ -697,8 +701,9 @@ bool pmaf_k_launch_generic(const DevView &D, const CostParams &cp, int lpa, int 
   return true;
 }
 
-void pmaf_k_launch_manager(const DevView &D, const CostParams &cp, const ManagerArgs &A, size_t lds, hipStream_t s) {
-  hipLaunchKernelGGL(k_manager, dim3((unsigned)D.P), dim3(64), lds, s, D, cp, A);
+void pmaf_k_launch_manager(const DevView &D, const CostParams &cp, const ManagerArgs &A, size_t lds, hipStream_t s,
+                           hipEvent_t done) {
+  hipExtLaunchKernelGGL(k_manager, dim3((unsigned)D.P), dim3(64), (unsigned)lds, s, nullptr, done, 0, D, cp, A);
 }
 
 void pmaf_k_launch_score(const DevView &D, const CostParams &cp, hipStream_t s) {

@@ -2,6 +2,7 @@
 // launcher. Compiled once per arithmetic policy (-DPMAF_W64_MATH=0|1|2, csrc/build.sh) so the three policies build in
 // parallel; each object defines pmaf_k_launch_w64_m<policy>, pmaf_k_launch_w64 (pmaf_k_misc.hip) dispatches.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include "pmaf_types.hpp"
 #include "pmaf_device.hpp"
@@ -300,13 +301,15 @@ __global__ __launch_bounds__(64) void k_rollout_w64(DevView D, CostParams CP) {
 #define PMAF_CAT2(a, b) a##b
 #define PMAF_CAT(a, b) PMAF_CAT2(a, b)
 bool PMAF_CAT(pmaf_k_launch_w64_m, PMAF_W64_MATH)(const DevView &D, const CostParams &cp, int tiles, bool dppsum,
-                                                  size_t lds, hipStream_t s) {
+                                                  size_t lds, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
   const dim3 g64((unsigned)D.N, (unsigned)D.P), block(64);
+#define PMAF_L(K) hipExtLaunchKernelGGL(K, g64, block, (unsigned)lds, s, e0, e1, 0, D, cp)
   // one slot per lane: both ordered-sum variants (the host picks by obstacle count); two / four slots: DPP only
-  if (tiles <= 1 && !dppsum) hipLaunchKernelGGL((k_rollout_w64<1, PMAF_W64_MATH, false>), g64, block, lds, s, D, cp);
-  else if (tiles <= 1) hipLaunchKernelGGL((k_rollout_w64<1, PMAF_W64_MATH, true>), g64, block, lds, s, D, cp);
-  else if (tiles == 2) hipLaunchKernelGGL((k_rollout_w64<2, PMAF_W64_MATH, true>), g64, block, lds, s, D, cp);
-  else if (tiles <= 4) hipLaunchKernelGGL((k_rollout_w64<4, PMAF_W64_MATH, true>), g64, block, lds, s, D, cp);
+  if (tiles <= 1 && !dppsum) PMAF_L((k_rollout_w64<1, PMAF_W64_MATH, false>));
+  else if (tiles <= 1) PMAF_L((k_rollout_w64<1, PMAF_W64_MATH, true>));
+  else if (tiles == 2) PMAF_L((k_rollout_w64<2, PMAF_W64_MATH, true>));
+  else if (tiles <= 4) PMAF_L((k_rollout_w64<4, PMAF_W64_MATH, true>));
   else return false;
+#undef PMAF_L
   return true;
 }

@@ -111,14 +111,19 @@ struct PlanArgs {
 // ---------------------------------------------------------------------------
 // k_rollout_w64<TILES, MATH, DPPSUM> on grid (N, P); tiles in {1,2,4}; dppsum: the ordered force sum by the DPP
 // row-broadcast chain (always for tiles >= 2) or by LDS batches. Returns false if this build holds no such variant.
+// e0 / e1 (may be NULL): HIP events attached to the kernel's own dispatch packet (hipExtLaunchKernel start / stop
+// events) -- no marker packets in the stream, so timing a launch does not put anything between two kernels
 bool pmaf_k_launch_w64(const DevView &D, const CostParams &cp, int tiles, int math, bool dppsum, size_t lds,
-                       hipStream_t s);
+                       hipStream_t s, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
 // k_rollout_grp<LPA, TILES, MATH> on grid (n_blocks, P); lpa in {8,16,32}, tiles in {1,2,4}, math XACT or IEEE
 bool pmaf_k_launch_grp(const DevView &D, const CostParams &cp, int lpa, int tiles, int math, int n_blocks, size_t lds,
-                       hipStream_t s);
+                       hipStream_t s, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
 // generic k_rollout<LPA>, any power-of-two lpa 1..64
-bool pmaf_k_launch_generic(const DevView &D, const CostParams &cp, int lpa, int n_blocks, size_t lds, hipStream_t s);
-void pmaf_k_launch_manager(const DevView &D, const CostParams &cp, const ManagerArgs &A, size_t lds, hipStream_t s);
+bool pmaf_k_launch_generic(const DevView &D, const CostParams &cp, int lpa, int n_blocks, size_t lds, hipStream_t s,
+                           hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
+// done (may be NULL): event signalled by the manager kernel's completion (the winner exchange waits for it)
+void pmaf_k_launch_manager(const DevView &D, const CostParams &cp, const ManagerArgs &A, size_t lds, hipStream_t s,
+                           hipEvent_t done = nullptr);
 void pmaf_k_launch_score(const DevView &D, const CostParams &cp, hipStream_t s);
 void pmaf_k_launch_restart_paths(const DevView &D, const double *pos, hipStream_t s);
 void pmaf_k_launch_link_force(int n, const double *link_pos, const double *k_r, const double *sent, double rad,

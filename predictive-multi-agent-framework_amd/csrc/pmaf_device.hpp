@@ -85,11 +85,14 @@ __device__ __forceinline__ double smin(double a, double b) { return (b < a) ? b 
 template <int MATH> struct Mth;
 template <> struct Mth<MATH_IEEE> {
   static __device__ __forceinline__ double sqrt(double z) { return __builtin_sqrt(z); }
+  static __device__ __forceinline__ double sqrt_pos(double z) { return __builtin_sqrt(z); }
   static __device__ __forceinline__ double div(double a, double b) { return a / b; }
   static __device__ __forceinline__ V3 div3(V3 a, double s) { return a / s; }
   static __device__ __forceinline__ double norm(V3 a) { return __builtin_sqrt(sqn(a)); }
   // s = |a| and the policy's helper value for dividing by s (unused here)
   static __device__ __forceinline__ void norm_rcp(V3 a, double &s, double &rs) { s = __builtin_sqrt(sqn(a)); rs = 0.0; }
+  // as norm_rcp for a squared norm z the caller has at hand and tests itself (s is only divided by when z != 0)
+  static __device__ __forceinline__ void norm_rcp_z(double z, double &s, double &rs) { s = __builtin_sqrt(z); rs = 0.0; }
   static __device__ __forceinline__ double div_n(double x, double s, double) { return x / s; }
   static __device__ __forceinline__ V3 div3_n(V3 a, double s, double) { return a / s; }
   // (the *_pos variants of the default policy are plain divisions here)
@@ -118,6 +121,20 @@ template <> struct Mth<MATH_XACT> {
     d = __builtin_fma(-g, g, z);
     g = __builtin_fma(d, h, g);
     return (z == 0.0 || z == __builtin_huge_val()) ? z : g;  // sqrt(+-0) = +-0, sqrt(inf) = inf
+  }
+  // sqrt(z) for a z that is known to be positive and finite, or whose root is discarded otherwise (the caller's
+  // select says so): the same iteration without the zero / infinity select (3 instructions)
+  static __device__ __forceinline__ double sqrt_pos(double z) {
+    double y = __builtin_amdgcn_rsq(z);
+    double g = z * y, h = 0.5 * y;
+    double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    h = __builtin_fma(h, r, h);
+    double d = __builtin_fma(-g, g, z);
+    g = __builtin_fma(d, h, g);
+    d = __builtin_fma(-g, g, z);
+    g = __builtin_fma(d, h, g);
+    return g;
   }
   static __device__ __forceinline__ double rcp_refined(double b) {
     double r = __builtin_amdgcn_rcp(b);
@@ -163,6 +180,9 @@ template <> struct Mth<MATH_XACT> {
   // 1 + 2^-52 are fixed points of the Newton step, it lands on the other one than v_rcp_f64 does, and the quotient
   // of a numerator on a rounding tie came out 1 ulp off (found by tools/fuzz_parity.py, now in the test suite).
   static __device__ __forceinline__ void norm_rcp(V3 a, double &s, double &rs) { s = sqrt(sqn(a)); rs = rcp_refined(s); }
+  // (with sqrt_pos here too the one-slot kernels came out slower on one box -- C2 281.7 vs 279.1 us, C3 1276 vs 1250 us:
+  // instruction scheduling, not arithmetic; measured per site with tools/ab.sh)
+  static __device__ __forceinline__ void norm_rcp_z(double z, double &s, double &rs) { s = sqrt(z); rs = rcp_refined(s); }
   static __device__ __forceinline__ double div_n(double x, double s, double rs) { return div_r(x, s, rs); }
   static __device__ __forceinline__ V3 div3_n(V3 a, double s, double rs) {
     return mk(div_r(a.x, s, rs), div_r(a.y, s, rs), div_r(a.z, s, rs));
@@ -188,8 +208,20 @@ template <> struct Mth<MATH_XACT> {
       u = (z > 0.0) ? q : a;
     }
   }
+  // normalized() alone: the norm itself is not returned, so its zero / infinity select can go -- for squaredNorm == 0
+  // the quotient is discarded (non-TP) or the divisor replaced by 1.0 (TP) before the garbage root is used
   template <bool TP = false>
-  static __device__ __forceinline__ V3 normalized(V3 a) { double s; V3 u; norm_unit<TP>(a, s, u); return u; }
+  static __device__ __forceinline__ V3 normalized(V3 a) {
+    const double z = sqn(a);
+    const double s = sqrt_pos(z);
+    if (TP) {
+      const bool pos = z > 0.0;
+      const double sd = pos ? s : 1.0;
+      return div3_n_pos(a, sd, rcp_refined(sd));
+    }
+    const V3 q = div3_n_pos(a, s, rcp_refined(s));
+    return (z > 0.0) ? q : a;
+  }
 };
 template <> struct Mth<MATH_FAST> {
   static __device__ __forceinline__ double rcp(double b) {
@@ -213,10 +245,12 @@ template <> struct Mth<MATH_FAST> {
     y = h + h;
   }
   static __device__ __forceinline__ double sqrt(double z) { double g, y; sqrt_rsqrt(z, g, y); return g; }
+  static __device__ __forceinline__ double sqrt_pos(double z) { return sqrt(z); }
   static __device__ __forceinline__ double div(double a, double b) { return a * rcp(b); }
   static __device__ __forceinline__ V3 div3(V3 a, double s) { double r = rcp(s); return a * r; }
   static __device__ __forceinline__ double norm(V3 a) { return sqrt(sqn(a)); }
   static __device__ __forceinline__ void norm_rcp(V3 a, double &s, double &rs) { sqrt_rsqrt(sqn(a), s, rs); }
+  static __device__ __forceinline__ void norm_rcp_z(double z, double &s, double &rs) { sqrt_rsqrt(z, s, rs); }
   static __device__ __forceinline__ double div_n(double x, double, double rs) { return x * rs; }
   static __device__ __forceinline__ V3 div3_n(V3 a, double, double rs) { return a * rs; }
   static __device__ __forceinline__ double div_pos(double a, double b) { return a * rcp(b); }

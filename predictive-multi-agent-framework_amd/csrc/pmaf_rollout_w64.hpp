@@ -336,16 +336,18 @@ __device__ __forceinline__ void circ_and_scale_w64(int lane, V3 p, V3 v, double 
     if (TILES > 2 && !__any(in_t[t])) continue;  // no term from this slot (wave-uniform; 2 slots: both in one block)
     const V3 rot = mk(O.rx[t], O.ry[t], O.rz[t]);
     const V3 rv = rv_t[t];
+    // |rv| is only divided by, and compared with 0: sqrt(z) != 0 <=> z != 0 (for z == 0 the term is discarded, has_c)
+    const double zrv = sqn(rv);
     double vn, rvn;
-    MT::norm_rcp(rv, vn, rvn);
-    const V3 nv = MT::div3_n_pos(rv, vn, rvn);  // only used when vn != 0 (has_c below)
+    MT::norm_rcp_z(zrv, vn, rvn);
+    const V3 nv = MT::div3_n_pos(rv, vn, rvn);
     const V3 cur = current_vector<MATH>(type, rv, g, ron_t[t], rot);
 #ifdef PMAF_ABL_NOCIRC   // timing experiments only (tools/ablate.sh): no circular-term arithmetic, list traffic kept
     const V3 c = rv; (void)nv; (void)cur; (void)rot;
 #else
     const V3 c = MT::div_pos(k_circ, d_t[t] * d_t[t]) * cross(nv, cross(cur, nv));  // d >= 1e-5
 #endif
-    const bool has_c = in_t[t] && (vn != 0);
+    const bool has_c = in_t[t] && (zrv != 0);   // vel_norm != 0, B/src/cf_agent.cpp:98
     // compact the contributing terms, ascending obstacle index
     const unsigned long long m = __ballot(has_c);
     if (DPPSUM) {
@@ -389,7 +391,7 @@ __device__ __forceinline__ void circ_and_scale_w64(int lane, V3 p, V3 v, double 
     }
     const bool stall = (dot(g, v) <= 0.0) && (zv < C.zv09_lt) && (dg > 0.15);  // norm(v) < vmax - 0.1 vmax
     // (shell == 0: nothing is ever inside it, bi stays "none" and w is discarded)
-    const double w1 = 1 - portable_exp<MATH>(-MT::div_pos(MT::sqrt(m), C.shell), EK);
+    const double w1 = 1 - portable_exp<MATH>(-MT::div_pos(MT::sqrt_pos(m), C.shell), EK);  // m >= 1e-5
     // |ro| and g.ro of the closest obstacle were computed by the lane that
     // owns it (same operands, same bits as recomputing them here)
     const int bl = bi & 63;

@@ -76,6 +76,12 @@ typedef struct pmaf_planner pmaf_planner;
  * all operands within 2^+-250, which the validated input range guarantees;
  * ~13 % slower). See csrc/pmaf_device.hpp "arithmetic policy". */
 #define PMAF_FLAG_IEEE_SEQUENCES 2
+/* pmaf_tick sleeps (20 us quanta) between its polls of the mailbox's sequence
+ * number instead of spinning: no host core is burnt while the previous rollout
+ * still runs (batch drivers issuing ticks back to back), at the price of the
+ * wake-up latency (set-point up to a quantum + scheduler latency later).
+ * Default: spin (lowest set-point latency). */
+#define PMAF_FLAG_BLOCKING_WAIT 4
 
 /*
  * Arguments of CfManager::init (B/src/cf_manager.cpp:41-124,

@@ -28,7 +28,7 @@ mkdir -p "$OBJ"
 # SIMD (<= 256 VGPRs; it sits at ~252, and one innocent-looking variant landed
 # on 268: occupancy 1, +50 % time), so tests/test_abi.py checks the record.
 KFLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -mllvm -amdgpu-sched-strategy=max-ilp \
-  -Wall -Wno-unused-function -Rpass-analysis=kernel-resource-usage ${PMAF_EXTRA_FLAGS}"
+  -Wall -Wno-unused-function -Rpass-analysis=kernel-resource-usage ${PMAF_EXTRA_FLAGS} ${PMAF_EXTRA_KFLAGS}"   # PMAF_EXTRA_KFLAGS: kernel objects only
 HFLAGS="-O2 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function -D__HIP_PLATFORM_AMD__ -I$ROCM/include ${PMAF_EXTRA_FLAGS}"
 
 DEPS_K="pmaf_types.hpp pmaf_device.hpp pmaf_rollout_w64.hpp pmaf_rollout_grp.hpp"
@@ -40,7 +40,7 @@ kcompile() {  # kcompile <object stem> <source> [defines...]
   local stale=0
   [ -f "$o" ] || stale=1
   for d in $src $DEPS_K build.sh; do [ "$d" -nt "$o" ] && stale=1; done
-  [ -n "$PMAF_EXTRA_FLAGS" ] && stale=1
+  [ -n "$PMAF_EXTRA_FLAGS$PMAF_EXTRA_KFLAGS" ] && stale=1
   [ "$stale" = 0 ] && return 0
   ( $HIPCC $KFLAGS "$@" -c "$src" -o "$o" 2> "$OBJ/$stem.log" ) &
   pids+=($!); names+=("$stem")

@@ -57,6 +57,7 @@ struct pmaf_planner {
   int lpa = 64;
   int math = MATH_XACT;        // arithmetic policy of the w64 rollout kernels (pmaf_device.hpp)
   bool force_generic = false;  // PMAF_FORCE_GENERIC=1: always use the generic k_rollout<LPA>
+  bool blocking_wait = false;  // PMAF_FLAG_BLOCKING_WAIT: pmaf_tick sleeps on an event instead of spinning on the mailbox
   bool dpp_sum = true;         // w64 kernels: ordered force sum by the DPP chain (M > 20) or LDS batches
   int n_blocks = 0;
   size_t lds_rollout = 0, lds_manager = 0;
@@ -347,12 +348,19 @@ static void wait_mailbox(pmaf_planner *h, double seq) {
     const volatile double *s = h->h_out + p * 12 + 11;
     unsigned spins = 0;
     while (*s != seq) {
+      if (h->blocking_wait) {
+        // PMAF_FLAG_BLOCKING_WAIT: give the core away between polls (batch drivers that issue ticks back to back
+        // would otherwise spin for the rest of the previous rollout); costs up to one sleep quantum of latency
+        std::this_thread::sleep_for(std::chrono::microseconds(20));
+        spins += 0x3ff;
+      } else {
 #if defined(__x86_64__) || defined(__i386__)
-      __builtin_ia32_pause();
+        __builtin_ia32_pause();
 #else
-      std::this_thread::yield();
+        std::this_thread::yield();
 #endif
-      if ((++spins & 0x3fffu) == 0) {
+      }
+      if ((++spins & 0x3fffu) == 0 || (h->blocking_wait && (spins & 0x3fffu) < 0x400)) {
         hipError_t e = hipStreamQuery(h->stream);
         if (e == hipErrorNotReady) continue;
         if (e != hipSuccess) throw HipError{e, "hipStreamQuery (mailbox wait)", __LINE__};
@@ -529,6 +537,7 @@ int pmaf_create(const pmaf_params *prm, pmaf_planner **out) {
     D.C.zvhalf_lt = sq_ge(0.5 * prm->velocity_max);
     D.C.zv09_lt = sq_ge(prm->velocity_max - 0.1 * prm->velocity_max);
     h->math = (prm->flags & PMAF_FLAG_FAST_MATH) ? MATH_FAST : (prm->flags & PMAF_FLAG_IEEE_SEQUENCES) ? MATH_IEEE : MATH_XACT;
+    h->blocking_wait = (prm->flags & PMAF_FLAG_BLOCKING_WAIT) != 0;
     h->lpa = lp ? lp : pick_lpa(N, P, M);
     { const char *fg = getenv("PMAF_FORCE_GENERIC"); h->force_generic = fg && fg[0] == '1'; }
     { const char *ab = getenv("PMAF_ABLATE"); D.ablate = ab ? atoi(ab) : 0; }
@@ -883,7 +892,8 @@ int pmaf_tick(pmaf_planner *h, const double *obstacles, double dt, const double 
     h->stepped = false;
     launch_rollout(h);
     // outputs of k_manager land in mapped pinned memory; wait for them only
-    // (no event between the two launches: the host polls the sequence number)
+    // (no event between the two launches: the host polls the sequence number -- spinning, or with
+    // PMAF_FLAG_BLOCKING_WAIT sleeping between polls)
     wait_mailbox(h, A.seq);
     if (h->x.c) begin_exchange(h, scored);  // pack + all-gather on the exchange stream, beside the rollout
     refresh_real_cache(h);

@@ -1195,3 +1195,21 @@ def test_both_ordered_sum_variants_of_the_one_slot_kernel(pmaf, oracle, scenes, 
         sc["detect_shell_rad"] = 0.6
         hip, _ = run_both(pmaf, oracle, scenes, sc, 3)
         hip.close()
+
+
+def test_blocking_wait_flag_gives_the_same_results(pmaf, oracle, scenes):
+    """PMAF_FLAG_BLOCKING_WAIT: pmaf_tick sleeps on the manager kernel's completion
+    event instead of spinning on the mailbox -- same results, and the host is
+    mostly idle while ticks are issued back to back"""
+    import time
+    sc = scenes.config_scene("C2", scene_id=4)
+    hip, ora = make_pair(pmaf, oracle, sc, blocking_wait=True)
+    t0, c0 = time.perf_counter(), time.process_time()
+    best = [hip.tick(sc["obstacles"], sc["dt"], sc["cost_gains"], sc["ws_limits"]) for t in range(150)]
+    hip.stop()
+    wall, cpu = time.perf_counter() - t0, time.process_time() - c0
+    assert best == [ora.tick(sc["obstacles"], sc["dt"], sc["cost_gains"], sc["ws_limits"]) for t in range(150)]
+    assert_state_equal(hip, ora)
+    assert cpu < 0.7 * wall   # the spinning default burns a full core: cpu ~ wall
+    print("blocking wait: %d ticks in %.1f ms wall, %.1f ms CPU" % (150, wall * 1e3, cpu * 1e3))
+    hip.close()

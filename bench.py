@@ -411,8 +411,9 @@ def main():
                 "median": float(np.median(ag_us)) if ag_us.size else None,
                 "p99": float(np.percentile(ag_us, 99)) if ag_us.size else None,
                 "n": int(ag_us.size), "per_rank_median": per_rank_ag_us,
-                "note": "device time between the events around ncclAllGather on the exchange stream (includes the "
-                        "wait for the slowest rank); off the rollout's critical path"},
+                "note": ("device time between the events around ncclAllGather on the exchange stream (includes the "
+                         "wait for the slowest rank); off the rollout's critical path") if backend == "nccl" else
+                        "host transport: wall time of the all-gather callback (gloo), run when the table is asked for"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": kernel_name,

@@ -230,6 +230,9 @@ __device__ __forceinline__ void real_step_w64(const DevView &D, const double dt_
 // obstacles inside the real agent's shell.
 __global__ __launch_bounds__(64) void k_manager(DevView D, CostParams CP, ManagerArgs A) {
   extern __shared__ double smem[];
+#ifdef PMAF_TICK_STAMPS
+  const unsigned long long t_mgr0 = wall_clock64();
+#endif
   const int lane = threadIdx.x;
   const int pop = blockIdx.x;
   const int n_obs = D.n_obs;
@@ -438,6 +441,9 @@ __global__ __launch_bounds__(64) void k_manager(DevView D, CostParams CP, Manage
       D.start_vel[pop * 3] = sv.x; D.start_vel[pop * 3 + 1] = sv.y; D.start_vel[pop * 3 + 2] = sv.z;
     }
   }
+#ifdef PMAF_TICK_STAMPS
+  if (lane == 0 && pop == 0) printf("M %llu %llu\n", t_mgr0, wall_clock64());
+#endif
 }
 
 // CfAgent::setPosition for every predicted agent (clear + push_back,

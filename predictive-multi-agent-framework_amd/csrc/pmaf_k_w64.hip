@@ -227,6 +227,9 @@ __device__ __forceinline__ void rollout_w64_body(const DevView &D, const CostPar
 #else
   path_cost_terms_w64<MATH>(lane, path, n, CP.ws, CP.k_workspace, clist, cost_ws, path_len);
 #endif
+#ifdef PMAF_TICK_STAMPS   // absolute device wall clock (100 MHz) of every wave's start / end: where a tick's time goes
+  if (lane == 0 && pop == 0) printf("R %d %llu %llu\n", a, t_begin, wall_clock64());
+#endif
 #ifdef PMAF_SECTION_TIMERS
   if (lane == 0 && pop == 0 && a < 7)
     printf("agent %d: loop %llu0 ns, path-cost pass %llu0 ns (%d points)\n", a, t_loop_end - t_begin, wall_clock64() - t_loop_end, n);

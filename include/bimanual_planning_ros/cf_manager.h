@@ -73,6 +73,7 @@ class CfManager {
   // converted paths are kept until a call that changes them
   std::vector<std::vector<Vector3d>> paths_cache_;
   bool paths_cached_ = false;
+  pmaf_comm *comm_ = nullptr;             // attached communicator (not owned)
   void touch() { paths_cached_ = false; }
 
   static void check(int rc, const char *what) {
@@ -133,7 +134,7 @@ class CfManager {
       random_vecs_ = std::move(o.random_vecs_);
       best_id_ = o.best_id_; best_type_ = o.best_type_;
       best_rand_ = std::move(o.best_rand_);
-      seed_ = o.seed_; device_ = o.device_;
+      seed_ = o.seed_; device_ = o.device_; comm_ = o.comm_;
       paths_cache_ = std::move(o.paths_cache_);
       paths_cached_ = o.paths_cached_; o.paths_cached_ = false;
       random_vecs_override_ = std::move(o.random_vecs_override_);
@@ -147,6 +148,24 @@ class CfManager {
   // explicit Random-agent vectors [N][n_obs][3] for the next init()
   void setRandomVectors(const std::vector<double> &v) { random_vecs_override_ = v; }
   pmaf_planner *handle() { return h_; }
+  // Sharded runs (one process per GPU): from now on every evaluateAgents / planTick all-gathers this
+  // manager's winner record with the other ranks' (ncclAllGather enqueued by the library beside the next rollout).
+  // The communicator (pmaf_comm_init_rccl / pmaf_comm_from_rccl / pmaf_comm_init_host) must outlive the manager or be
+  // detached with attachCommunicator(nullptr); a later init() keeps it attached.
+  void attachCommunicator(pmaf_comm *comm) {
+    comm_ = comm;
+    if (h_) check(pmaf_attach_comm(h_, comm), "attachCommunicator");
+  }
+  // Winner records of ALL ranks after the last evaluateAgents / planTick: [world][8 + 3 max_prediction_steps] doubles
+  // = cost, agent index, n_points, agent type, next set-point[3], goal distance, the winning path (zero-padded)
+  std::vector<double> gatherWinners() {
+    require();
+    const double *t = nullptr;
+    size_t n = 0;
+    check(pmaf_winners_wait(h_, &t, &n), "gatherWinners");
+    return std::vector<double>(t, t + n);
+  }
+  size_t winnerRecordDoubles() const { return h_ ? pmaf_winner_record_doubles(h_) : 0; }
 
   // CfManager::init, B/src/cf_manager.cpp:41-124
   void init(const Vector3d goal_pos, const double delta_t, const std::vector<Obstacle> &obstacles,
@@ -214,6 +233,7 @@ class CfManager {
       const int32_t id = best_id_, type = best_type_;
       check(pmaf_set_best(h_, &id, &type, best_rand_.data()), "CfManager::init(best)");
     }
+    if (comm_) check(pmaf_attach_comm(h_, comm_), "CfManager::init(communicator)");
   }
 
   void startPrediction() { require(); touch(); check(pmaf_start(h_), "startPrediction"); }   // cf_manager.h:57-61

@@ -40,6 +40,11 @@ int main(int argc, char **argv) {
   for (int i = 0; i < 6; ++i) ws(i) = wsv[i];
 
   const bool viz = argc > 5 && !strcmp(argv[5], "viz");
+  // `comm`: a one-rank RCCL communicator created through the C-ABI is attached to the manager; after every
+  // evaluateAgents the gathered winner record must hold the best agent's index and the path that was scored
+  const bool with_comm = argc > 5 && !strcmp(argv[5], "comm");
+  pmaf_comm *comm = nullptr;
+  long comm_checked = 0;
   CfManager moved_from;
   moved_from.setInitialPosition(start);   // planCallback while planning is not active
   CfManager cf_manager_ = std::move(moved_from);   // cf_manager.h:53 (move construction keeps the state)
@@ -49,6 +54,14 @@ int main(int argc, char **argv) {
     cf_manager_ = std::move(tmp);
   }
   cf_manager_.setRandomVectors(rv);
+  if (with_comm) {
+    unsigned char id[PMAF_COMM_ID_BYTES];
+    if (pmaf_comm_unique_id(id) != PMAF_OK || pmaf_comm_init_rccl(1, 0, id, -1, &comm) != PMAF_OK) {
+      fprintf(stderr, "communicator: %s\n", pmaf_last_error());
+      return 4;
+    }
+    cf_manager_.attachCommunicator(comm);   // before init(): the attachment survives (re-)initialisation
+  }
   auto do_init = [&] {
     cf_manager_.init(goal, dt, obstacles, std::vector<double>(N, 4.0), std::vector<double>(N, 0.025),
                      std::vector<double>(N, 0.08), std::vector<double>(N, 3.0), std::vector<double>(N, 0.0),
@@ -69,7 +82,18 @@ int main(int argc, char **argv) {
     const bool with_viz = viz && (t % 2 == 0);
     const auto t0 = std::chrono::steady_clock::now();
     cf_manager_.stopPrediction();
+    std::vector<std::vector<Vector3d>> scored;
+    if (with_comm) scored = cf_manager_.getPredictedPaths();   // the paths this evaluation scores
     int best = cf_manager_.evaluateAgents(obstacles, 100.0, 10.0, 0.001, 1.0, ws);
+    if (with_comm) {
+      const std::vector<double> w = cf_manager_.gatherWinners();
+      const size_t rec = cf_manager_.winnerRecordDoubles();
+      bool ok = w.size() == rec && (int)w[1] == best && (size_t)w[2] == scored[best].size();
+      for (size_t k = 0; ok && k < scored[best].size(); ++k)
+        ok = w[8 + 3 * k] == scored[best][k].x() && w[8 + 3 * k + 1] == scored[best][k].y() && w[8 + 3 * k + 2] == scored[best][k].z();
+      if (!ok) { fprintf(stderr, "winner record mismatch at tick %d\n", t); return 5; }
+      ++comm_checked;
+    }
     if (with_viz) {                          // :340-347, verbatim call pattern
       for (int i = 0; i < (int)cf_manager_.getPredictedPaths().size(); i++) {
         if (cf_manager_.getPredictedPaths().at(i).size() > 2) {
@@ -96,6 +120,11 @@ int main(int argc, char **argv) {
     printf("P %zu %zu %.17g %.17g %.17g %.17g\n", a, paths[a].size(), paths[a].back().x(), paths[a].back().y(),
            paths[a].back().z(), lens[a]);
   printf("T %zu\n", cf_manager_.getPlannedTrajectory().size());
+  if (with_comm) {
+    printf("W %ld\n", comm_checked);
+    cf_manager_.attachCommunicator(nullptr);
+    pmaf_comm_destroy(comm);
+  }
   if (viz && !us_viz.empty() && !us_plain.empty()) {
     std::sort(us_viz.begin(), us_viz.end());
     std::sort(us_plain.begin(), us_plain.end());

@@ -12,6 +12,39 @@ import conftest
 ROOT = conftest.ROOT
 
 
+def test_ros_message_converters_with_lookalike_structs(tmp_path):
+    """include/bimanual_planning_ros/ros_messages.h against structs shaped like the generated ROS messages
+    (Position: boost::array<double,3> data; Obstacles: vectors of Position + radius), host-only"""
+    src = r'''
+#include <array>
+#include <cstdio>
+#include <vector>
+#include "bimanual_planning_ros/ros_messages.h"
+using namespace ghostplanner::cfplanner;
+struct Position { std::array<double, 3> data; };
+struct Obstacles { std::vector<Position> pos, vel; std::vector<double> radius; };
+int main() {
+  std::vector<Obstacle> obs = {Obstacle(Vector3d(1, 2, 3), Vector3d(0.1, 0, 0), 0.2), Obstacle(Vector3d(4, 5, 6), Vector3d(0, 0.2, 0), 0.3),
+                               Obstacle(Vector3d(100, 100, 100), Vector3d(0, 0, 0), 0.1)};
+  Obstacles m = ros_msgs::toObstaclesMsg<Obstacles, Position>(obs);
+  if (m.radius.size() != 2 || m.pos[1].data[2] != 6 || m.vel[0].data[0] != 0.1) return 1;   // the last one is not streamed
+  m.pos[0].data[0] = 7.5; m.vel[1].data[1] = -0.4; m.radius[0] = 9.0;
+  ros_msgs::applyObstaclesMsg(m, obs);
+  if (obs[0].getPosition().x() != 7.5 || obs[1].getVelocity().y() != -0.4) return 2;
+  if (obs[0].getRadius() != 0.2 || obs[2].getPosition().x() != 100) return 3;              // radii and the sentinel untouched
+  Position p = ros_msgs::toPositionMsg<Position>(Vector3d(0.5, -0.25, 0.75));
+  Vector3d v = ros_msgs::toVector(p);
+  if (v.x() != 0.5 || v.y() != -0.25 || v.z() != 0.75) return 4;
+  return 0;
+}
+'''
+    exe = str(tmp_path / "rosmsg")
+    r = subprocess.run(["g++", "-std=c++17", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"), "-x", "c++", "-", "-o", exe],
+                       input=src.encode(), capture_output=True)
+    assert r.returncode == 0, r.stderr.decode()
+    assert subprocess.run([exe]).returncode == 0
+
+
 def test_facade_headers_compile_standalone():
     """host-only: the facade is plain C++17 over include/pmaf.h"""
     src = "#include \"bimanual_planning_ros/cf_manager.h\"\nint main(){ghostplanner::cfplanner::CfManager m; (void)m; return 0;}\n"
@@ -82,3 +115,18 @@ def test_node_visualisation_loop_does_not_dominate_the_tick(scenes, tmp_path, hi
     print("tick with the visualisation loop %.0f us, without %.0f us (%d path points visited)" % (with_viz, plain, visited))
     assert visited > 1000 * ticks // 2
     assert with_viz < 2.0 * plain
+
+
+@pytest.mark.gpu
+def test_facade_with_an_attached_rccl_communicator(scenes, tmp_path, hip_lib):
+    """C++ host, as INTEGRATION.md section 4 shows it: pmaf_comm_unique_id / pmaf_comm_init_rccl (one rank),
+    CfManager::attachCommunicator before init(), the node's five-call sequence; after every evaluateAgents the
+    gathered winner record holds the best index and the scored path"""
+    N, cap, ticks = 12, 151, 25
+    sc = scenes.static1_scene(N, cap - 1)
+    rvf = tmp_path / "rv.bin"
+    np.ascontiguousarray(sc["random_vecs"]).tofile(rvf)
+    exe = os.path.join(ROOT, "tests", "cpp", "facade_tick")
+    r = subprocess.run([exe, str(N), str(cap), str(ticks), str(rvf), "comm"], capture_output=True)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    assert ("W %d" % ticks) in r.stdout.decode()

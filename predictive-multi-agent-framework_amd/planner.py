@@ -488,6 +488,17 @@ class PmafComm:
         return self
 
     @classmethod
+    def from_rccl(cls, nccl_comm_ptr, device=-1):
+        """adopt an ncclComm_t the application owns (pmaf_comm_from_rccl; not destroyed with this object)"""
+        self = cls()
+        c = _V()
+        rc = self.L.pmaf_comm_from_rccl(C.c_void_p(nccl_comm_ptr), device, C.byref(c))
+        if rc != 0:
+            raise PmafError(rc, self.L.pmaf_last_error().decode())
+        self._c = c
+        return self
+
+    @classmethod
     def host(cls, world, rank, allgather):
         """allgather(send: np.ndarray[uint8]) -> np.ndarray[uint8] of world * len(send) bytes, rank-major"""
         self = cls()

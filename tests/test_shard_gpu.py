@@ -176,6 +176,45 @@ def test_step_api_exchange_after_evaluate(pmaf, scenes):
     hip.close(); comm.close()
 
 
+def test_adopting_the_applications_own_nccl_communicator(pmaf, scenes):
+    """pmaf_comm_from_rccl: the host application created its ncclComm_t itself (here: straight through librccl's C
+    API, one rank); the library adopts it, exchanges through it and does not destroy it"""
+    import ctypes as C
+    pytest.importorskip("torch")   # (its bundled librccl is the one already mapped into the process)
+    rccl = C.CDLL("librccl.so.1")
+    uid = (C.c_ubyte * 128)()
+    assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
+
+    class NcclUniqueId(C.Structure):
+        _fields_ = [("internal", C.c_ubyte * 128)]
+    comm = C.c_void_p()
+    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, NcclUniqueId, C.c_int]
+    u = NcclUniqueId()
+    C.memmove(C.byref(u), uid, 128)
+    assert rccl.ncclCommInitRank(C.byref(comm), 1, u, 0) == 0
+    pc = pmaf.PmafComm.from_rccl(comm.value, 0)
+    assert pc.world == 1 and pc.rank == 0
+    sc = scenes.synthetic_scene(16, 60, 8, 8, 1)
+    hip = pmaf.PmafPlanner(sc, device=0, mgr_init_pos=sc["start"])
+    hip.set_initial_position(sc["start"])
+    hip.attach_comm(pc)
+    for t in range(5):
+        hip.stop()
+        paths, n = hip.paths()
+        b = hip.tick(sc["obstacles"], sc["dt"], sc["cost_gains"], sc["ws_limits"])
+        rec = pmaf.shard.unpack_winner_records(hip.winners_wait()[0], sc["max_prediction_steps"])[0]
+        assert rec["index"] == b
+        np.testing.assert_array_equal(rec["path"], paths[b, :n[b]])
+    hip.attach_comm(None)
+    hip.close()
+    pc.close()
+    # still usable by its owner after the library let go of it
+    cnt = C.c_int(0)
+    assert rccl.ncclCommCount(comm, C.byref(cnt)) == 0 and cnt.value == 1
+    rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+    assert rccl.ncclCommDestroy(comm) == 0
+
+
 # ---------------------------------------------------------------------------
 # two processes on GPU 0 (host-transport communicator over gloo)
 # ---------------------------------------------------------------------------

@@ -475,7 +475,7 @@ static int guarded(F &&f) {
     return e.code;
   } catch (const HipError &e) {
     char buf[512];
-    snprintf(buf, sizeof(buf), "HIP error %d (%s) at %s [pmaf_hip.hip:%d]", (int)e.e, hipGetErrorString(e.e), e.what, e.line);
+    snprintf(buf, sizeof(buf), "HIP error %d (%s) at %s [pmaf_host.cpp:%d]", (int)e.e, hipGetErrorString(e.e), e.what, e.line);
     g_err = buf;
     return PMAF_ERR_DEVICE;
   } catch (const std::bad_alloc &) {

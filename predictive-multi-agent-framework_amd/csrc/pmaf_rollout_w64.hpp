@@ -18,7 +18,7 @@
 //     attractorForce's speed limit) run as ONE sqrt / reciprocal / divide
 //     sequence in lanes 63 / 62 / 61; with one slot per lane the obstacle
 //     lanes compute the next step's |ro|, ro.normalized() in that sequence too
-//     (rollout_w64_body in pmaf_hip.hip);
+//     (rollout_w64_body in pmaf_k_w64.hip);
 //   * the sequential `force_ += curr_force` (cf_agent.cpp:106) is reproduced
 //     by compacting the non-zero per-obstacle terms, in ascending obstacle
 //     index, into an LDS list (v_mbcnt rank) that every lane (lane 0 alone

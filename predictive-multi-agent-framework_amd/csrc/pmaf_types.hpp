@@ -15,7 +15,7 @@ enum : int { MATH_IEEE = 0, MATH_FAST = 1, MATH_XACT = 2 };
 
 struct PopConst {
   double dt, vel_max, approach, shell, mass, rad;
-  // exact squared thresholds (computed on the host, pmaf_hip.hip:sq_gt/sq_ge):
+  // exact squared thresholds (computed on the host, pmaf_host.cpp:sq_gt/sq_ge):
   // for every z >= 0   sqrt(z) > 1e-5  <=>  z >= zf_gt
   //                    sqrt(z) > 13.0  <=>  z >= zacc_gt
   //                    sqrt(z) < 0.2   <=>  z <  zinit_lt

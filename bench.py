@@ -231,8 +231,40 @@ def main():
     # ---- the sharded runs' collective: winner records all-gathered once per tick ----
     comm = None
     exchange = (world > 1 or force_dist) and not args.no_exchange
+    transport = None
     if exchange:
-        comm = pkg.shard.make_comm(dist, world, rank, backend="rccl" if backend == "nccl" else "host", device=local_rank)
+        transport = "rccl" if backend == "nccl" else "host"
+        if transport == "rccl":
+            # the library's own RCCL communicator; should its bootstrap fail on any rank (environment), every rank
+            # falls back to the host transport over a gloo side group so that the run still measures the exchange
+            import torch
+            ok = 1
+            try:
+                if os.environ.get("PMAF_BENCH_FAIL_RCCL") == "1":   # test hook for the fallback below
+                    raise RuntimeError("PMAF_BENCH_FAIL_RCCL")
+                comm = pkg.shard.make_comm(dist, world, rank, backend="rccl", device=local_rank)
+            except Exception as e:  # noqa: BLE001
+                sys.stderr.write("rank %d: RCCL communicator failed (%s)\n" % (rank, e))
+                comm, ok = None, 0
+            flag = torch.tensor([ok], dtype=torch.int32, device=red_dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 0:
+                if comm is not None:
+                    comm.close()
+                transport = "host"
+                side = dist.new_group(backend="gloo")
+
+                class _Side:  # the few calls torch_host_allgather makes, bound to the gloo group
+                    @staticmethod
+                    def get_world_size():
+                        return world
+
+                    @staticmethod
+                    def all_gather_into_tensor(out, t):
+                        return dist.all_gather_into_tensor(out, t, group=side)
+                comm = pkg.PmafComm.host(world, rank, pkg.shard.torch_host_allgather(_Side))
+        else:
+            comm = pkg.shard.make_comm(dist, world, rank, backend="host", device=local_rank)
         planner.attach_comm(comm)
 
     tick_no = [0]
@@ -383,15 +415,16 @@ def main():
                                    "%d population(s) per GPU (%d in the job), %s obstacles, one pmaf_tick per step%s"
                                    % (workload, N, H, n_obs - 1, P, total_pops, "moving" if args.dynamic else "static",
                                       ", winner records all-gathered once per tick (%s)" %
-                                      ("RCCL" if backend == "nccl" else "host transport") if comm is not None else ""),
+                                      ("RCCL" if transport == "rccl" else "host transport") if comm is not None else ""),
                        "agents": N, "horizon": H, "obstacles": n_obs - 1, "populations_per_gpu": P,
                        "populations_total": total_pops,
                        "parallelism": "population-per-gpu x%d (%s)" % (world, "sharded scenes" if scaling == "strong" else
                                                                       "distinct scenes" if args.distinct_scenes else
                                                                       "same scene on every GPU"),
                        "collective": None if comm is None else
-                       "ncclAllGather of %d B winner records per rank per tick, second stream, overlapped with the "
-                       "rollout" % (P * (8 + 3 * (H + 1)) * 8),
+                       "%s of %d B winner records per rank per tick, second stream, overlapped with the "
+                       "rollout" % ("ncclAllGather" if transport == "rccl" else "host-transport all-gather",
+                                    P * (8 + 3 * (H + 1)) * 8),
                        "lanes_per_agent": cfg["lanes_per_agent"], "rollout_blocks": cfg["n_blocks"],
                        "arithmetic": "f64, hand-expanded IEEE div/sqrt sequences (default policy; bit-identical to "
                                      "the CPU oracle)"},
@@ -411,8 +444,9 @@ def main():
                 "median": float(np.median(ag_us)) if ag_us.size else None,
                 "p99": float(np.percentile(ag_us, 99)) if ag_us.size else None,
                 "n": int(ag_us.size), "per_rank_median": per_rank_ag_us,
+                "transport": transport,
                 "note": ("device time between the events around ncclAllGather on the exchange stream (includes the "
-                         "wait for the slowest rank); off the rollout's critical path") if backend == "nccl" else
+                         "wait for the slowest rank); off the rollout's critical path") if transport == "rccl" else
                         "host transport: wall time of the all-gather callback (gloo), run when the table is asked for"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,

@@ -430,3 +430,19 @@ def test_bench_single_rank_rccl_exchange():
     assert r.returncode == 0, r.stderr[-3000:]
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert out["allgather_us"]["n"] >= 20 and "RCCL" in out["config"]["workload"]
+
+
+@pytest.mark.timeout(600)
+def test_bench_rccl_bootstrap_failure_falls_back_to_host_transport():
+    """if the library's RCCL communicator cannot be built, every rank switches to the host transport over a gloo
+    side group and the run still measures the exchange (and says so)"""
+    import json
+    import subprocess
+    env = dict(os.environ, PMAF_BENCH_FORCE_DIST="1", PMAF_BENCH_FAIL_RCCL="1", MASTER_PORT=str(_free_port()))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "5",
+                        "--min-seconds", "0.1", "--cpu-seconds", "0", "--flop-ticks", "0"],
+                       capture_output=True, text=True, timeout=500, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["allgather_us"]["n"] >= 20 and out["allgather_us"]["transport"] == "host"
+    assert "host transport" in out["config"]["workload"]

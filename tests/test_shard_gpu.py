@@ -446,3 +446,52 @@ def test_bench_rccl_bootstrap_failure_falls_back_to_host_transport():
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert out["allgather_us"]["n"] >= 20 and out["allgather_us"]["transport"] == "host"
     assert "host transport" in out["config"]["workload"]
+
+
+@pytest.mark.timeout(600)
+def test_exchange_lifecycle_does_not_leak(pmaf, scenes):
+    """handle + communicator + attached exchange (second path buffer, record staging, exchange stream, events),
+    created and destroyed in a loop: device memory returns to where it was and every cycle gives the same table;
+    closing the handle with an exchange still in flight, and closing the communicator first, are both safe"""
+    torch = pytest.importorskip("torch")
+    scs = _scenes3(scenes)
+    starts = np.stack([s["start"] for s in scs])
+    sc = scs[0]
+    obs = np.stack([s["obstacles"] for s in scs])
+
+    def one(transport, wait):
+        hip = pmaf.PmafPlanner(scs, device=0, mgr_init_pos=starts)
+        hip.set_initial_position(starts)
+        comm = (pmaf.PmafComm.rccl(1, 0, pmaf.PmafComm.unique_id(), 0) if transport == "rccl"
+                else pmaf.PmafComm.host(1, 0, lambda b: b))
+        hip.attach_comm(comm)
+        for _ in range(4):
+            hip.tick(obs, sc["dt"], sc["cost_gains"], sc["ws_limits"])
+        tab = hip.winners_wait().copy() if wait else None   # wait=False: destroy with the exchange in flight
+        hip.paths()                                         # the pinned host mirror of the paths as well
+        hip.close()
+        comm.close()
+        return tab
+
+    ref = {t: one(t, True) for t in ("rccl", "host")}
+    np.testing.assert_array_equal(ref["rccl"], ref["host"])
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info(0)[0]
+    for i in range(12):
+        for t in ("rccl", "host"):
+            tab = one(t, i % 2 == 0)
+            if tab is not None:
+                np.testing.assert_array_equal(tab, ref[t])
+    torch.cuda.synchronize()
+    free1 = torch.cuda.mem_get_info(0)[0]
+    assert free0 - free1 < 16 << 20, (free0, free1)
+    # communicator closed before the handle it is attached to: the handle must be detached first, and says so
+    hip = pmaf.PmafPlanner(scs, device=0, mgr_init_pos=starts)
+    hip.set_initial_position(starts)
+    comm = pmaf.PmafComm.host(1, 0, lambda b: b)
+    hip.attach_comm(comm)
+    hip.tick(obs, sc["dt"], sc["cost_gains"], sc["ws_limits"])
+    hip.attach_comm(None)
+    comm.close()
+    hip.tick(obs, sc["dt"], sc["cost_gains"], sc["ws_limits"])
+    hip.close()

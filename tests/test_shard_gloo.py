@@ -1,4 +1,4 @@
-"""world_size-2 gloo tests of the multi-GPU path (population sharding + winner
+"""world_size-2 (and one world_size-4) gloo tests of the multi-GPU path (population sharding + winner
 record all-gather + agent-range merge rule). Run on CPU: the rank-local
 planner is the oracle (test-only compute stand-in for the kernels); everything
 else is the product path -- shard.py over libpmaf_hip.so's communicator entry
@@ -62,9 +62,10 @@ def _worker(rank, world, port, n_scenes, ticks, q):
 
 
 @pytest.mark.timeout(300)
-def test_population_sharding_and_winner_all_gather_world2():
+@pytest.mark.parametrize("world,n_scenes", [(2, 4), (4, 8)])
+def test_population_sharding_and_winner_all_gather(world, n_scenes):
     import torch.multiprocessing as mp
-    world, n_scenes, ticks = 2, 4, 3
+    ticks = 3
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -76,8 +77,9 @@ def test_population_sharding_and_winner_all_gather_world2():
         p.join(60)
         assert p.exitcode == 0
     # every rank ends with the same gathered table
-    np.testing.assert_array_equal(results[0], results[1])
-    # single-process reference of the same 4 populations
+    for r in range(1, world):
+        np.testing.assert_array_equal(results[0], results[r])
+    # single-process reference of the same populations
     sys.path.insert(0, ROOT)
     import __graft_entry__ as graft
     from oracle import orc

@@ -396,9 +396,11 @@ def test_agent_range_shards_two_ranks_hip_planner(pmaf, oracle, scenes):
     ([], 2),                                   # default multi-GPU workload: C2 per rank + winner all-gather
     (["--config", "C5", "--shard", "--total-populations", "4"], 2),
     (["--config", "C4"], 2),
+    ([], 4),
+    (["--config", "C5", "--shard", "--total-populations", "8"], 4),
 ])
 def test_bench_multi_rank_modes_on_one_gpu(args, n_ranks):
-    """bench.py's N > 1 workloads, run as 2 ranks sharing GPU 0 with the host
+    """bench.py's N > 1 workloads, run as 2 or 4 ranks sharing GPU 0 with the host
     transport (test hooks PMAF_BENCH_BACKEND=gloo / PMAF_BENCH_SINGLE_DEVICE=1):
     the JSON line carries the collective's timing and per-rank tick times"""
     import json

@@ -27,8 +27,9 @@ Workloads
 
 Timing: W warm-up ticks, then blocks of K ticks, each block bracketed by a
 barrier + device synchronisation on both sides; blocks are repeated until
---min-seconds have been timed and the MEDIAN block (max over ranks) is
-reported, so a short `--steps 20` run gives the stationary figure too.
+--min-seconds have been timed (and at least --min-blocks blocks) and the
+MEDIAN block (max over ranks) is reported, so a short `--steps 20` run gives
+the stationary figure too.
 
 Prints ONE JSON line on rank 0.
 """
@@ -146,6 +147,7 @@ def main():
     ap.add_argument("--dynamic", action="store_true", help="moving obstacles, re-uploaded every tick")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline time budget (0 = skip)")
     ap.add_argument("--flop-ticks", type=int, default=24, help="ticks of the instrumented-oracle flop count (0 = skip)")
+    ap.add_argument("--min-blocks", type=int, default=5, help="time at least this many blocks of --steps ticks")
     ap.add_argument("--min-seconds", type=float, default=1.0,
                     help="repeat blocks of --steps ticks until this much has been timed; the median block is reported")
     ap.add_argument("--distinct-scenes", action="store_true",
@@ -346,7 +348,9 @@ def main():
         lat.append(blk_lat)
         total_timed += el
         n_blocks += 1
-        if total_timed >= args.min_seconds or n_blocks >= max_blocks:   # same decision on every rank (el is reduced)
+        # same decision on every rank (el is reduced). At least --min-blocks blocks, so that the median is one of
+        # several blocks and a single slow block (a clock or scheduling hiccup on the box) cannot move it
+        if (total_timed >= args.min_seconds and n_blocks >= args.min_blocks) or n_blocks >= max_blocks:
             break
         sync_all()
     elapsed = float(np.median(block_s))

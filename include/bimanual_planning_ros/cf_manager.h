@@ -425,6 +425,9 @@ class CfManager {
   }
 
   // ---- synchronous stepping API (no callers in the reference; B/src/cf_manager.cpp:220-224, 238-244, 265-291) ----
+  // Deviation: after any of these calls startPrediction() needs a resetEEAgents() / setInitialPosition() first
+  // (std::runtime_error otherwise): rollouts start from the population's reset state, the reference's threads would
+  // continue with each agent's own velocity, known flags and advanced obstacle copies (pmaf.h).
   void setEEAgentPositions(const Vector3d &position) {                              // :220-224
     require();
     touch();

@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define PMAF_ABI_VERSION 2
+#define PMAF_ABI_VERSION 3
 
 typedef enum pmaf_status {
   PMAF_OK = 0,
@@ -172,10 +172,18 @@ int pmaf_move_agents(pmaf_planner *h, const double *obstacles, double dt, int32_
 int pmaf_move_agent(pmaf_planner *h, const double *obstacles, double dt, int32_t steps,
                     const int32_t *agent_id, int32_t max_calls, int32_t *calls);
 /* CfManager::setEEAgentPositions (B/src/cf_manager.cpp:220-224): every agent's
- * path restarts at pos [P][3]; velocities stay. */
+ * path restarts at pos [P][3]; velocities stay (for the stepping calls that
+ * follow). Deviation: like after pmaf_move_agent(s), pmaf_start then needs a
+ * pmaf_reset_agents / pmaf_set_initial_position first (PMAF_ERR_STATE
+ * otherwise) -- in the reference a startPrediction() here would continue with
+ * each agent's OWN velocity, known flags and advanced obstacle copies
+ * (CfAgent::setPosition only clears the path, B/src/cf_agent.cpp:39-42), which
+ * a rollout launched from the population's reset state cannot reproduce. The
+ * reference has no caller of this method. */
 int pmaf_set_agent_positions(pmaf_planner *h, const double *pos);
 /* CfManager::setEEAgentPosAndVels (B/src/cf_manager.cpp:238-244): pos, vel [P][3]
- * (velocity clamped to velocity_max, CfAgent::setVelocity). */
+ * (velocity clamped to velocity_max, CfAgent::setVelocity). Same rule for a
+ * following pmaf_start as pmaf_set_agent_positions. */
 int pmaf_set_agent_pos_and_vels(pmaf_planner *h, const double *pos, const double *vel);
 /* CfAgent::evalObstacleDistance (B/src/cf_agent.cpp:146-157) of every agent at
  * its latest position against obstacles [P][n_obstacles][7]; out [P][N]. */
@@ -305,7 +313,10 @@ int pmaf_allgather_winners(pmaf_planner *h, pmaf_comm *c, void *recv_device, siz
  * the path being sent). c = NULL detaches. The communicator must outlive the
  * attachment. */
 int pmaf_attach_comm(pmaf_planner *h, pmaf_comm *c);
-/* wait for the exchange of the last pmaf_tick / pmaf_evaluate; *records =
+/* (The handle keeps two exchange slots: a tick never waits for the collective
+ * of the tick before it, only -- when it comes to reuse that slot -- for the
+ * one two ticks back.)
+ * wait for the exchange of the last pmaf_tick / pmaf_evaluate; *records =
  * [world][P][record] doubles in pinned host memory, valid until the next
  * pmaf_tick / pmaf_evaluate; *n_doubles = world * P * record. */
 int pmaf_winners_wait(pmaf_planner *h, const double **records, size_t *n_doubles);
@@ -316,6 +327,58 @@ void *pmaf_winners_device(pmaf_planner *h);
  * the slowest rank; host communicator: wall time of the callback), oldest
  * first, at most max_n; *n = number written. Clears the record. */
 int pmaf_get_exchange_times_us(pmaf_planner *h, double *out, int32_t max_n, int32_t *n);
+
+/* ---- peer mailboxes: header-only exchange WITHOUT a collective (ABI 3) ----
+ * Where a population needs only another population's set-point of the previous
+ * tick (BASELINE config 4: each arm's trailing repulsive obstacle is the other
+ * arm's end effector, B/src/cf_agent.cpp:159-181 for the obstacle's role), a
+ * collective per tick puts a launch + rendezvous on the control path. Instead
+ * every rank owns an INBOX in its device memory that is mapped into every peer
+ * process (hipIpcGetMemHandle / hipIpcOpenMemHandle; peer GPUs reach it over
+ * xGMI). The manager kernel of pmaf_tick number t
+ *   - stores the 8-double record header of each of its populations, then the
+ *     sequence number t behind a system-scope release, straight into slot
+ *     [t & 1][rank][pop] of EVERY rank's inbox, and
+ *   - for a population coupled with pmaf_peer_couple, reads the header with
+ *     sequence number t-1 of (src_rank, src_pop) from its OWN inbox (local HBM)
+ *     and uses its position[3] as the live trailing obstacle (velocity 0, the
+ *     given radius) of this tick's real step and of the rollout it starts.
+ * No host, no stream, no collective is involved; the winner-record all-gather
+ * above stays what it was (the path table, off the control path). Every rank
+ * must issue the same number of pmaf_tick calls; the other entry points
+ * (pmaf_evaluate ...) neither publish nor consume. Not part of a checkpoint
+ * (reconnect after pmaf_load_state). No reference equivalent. */
+#define PMAF_PEER_HANDLE_BYTES 128
+/* allocate this handle's inbox for `world` ranks and export it: hand the
+ * PMAF_PEER_HANDLE_BYTES bytes of every rank to every rank (any transport) */
+int pmaf_peer_export(pmaf_planner *h, int32_t world, void *handle_out);
+/* handles = [world][PMAF_PEER_HANDLE_BYTES] in rank order (handles[rank] = this
+ * handle's own export). Handles exported by the same process are used directly
+ * (several handles of one process: one host driving several GPUs, tests), the
+ * others are opened with hipIpcOpenMemHandle. Every rank must hold the same
+ * number of populations. */
+int pmaf_peer_connect(pmaf_planner *h, int32_t world, int32_t rank, const void *handles);
+/* couple population `pop`'s trailing obstacle to the set-point of population
+ * src_pop on rank src_rank (src_rank < 0: uncouple). init_pos [3] (may be
+ * NULL) = the source's position the FIRST tick uses (only before the first
+ * pmaf_tick after pmaf_peer_connect); without it the first tick waits for a
+ * header that only a previous tick could have published. */
+int pmaf_peer_couple(pmaf_planner *h, int32_t pop, int32_t src_rank, int32_t src_pop, double radius,
+                     const double *init_pos);
+/* every rank must have stopped ticking (barrier) before ANY rank disconnects or
+ * destroys its handle: peers store into this rank's inbox */
+int pmaf_peer_disconnect(pmaf_planner *h);
+/* observability / tests: the newest header [world][P][8] and its sequence
+ * number [world][P] (-1: none yet) in this rank's inbox; a small blocking copy */
+int pmaf_peer_read(pmaf_planner *h, double *headers, double *seq);
+/* per pmaf_tick since the last call (oldest first, at most max_n; clears the
+ * record): wait_us = time the manager kernel waited for the coupled header
+ * (what the control path pays for the coupling; ~0 when the ranks keep pace),
+ * publish_us = its stores into the peers' inboxes incl. the system-scope fence
+ * (device clock) */
+int pmaf_get_peer_times_us(pmaf_planner *h, double *wait_us, double *publish_us, int32_t max_n, int32_t *n);
+/* hipGetDeviceCount (0 without a usable HIP device) */
+int pmaf_device_count(void);
 
 /* ---- checkpoint / resume (no reference equivalent: its state lives in RAM) ---- */
 /* Serialise the complete planner state of a handle (agents' rotation vectors

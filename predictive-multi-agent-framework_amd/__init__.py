@@ -14,5 +14,5 @@ seeded synthetic scenes), shard.py (population sharding across ranks: the
 orchestration over the C-ABI's communicator / winner-exchange entry points).
 """
 from . import scenes, shard  # noqa: F401
-from .planner import (LIB_PATH, SYMBOLS, PmafComm, PmafError, PmafPlanner, debug_math, load_library,  # noqa: F401
-                      select_best)  # noqa: F401
+from .planner import (LIB_PATH, SYMBOLS, PmafComm, PmafError, PmafPlanner, debug_math, device_count,  # noqa: F401
+                      load_library, select_best)  # noqa: F401

@@ -2,6 +2,7 @@
 // protocol, getters, checkpointing) over the kernels of pmaf_k_*.hip (launch interface: pmaf_types.hpp).
 // Plain C++ against the HIP runtime API; there is no CPU fallback in this library.
 #include <hip/hip_runtime_api.h>
+#include <unistd.h>
 
 #include <cmath>
 #include <cstdio>
@@ -66,7 +67,7 @@ struct pmaf_planner {
   uint64_t mailbox_seq = 0;     // sequence number of the last pmaf_tick (mailbox entry 11)
   std::vector<void *> allocs;
   std::vector<size_t> alloc_bytes;  // size of every device buffer (state save / load)
-  double *h_out = nullptr;      // pinned [P][12] mailbox written by k_manager
+  double *h_out = nullptr;      // pinned [P][PMAF_MBOX] mailbox written by k_manager
   // host copy of the real agent's state (getNextPosition / getNextVelocity /
   // getEEForce / getDistFromGoal must not wait for the running rollout)
   std::vector<double> real_pos_h, real_vel_h, real_force_h;
@@ -77,18 +78,45 @@ struct pmaf_planner {
   double *h_zc = nullptr, *d_zc = nullptr;  // mapped pinned obstacle buffer read by k_manager in pmaf_tick
   int stage_next = 0;
   // ---- winner-record exchange of sharded runs (pmaf_attach_comm) ----
+  // Two exchange slots used alternately: the selection of tick k sends from slot k & 1, so its manager kernel only has
+  // to wait for the exchange of tick k-2 (long through) -- never for the collective of the tick before, which a slower
+  // peer rank may not even have joined yet.
   struct Exchange {
     pmaf_comm *c = nullptr;
-    hipStream_t xs = nullptr;          // exchange stream: pack + all-gather overlap the next rollout
-    hipEvent_t ev_pack = nullptr;      // k_winner_path has read the scored paths
-    hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;  // around ncclAllGather (timing)
-    hipEvent_t ev_done = nullptr;      // table on the host
-    double *d_send = nullptr, *d_recv = nullptr;  // [P][rec], [world][P][rec]
-    double *h_send = nullptr, *h_recv = nullptr;  // pinned
+    hipStream_t xp = nullptr;          // pack stream: k_winner_path (local work only, never behind a collective)
+    hipStream_t xs = nullptr;          // exchange stream: all-gather + copy of the table to the host
+    struct Slot {
+      hipEvent_t ev_pack = nullptr;    // k_winner_path has read the scored paths
+      hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;  // around ncclAllGather (timing)
+      hipEvent_t ev_done = nullptr;    // table on the host
+      double *d_send = nullptr, *d_recv = nullptr;  // [P][rec], [world][P][rec]
+      double *h_send = nullptr, *h_recv = nullptr;  // pinned
+      bool inflight = false;
+      bool pack_pending = false;       // ev_pack recorded and not yet known to have completed
+    } slot[2];
+    int cur = 1;                       // slot of the last exchange begun (the next one takes cur ^ 1)
     double *paths_a = nullptr, *paths_b = nullptr;  // the two path buffers (a = the handle's original one)
-    bool inflight = false;
+    bool failed = false;               // the last exchange did not complete: pmaf_winners_wait reports it
     std::vector<double> ag_us;
+    bool any_inflight() const { return slot[0].inflight || slot[1].inflight; }
   } x;
+  // ---- peer mailboxes (pmaf_peer_*): header-only exchange without a collective ----
+  struct Peer {
+    bool on = false;
+    int world = 0, rank = 0;
+    double *inbox = nullptr;             // this rank's inbox [2][world][P][PMAF_PEER_SLOT] (device memory)
+    bool inbox_fine = false;
+    std::vector<double *> mapped;        // every rank's inbox as mapped into this process
+    std::vector<char> opened;            // 1: mapped[r] came from hipIpcOpenMemHandle
+    PeerView *d_view = nullptr;
+    int32_t *d_couple = nullptr;
+    double *d_radius = nullptr;
+    std::vector<int32_t> couple_h;
+    std::vector<double> radius_h;
+    uint64_t tick = 0;                   // pmaf_ticks since pmaf_peer_connect = sequence number last published
+    double us_per_tick = 0.01;           // wall_clock64 period
+    std::vector<double> wait_us, pub_us;
+  } peer;
   double *d_send1 = nullptr;           // send buffer of the one-shot pmaf_allgather_winners
   // host mirror of the predicted paths (pmaf_get_paths): the reference's node calls getPredictedPaths() /
   // getNumPredictionSteps(i) 3 x N times per tick (B/src/panda_bimanual_control.cpp:341-344) -- one D2H per
@@ -99,7 +127,8 @@ struct pmaf_planner {
   double *d_plan_obs = nullptr;        // [P][7][n_obs] the stepping API's obstacle list (pmaf_move_agents ...)
   double *d_plan_out = nullptr;        // [P][N] pmaf_eval_obstacle_distance
   int32_t *d_plan_calls = nullptr;     // [P]
-  bool stepped = false;                // agents were moved by the stepping API: a rollout needs a reset first
+  bool stepped = false;                // agents were moved / set by the stepping API: a rollout needs a reset first
+  double exchange_timeout_s = 60.0;    // PMAF_EXCHANGE_TIMEOUT_S: bound of the wait for a winner exchange
   double *d_link = nullptr, *h_link = nullptr;  // pmaf_link_force scratch (device / pinned host), grown on demand
   size_t link_scratch_doubles = 0;
   double *d_reset_in = nullptr; // [P][6]
@@ -273,7 +302,8 @@ static void launch_rollout(pmaf_planner *h) {
 static void sync(pmaf_planner *h) {
   HIP_CHECK(hipStreamSynchronize(h->stream));
   // an exchange in flight still reads the scored path buffer until its pack kernel is through
-  if (h->x.inflight) HIP_CHECK(hipEventSynchronize(h->x.ev_pack));
+  for (auto &sl : h->x.slot)
+    if (sl.pack_pending) { HIP_CHECK(hipEventSynchronize(sl.ev_pack)); sl.pack_pending = false; }
   if (!h->ev_inflight.empty()) drain_events(h, true);
 }
 
@@ -331,7 +361,7 @@ static void launch_manager(pmaf_planner *h, const ManagerArgs &A0, hipEvent_t do
 // k_manager launch has completed)
 static void refresh_real_cache(pmaf_planner *h) {
   for (int p = 0; p < h->D.P; p++) {
-    const double *o = h->h_out + p * 12;
+    const double *o = h->h_out + p * PMAF_MBOX;
     for (int c = 0; c < 3; c++) {
       h->real_pos_h[p * 3 + c] = o[1 + c];
       h->real_vel_h[p * 3 + c] = o[4 + c];
@@ -345,7 +375,7 @@ static void refresh_real_cache(pmaf_planner *h) {
 // launch cannot leave the host spinning.
 static void wait_mailbox(pmaf_planner *h, double seq) {
   for (int p = 0; p < h->D.P; p++) {
-    const volatile double *s = h->h_out + p * 12 + 11;
+    const volatile double *s = h->h_out + p * PMAF_MBOX + 11;
     unsigned spins = 0;
     while (*s != seq) {
       if (h->blocking_wait) {
@@ -373,7 +403,7 @@ static void wait_mailbox(pmaf_planner *h, double seq) {
 
 static void append_real_path(pmaf_planner *h) {
   for (int p = 0; p < h->D.P; p++) {
-    const double *o = h->h_out + p * 12;
+    const double *o = h->h_out + p * PMAF_MBOX;
     h->real_path[p].insert(h->real_path[p].end(), {o[1], o[2], o[3]});
   }
 }
@@ -383,86 +413,175 @@ static size_t winner_rec(const pmaf_planner *h) { return PMAF_WINNER_HDR + (size
 
 // complete the exchange in flight (if any): RCCL -- wait for the table on the host and book the all-gather's device
 // time; host transport -- wait for the packed records, then run the caller's collective here
-static void finish_exchange(pmaf_planner *h) {
+static void finish_exchange(pmaf_planner *h, int which) {
   pmaf_planner::Exchange &x = h->x;
-  if (!x.inflight) return;
+  pmaf_planner::Exchange::Slot &sl = x.slot[which];
+  if (!sl.inflight) return;
+  // Whatever happens below, this exchange is over: a failed one must not be retried by the next call (the ranks
+  // would no longer issue their collectives in the same order)
+  sl.inflight = false;
   {
     // normally long through; poll instead of a blocking wait (whose wake-up latency would land on the next tick's
-    // enqueue when the exchange is still in flight)
+    // enqueue when the exchange is still in flight). Bounded: a peer that died leaves ncclAllGather waiting for ever --
+    // after PMAF_EXCHANGE_TIMEOUT_S (default 60 s) the call fails with PMAF_ERR_DEVICE instead of spinning on
     hipError_t e;
     unsigned spins = 0;
-    while ((e = hipEventQuery(x.ev_done)) == hipErrorNotReady) {
+    std::chrono::steady_clock::time_point t_start{};
+    bool timing = false;
+    while ((e = hipEventQuery(sl.ev_done)) == hipErrorNotReady) {
 #if defined(__x86_64__) || defined(__i386__)
       __builtin_ia32_pause();
 #endif
-      if ((++spins & 0xfffffu) == 0) std::this_thread::yield();
+      if ((++spins & 0xfffffu) == 0) {
+        std::this_thread::yield();
+        const auto now = std::chrono::steady_clock::now();
+        if (!timing) { timing = true; t_start = now; }
+        else if (std::chrono::duration<double>(now - t_start).count() > h->exchange_timeout_s) {
+          x.failed = true;
+          fail(PMAF_ERR_DEVICE, "winner exchange: the all-gather did not complete within the time limit (a peer rank "
+                                "gone? PMAF_EXCHANGE_TIMEOUT_S)");
+        }
+      }
     }
-    if (e != hipSuccess) throw HipError{e, "hipEventQuery (winner exchange)", __LINE__};
+    if (e != hipSuccess) { x.failed = true; throw HipError{e, "hipEventQuery (winner exchange)", __LINE__}; }
   }
+  sl.pack_pending = false;
   const size_t n_local = (size_t)h->D.P * winner_rec(h);
   if (x.c->rccl) {
     float ms = 0.f;
-    HIP_CHECK(hipEventElapsedTime(&ms, x.ev_t0, x.ev_t1));
+    HIP_CHECK(hipEventElapsedTime(&ms, sl.ev_t0, sl.ev_t1));
     x.ag_us.push_back((double)ms * 1e3);
   } else {
     const auto t0 = std::chrono::steady_clock::now();
-    if (x.c->fn(x.c->ctx, x.h_send, x.h_recv, n_local * sizeof(double)) != 0)
+    if (x.c->fn(x.c->ctx, sl.h_send, sl.h_recv, n_local * sizeof(double)) != 0) {
+      x.failed = true;
       fail(PMAF_ERR_DEVICE, "winner exchange: the host all-gather callback failed");
+    }
     x.ag_us.push_back(std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count());
-    HIP_CHECK(hipMemcpyAsync(x.d_recv, x.h_recv, n_local * x.c->world * sizeof(double), hipMemcpyHostToDevice, x.xs));
+    HIP_CHECK(hipMemcpyAsync(sl.d_recv, sl.h_recv, n_local * x.c->world * sizeof(double), hipMemcpyHostToDevice, x.xs));
     HIP_CHECK(hipStreamSynchronize(x.xs));
   }
   if (x.ag_us.size() > (1u << 20)) x.ag_us.erase(x.ag_us.begin(), x.ag_us.begin() + (1u << 19));
-  x.inflight = false;
+}
+// all exchanges in flight, oldest first (the host transport runs the callers' collectives here: same order on every rank)
+static void finish_exchanges(pmaf_planner *h) {
+  finish_exchange(h, h->x.cur ^ 1);
+  finish_exchange(h, h->x.cur);
+}
+// the slot the next selection will send from: its previous exchange (two selections ago) must be through, and so
+// must the pack kernel of the LAST exchange, which reads the path buffer the rollout launched next overwrites
+// (local work on its own stream -- this wait never involves a peer)
+static pmaf_planner::Exchange::Slot &claim_exchange_slot(pmaf_planner *h) {
+  pmaf_planner::Exchange &x = h->x;
+  finish_exchange(h, x.cur ^ 1);
+  pmaf_planner::Exchange::Slot &last = x.slot[x.cur];
+  if (last.pack_pending) {
+    if (hipEventQuery(last.ev_pack) != hipSuccess) HIP_CHECK(hipEventSynchronize(last.ev_pack));
+    last.pack_pending = false;
+  }
+  return x.slot[x.cur ^ 1];
 }
 
-// pack the selected agents' paths out of `scored_paths` behind the headers k_manager wrote into d_send and all-gather
-// the records, all on the exchange stream
+// pack the selected agents' paths out of `scored_paths` behind the headers k_manager wrote into the claimed slot's
+// send buffer and all-gather the records.
 // Called once the HOST knows that k_manager has written the record headers (pmaf_tick: the mailbox's sequence number
 // has arrived, and the headers are stored before it behind a system-scope fence; pmaf_evaluate: the stream is
-// synchronised): the exchange stream then needs no event from the handle's stream -- a cross-stream event between
+// synchronised): the exchange streams then need no event from the handle's stream -- a cross-stream event between
 // the manager and the rollout cost 4-7 us per tick (measured), this costs the rollout nothing.
 static void begin_exchange(pmaf_planner *h, const double *scored_paths) {
   pmaf_planner::Exchange &x = h->x;
+  x.cur ^= 1;
+  pmaf_planner::Exchange::Slot &sl = x.slot[x.cur];
   const size_t n_local = (size_t)h->D.P * winner_rec(h);
-  pmaf_k_launch_winner_path(h->D, scored_paths, x.d_send, x.xs);
+  pmaf_k_launch_winner_path(h->D, scored_paths, sl.d_send, x.xp);
   HIP_CHECK(hipGetLastError());
-  HIP_CHECK(hipEventRecord(x.ev_pack, x.xs));
+  HIP_CHECK(hipEventRecord(sl.ev_pack, x.xp));
+  sl.pack_pending = true;
+  HIP_CHECK(hipStreamWaitEvent(x.xs, sl.ev_pack, 0));
   if (x.c->rccl) {
-    HIP_CHECK(hipEventRecord(x.ev_t0, x.xs));
-    const std::string err = pmaf_comm_enqueue_allgather(x.c, x.d_send, x.d_recv, n_local, x.xs);
+    HIP_CHECK(hipEventRecord(sl.ev_t0, x.xs));
+    const std::string err = pmaf_comm_enqueue_allgather(x.c, sl.d_send, sl.d_recv, n_local, x.xs);
     if (!err.empty()) fail(PMAF_ERR_DEVICE, err);
-    HIP_CHECK(hipEventRecord(x.ev_t1, x.xs));
-    HIP_CHECK(hipMemcpyAsync(x.h_recv, x.d_recv, n_local * x.c->world * sizeof(double), hipMemcpyDeviceToHost, x.xs));
+    HIP_CHECK(hipEventRecord(sl.ev_t1, x.xs));
+    HIP_CHECK(hipMemcpyAsync(sl.h_recv, sl.d_recv, n_local * x.c->world * sizeof(double), hipMemcpyDeviceToHost, x.xs));
   } else {
-    HIP_CHECK(hipMemcpyAsync(x.h_send, x.d_send, n_local * sizeof(double), hipMemcpyDeviceToHost, x.xs));
+    HIP_CHECK(hipMemcpyAsync(sl.h_send, sl.d_send, n_local * sizeof(double), hipMemcpyDeviceToHost, x.xs));
   }
-  HIP_CHECK(hipEventRecord(x.ev_done, x.xs));
-  x.inflight = true;
+  HIP_CHECK(hipEventRecord(sl.ev_done, x.xs));
+  sl.inflight = true;
+  x.failed = false;
 }
 
 static void detach_comm(pmaf_planner *h) {
   pmaf_planner::Exchange &x = h->x;
   if (!x.c) return;
   h->paths_gen++;
-  if (x.inflight) {
-    // an RCCL all-gather already enqueued completes (every rank enqueued it); a host collective not yet run is dropped
-    (void)hipStreamSynchronize(x.xs);
-    x.inflight = false;
-  }
+  // an RCCL all-gather already enqueued completes (every rank enqueued it); a host collective not yet run is dropped
+  if (x.xp) (void)hipStreamSynchronize(x.xp);
+  if (x.any_inflight() && x.xs) (void)hipStreamSynchronize(x.xs);
   (void)hipStreamSynchronize(h->stream);
   if (h->D.paths != x.paths_a) {  // the handle goes back to its own path buffer
     (void)hipMemcpy(x.paths_a, x.paths_b, sizeof(double) * (size_t)h->D.P * h->D.N * h->D.cap * 3, hipMemcpyDeviceToDevice);
     h->D.paths = x.paths_a;
   }
   if (x.paths_b) (void)hipFree(x.paths_b);
-  if (x.d_send) (void)hipFree(x.d_send);
-  if (x.d_recv) (void)hipFree(x.d_recv);
-  if (x.h_send) (void)hipHostFree(x.h_send);
-  if (x.h_recv) (void)hipHostFree(x.h_recv);
-  for (hipEvent_t e : {x.ev_pack, x.ev_t0, x.ev_t1, x.ev_done}) if (e) (void)hipEventDestroy(e);
+  for (auto &sl : x.slot) {
+    if (sl.d_send) (void)hipFree(sl.d_send);
+    if (sl.d_recv) (void)hipFree(sl.d_recv);
+    if (sl.h_send) (void)hipHostFree(sl.h_send);
+    if (sl.h_recv) (void)hipHostFree(sl.h_recv);
+    for (hipEvent_t e : {sl.ev_pack, sl.ev_t0, sl.ev_t1, sl.ev_done}) if (e) (void)hipEventDestroy(e);
+  }
+  if (x.xp) (void)hipStreamDestroy(x.xp);
   if (x.xs) (void)hipStreamDestroy(x.xs);
   x = pmaf_planner::Exchange{};
+}
+
+// ---- peer mailboxes ----------------------------------------------------------
+struct PeerHandleBlob {   // what pmaf_peer_export hands out (PMAF_PEER_HANDLE_BYTES)
+  uint64_t magic;
+  int64_t pid;
+  uint64_t ptr;           // the inbox in the exporting process (used when the importer IS that process)
+  int32_t world, P, device, pad;
+  hipIpcMemHandle_t ipc;
+  unsigned char fill[PMAF_PEER_HANDLE_BYTES - 40 - sizeof(hipIpcMemHandle_t)];
+};
+static_assert(sizeof(PeerHandleBlob) == PMAF_PEER_HANDLE_BYTES, "pmaf.h: PMAF_PEER_HANDLE_BYTES");
+static const uint64_t kPeerMagic = 0x504d41465f505231ull;  // "PMAF_PR1"
+
+static size_t peer_inbox_doubles(int world, int P) { return (size_t)2 * world * P * PMAF_PEER_SLOT; }
+
+// after the mailbox of a tick has arrived: the wait for the coupled header / the publish time of this tick's manager
+// kernel, and whether a header it waited for never came
+static bool peer_book_tick(pmaf_planner *h) {
+  pmaf_planner::Peer &pr = h->peer;
+  double w = 0.0, pb = 0.0;
+  bool late = false;
+  for (int p = 0; p < h->D.P; p++) {
+    const double *o = h->h_out + p * PMAF_MBOX;
+    w = std::max(w, o[12]);
+    pb = std::max(pb, o[13]);
+    late = late || o[14] != 0.0;
+  }
+  pr.wait_us.push_back(w * pr.us_per_tick);
+  pr.pub_us.push_back(pb * pr.us_per_tick);
+  if (pr.wait_us.size() > (1u << 20)) {
+    pr.wait_us.erase(pr.wait_us.begin(), pr.wait_us.begin() + (1u << 19));
+    pr.pub_us.erase(pr.pub_us.begin(), pr.pub_us.begin() + (1u << 19));
+  }
+  return late;
+}
+
+static void peer_disconnect(pmaf_planner *h) {
+  pmaf_planner::Peer &pr = h->peer;
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  for (size_t r = 0; r < pr.mapped.size(); r++)
+    if (pr.opened[r] && pr.mapped[r]) (void)hipIpcCloseMemHandle(pr.mapped[r]);
+  if (pr.d_view) (void)hipFree(pr.d_view);
+  if (pr.d_couple) (void)hipFree(pr.d_couple);
+  if (pr.d_radius) (void)hipFree(pr.d_radius);
+  if (pr.inbox) (void)hipFree(pr.inbox);
+  pr = pmaf_planner::Peer{};
 }
 
 template <typename F>
@@ -541,6 +660,7 @@ int pmaf_create(const pmaf_params *prm, pmaf_planner **out) {
     h->lpa = lp ? lp : pick_lpa(N, P, M);
     { const char *fg = getenv("PMAF_FORCE_GENERIC"); h->force_generic = fg && fg[0] == '1'; }
     { const char *ab = getenv("PMAF_ABLATE"); D.ablate = ab ? atoi(ab) : 0; }
+    { const char *to = getenv("PMAF_EXCHANGE_TIMEOUT_S"); if (to && atof(to) > 0.0) h->exchange_timeout_s = atof(to); }
     h->dpp_sum = M > 20;
     { const char *ds = getenv("PMAF_SUM"); if (ds && ds[0]) h->dpp_sum = (ds[0] == 'd'); }  // "dpp" / "lds": tests, timing
     {
@@ -609,7 +729,7 @@ int pmaf_create(const pmaf_params *prm, pmaf_planner **out) {
     D.zsent_lt = zsent;
     h->d_reset_in = h->dalloc<double>(P * 6);
     h->d_agent_id = h->dalloc<int32_t>(P);
-    HIP_CHECK(hipHostMalloc((void **)&h->h_out, sizeof(double) * P * 12, hipHostMallocMapped));
+    HIP_CHECK(hipHostMalloc((void **)&h->h_out, sizeof(double) * P * PMAF_MBOX, hipHostMallocMapped));
     HIP_CHECK(hipHostGetDevicePointer((void **)&h->d_out, h->h_out, 0));
     HIP_CHECK(hipHostMalloc((void **)&h->h_zc, sizeof(double) * (size_t)P * 7 * n_obs, hipHostMallocMapped));
     HIP_CHECK(hipHostGetDevicePointer((void **)&h->d_zc, h->h_zc, 0));
@@ -617,7 +737,7 @@ int pmaf_create(const pmaf_params *prm, pmaf_planner **out) {
       HIP_CHECK(hipHostMalloc((void **)&h->h_stage[i], sizeof(double) * (size_t)P * 7 * n_obs, hipHostMallocDefault));
       HIP_CHECK(hipEventCreateWithFlags(&h->ev_stage[i], hipEventDisableTiming));
     }
-    std::memset(h->h_out, 0, sizeof(double) * P * 12);
+    std::memset(h->h_out, 0, sizeof(double) * P * PMAF_MBOX);
 
     // ---- initial state = freshly constructed agents (cf_agent.h:69-97) ----
     std::vector<double> init(P * 3, 0.0);
@@ -702,6 +822,7 @@ int pmaf_destroy(pmaf_planner *h) {
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   detach_comm(h);
+  peer_disconnect(h);
   if (h->d_send1) (void)hipFree(h->d_send1);
   for (void *p : h->allocs) (void)hipFree(p);
   for (void *p : h->scratch) (void)hipFree(p);
@@ -767,8 +888,8 @@ int pmaf_start(pmaf_planner *h) {
     REQUIRE(h, "pmaf_start: NULL handle");
     h->use_device();
     if (h->stepped)
-      fail(PMAF_ERR_STATE, "pmaf_start: the agents were moved by pmaf_move_agent(s); call pmaf_reset_agents or "
-                           "pmaf_set_agent_* / pmaf_set_initial_position first (rollouts start from the population's reset state)");
+      fail(PMAF_ERR_STATE, "pmaf_start: the agents were moved / set by the stepping API (pmaf_move_agent(s), pmaf_set_agent_*); "
+                           "call pmaf_reset_agents or pmaf_set_initial_position first (rollouts start from the population's reset state)");
     // a finished rollout that was not reset has nothing left to predict
     // (guard B/src/cf_agent.cpp:310-311 is already false)
     if (!h->rollout_pending) return;
@@ -802,8 +923,7 @@ int pmaf_evaluate(pmaf_planner *h, const double *cost_gains, const double *ws, i
     A.do_select = 1;
     A.out = h->d_out;
     if (h->x.c) {
-      finish_exchange(h);  // the previous exchange owns the send buffer until it is through
-      A.winner_hdr = h->x.d_send;
+      A.winner_hdr = claim_exchange_slot(h).d_send;  // (its exchange of two selections ago is through)
       A.winner_stride = (int)winner_rec(h);
     }
     launch_manager(h, A);
@@ -812,7 +932,7 @@ int pmaf_evaluate(pmaf_planner *h, const double *cost_gains, const double *ws, i
     if (!h->ev_inflight.empty()) drain_events(h, true);
     refresh_real_cache(h);
     if (best_idx)
-      for (int p = 0; p < h->D.P; p++) best_idx[p] = (int32_t)h->h_out[p * 12];
+      for (int p = 0; p < h->D.P; p++) best_idx[p] = (int32_t)h->h_out[p * PMAF_MBOX];
   });
 }
 
@@ -882,9 +1002,13 @@ int pmaf_tick(pmaf_planner *h, const double *obstacles, double dt, const double 
     A.out = h->d_out;
     A.seq = (double)(++h->mailbox_seq);
     if (h->x.c) {
-      finish_exchange(h);  // normally long through: it ran beside the previous rollout
-      A.winner_hdr = h->x.d_send;
+      // the send buffer of the exchange two ticks back (long through); the previous tick's collective is NOT waited for
+      A.winner_hdr = claim_exchange_slot(h).d_send;
       A.winner_stride = (int)winner_rec(h);
+    }
+    if (h->peer.on) {
+      A.peer = h->peer.d_view;
+      A.peer_tick = (double)(++h->peer.tick);
     }
     launch_manager(h, A);
     const double *scored = h->D.paths;  // the paths this selection scored; the rollout below writes the other buffer
@@ -895,15 +1019,19 @@ int pmaf_tick(pmaf_planner *h, const double *obstacles, double dt, const double 
     // (no event between the two launches: the host polls the sequence number -- spinning, or with
     // PMAF_FLAG_BLOCKING_WAIT sleeping between polls)
     wait_mailbox(h, A.seq);
+    const bool peer_late = h->peer.on && peer_book_tick(h);
     if (h->x.c) begin_exchange(h, scored);  // pack + all-gather on the exchange stream, beside the rollout
     refresh_real_cache(h);
     append_real_path(h);
     for (int p = 0; p < h->D.P; p++) {
-      const double *o = h->h_out + p * 12;
+      const double *o = h->h_out + p * PMAF_MBOX;
       if (best_idx) best_idx[p] = (int32_t)o[0];
       if (next_pos) { next_pos[p * 3] = o[1]; next_pos[p * 3 + 1] = o[2]; next_pos[p * 3 + 2] = o[3]; }
       if (next_vel) { next_vel[p * 3] = o[4]; next_vel[p * 3 + 1] = o[5]; next_vel[p * 3 + 2] = o[6]; }
     }
+    if (peer_late)
+      fail(PMAF_ERR_DEVICE, "pmaf_tick: the header of a coupled peer population did not arrive in time (a peer rank behind "
+                            "by more than PMAF_PEER_TIMEOUT_S, or gone); the trailing obstacle kept its previous value");
   });
 }
 
@@ -995,8 +1123,11 @@ static void set_agents(pmaf_planner *h, const double *pos, const double *vel) {
   HIP_CHECK(hipGetLastError());
   sync(h);
   h->scores_valid = false;
-  h->rollout_pending = true;
-  h->stepped = false;
+  h->rollout_pending = false;
+  // like after pmaf_move_agent(s): in the reference a startPrediction() here would continue with each agent's OWN
+  // velocity, known flags and advanced obstacle copies (CfAgent::setPosition only clears the path,
+  // B/src/cf_agent.cpp:39-42), which a rollout launched from the population's reset state cannot reproduce
+  h->stepped = true;
 }
 
 int pmaf_set_agent_positions(pmaf_planner *h, const double *pos) {
@@ -1300,25 +1431,28 @@ int pmaf_attach_comm(pmaf_planner *h, pmaf_comm *c) {
     const size_t path_bytes = sizeof(double) * (size_t)h->D.P * h->D.N * h->D.cap * 3;
     try {
       {
-        // a high-priority stream: its own hardware queue, so the pack kernel and the all-gather are dispatched beside
+        // high-priority streams: their own hardware queues, so the pack kernel and the all-gather are dispatched beside
         // the rollout instead of queueing with it (streams of equal priority may share a hardware queue: measured
         // +48 us per C2 tick with the exchange on a default-priority stream)
         int lo = 0, hi = 0;
         HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        HIP_CHECK(hipStreamCreateWithPriority(&x.xp, hipStreamNonBlocking, hi));
         HIP_CHECK(hipStreamCreateWithPriority(&x.xs, hipStreamNonBlocking, hi));
       }
-      HIP_CHECK(hipEventCreateWithFlags(&x.ev_pack, hipEventDisableTiming));
-      HIP_CHECK(hipEventCreate(&x.ev_t0));
-      HIP_CHECK(hipEventCreate(&x.ev_t1));
-      HIP_CHECK(hipEventCreateWithFlags(&x.ev_done, hipEventDisableTiming));
-      HIP_CHECK(hipMalloc((void **)&x.d_send, sizeof(double) * n_local));
-      HIP_CHECK(hipMalloc((void **)&x.d_recv, sizeof(double) * n_local * (size_t)c->world));
-      HIP_CHECK(hipHostMalloc((void **)&x.h_send, sizeof(double) * n_local, hipHostMallocDefault));
-      HIP_CHECK(hipHostMalloc((void **)&x.h_recv, sizeof(double) * n_local * (size_t)c->world, hipHostMallocDefault));
+      for (auto &sl : x.slot) {
+        HIP_CHECK(hipEventCreateWithFlags(&sl.ev_pack, hipEventDisableTiming));
+        HIP_CHECK(hipEventCreate(&sl.ev_t0));
+        HIP_CHECK(hipEventCreate(&sl.ev_t1));
+        HIP_CHECK(hipEventCreateWithFlags(&sl.ev_done, hipEventDisableTiming));
+        HIP_CHECK(hipMalloc((void **)&sl.d_send, sizeof(double) * n_local));
+        HIP_CHECK(hipMalloc((void **)&sl.d_recv, sizeof(double) * n_local * (size_t)c->world));
+        HIP_CHECK(hipHostMalloc((void **)&sl.h_send, sizeof(double) * n_local, hipHostMallocDefault));
+        HIP_CHECK(hipHostMalloc((void **)&sl.h_recv, sizeof(double) * n_local * (size_t)c->world, hipHostMallocDefault));
+        HIP_CHECK(hipMemset(sl.d_send, 0, sizeof(double) * n_local));
+        HIP_CHECK(hipMemset(sl.d_recv, 0, sizeof(double) * n_local * (size_t)c->world));
+        std::memset(sl.h_recv, 0, sizeof(double) * n_local * (size_t)c->world);
+      }
       HIP_CHECK(hipMalloc((void **)&x.paths_b, path_bytes));
-      HIP_CHECK(hipMemset(x.d_send, 0, sizeof(double) * n_local));
-      HIP_CHECK(hipMemset(x.d_recv, 0, sizeof(double) * n_local * (size_t)c->world));
-      std::memset(x.h_recv, 0, sizeof(double) * n_local * (size_t)c->world);
       x.paths_a = h->D.paths;
       x.c = c;
       h->paths_gen++;
@@ -1336,13 +1470,14 @@ int pmaf_winners_wait(pmaf_planner *h, const double **records, size_t *n_doubles
     REQUIRE(h, "pmaf_winners_wait: NULL handle");
     if (!h->x.c) fail(PMAF_ERR_STATE, "pmaf_winners_wait: no communicator attached (pmaf_attach_comm)");
     h->use_device();
-    finish_exchange(h);
-    if (records) *records = h->x.h_recv;
+    finish_exchanges(h);
+    if (h->x.failed) fail(PMAF_ERR_DEVICE, "pmaf_winners_wait: the last winner exchange failed (no table)");
+    if (records) *records = h->x.slot[h->x.cur].h_recv;
     if (n_doubles) *n_doubles = (size_t)h->D.P * winner_rec(h) * (size_t)h->x.c->world;
   });
 }
 
-void *pmaf_winners_device(pmaf_planner *h) { return h ? (void *)h->x.d_recv : nullptr; }
+void *pmaf_winners_device(pmaf_planner *h) { return h ? (void *)h->x.slot[h->x.cur].d_recv : nullptr; }
 
 int pmaf_get_exchange_times_us(pmaf_planner *h, double *out, int32_t max_n, int32_t *n) {
   return guarded([&] {
@@ -1355,6 +1490,190 @@ int pmaf_get_exchange_times_us(pmaf_planner *h, double *out, int32_t max_n, int3
   });
 }
 
+// ---- peer mailboxes (include/pmaf.h) ----
+int pmaf_peer_export(pmaf_planner *h, int32_t world, void *handle_out) {
+  return guarded([&] {
+    REQUIRE(h && handle_out, "pmaf_peer_export: NULL argument");
+    REQUIRE(world >= 1 && world <= PMAF_PEER_MAX_WORLD, "pmaf_peer_export: need 1 <= world <= 64");
+    h->use_device();
+    sync(h);
+    peer_disconnect(h);
+    pmaf_planner::Peer &pr = h->peer;
+    const size_t bytes = sizeof(double) * peer_inbox_doubles(world, h->D.P);
+    // fine-grained device memory: stores of other agents (peer GPUs over xGMI) become visible to this GPU's
+    // system-scope loads without a kernel boundary; plain device memory as the fall-back
+    hipError_t e = hipExtMallocWithFlags((void **)&pr.inbox, bytes, hipDeviceMallocFinegrained);
+    pr.inbox_fine = e == hipSuccess;
+    if (e != hipSuccess) { (void)hipGetLastError(); HIP_CHECK(hipMalloc((void **)&pr.inbox, bytes)); }
+    {
+      // sequence numbers start at -1 (no header yet)
+      std::vector<double> init(peer_inbox_doubles(world, h->D.P), 0.0);
+      for (size_t i = 8; i < init.size(); i += PMAF_PEER_SLOT) init[i] = -1.0;
+      HIP_CHECK(hipMemcpy(pr.inbox, init.data(), bytes, hipMemcpyHostToDevice));
+    }
+    pr.world = world;
+    PeerHandleBlob b{};
+    b.magic = kPeerMagic; b.pid = (int64_t)getpid(); b.ptr = (uint64_t)(uintptr_t)pr.inbox;
+    b.world = world; b.P = h->D.P; b.device = h->device;
+    if (world > 1) {
+      e = hipIpcGetMemHandle(&b.ipc, pr.inbox);
+      if (e != hipSuccess && pr.inbox_fine) {   // this runtime does not export fine-grained memory: plain device memory
+        (void)hipGetLastError();
+        (void)hipFree(pr.inbox); pr.inbox = nullptr; pr.inbox_fine = false;
+        HIP_CHECK(hipMalloc((void **)&pr.inbox, bytes));
+        std::vector<double> init(peer_inbox_doubles(world, h->D.P), 0.0);
+        for (size_t i = 8; i < init.size(); i += PMAF_PEER_SLOT) init[i] = -1.0;
+        HIP_CHECK(hipMemcpy(pr.inbox, init.data(), bytes, hipMemcpyHostToDevice));
+        b.ptr = (uint64_t)(uintptr_t)pr.inbox;
+        e = hipIpcGetMemHandle(&b.ipc, pr.inbox);
+      }
+      if (e != hipSuccess) throw HipError{e, "hipIpcGetMemHandle (peer inbox)", __LINE__};
+    }
+    std::memcpy(handle_out, &b, sizeof(b));
+  });
+}
+
+int pmaf_peer_connect(pmaf_planner *h, int32_t world, int32_t rank, const void *handles) {
+  return guarded([&] {
+    REQUIRE(h && handles, "pmaf_peer_connect: NULL argument");
+    pmaf_planner::Peer &pr = h->peer;
+    REQUIRE(pr.inbox && !pr.on, "pmaf_peer_connect: call pmaf_peer_export first (once per connection)");
+    REQUIRE(world == pr.world && rank >= 0 && rank < world, "pmaf_peer_connect: world differs from pmaf_peer_export's, or bad rank");
+    h->use_device();
+    sync(h);
+    const PeerHandleBlob *hb = static_cast<const PeerHandleBlob *>(handles);
+    pr.mapped.assign(world, nullptr);
+    pr.opened.assign(world, 0);
+    for (int r = 0; r < world; r++) {
+      const PeerHandleBlob &b = hb[r];
+      REQUIRE(b.magic == kPeerMagic, "pmaf_peer_connect: not a handle of pmaf_peer_export");
+      REQUIRE(b.world == world && b.P == h->D.P, "pmaf_peer_connect: every rank must export for the same world and hold the same number of populations");
+      if (r == rank) {
+        REQUIRE(b.pid == (int64_t)getpid() && b.ptr == (uint64_t)(uintptr_t)pr.inbox, "pmaf_peer_connect: handles[rank] is not this handle's own export");
+        pr.mapped[r] = pr.inbox;
+      } else if (b.pid == (int64_t)getpid()) {
+        // another handle of this process (several "ranks" in one process: tests, one host driving several GPUs)
+        if (b.device != h->device) {
+          hipError_t e = hipDeviceEnablePeerAccess(b.device, 0);
+          if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) throw HipError{e, "hipDeviceEnablePeerAccess (peer inbox)", __LINE__};
+          (void)hipGetLastError();
+        }
+        pr.mapped[r] = reinterpret_cast<double *>((uintptr_t)b.ptr);
+      } else {
+        void *p = nullptr;
+        HIP_CHECK(hipIpcOpenMemHandle(&p, b.ipc, hipIpcMemLazyEnablePeerAccess));
+        pr.mapped[r] = static_cast<double *>(p);
+        pr.opened[r] = 1;
+      }
+    }
+    pr.rank = rank;
+    const int P = h->D.P;
+    HIP_CHECK(hipMalloc((void **)&pr.d_view, sizeof(PeerView)));
+    HIP_CHECK(hipMalloc((void **)&pr.d_couple, sizeof(int32_t) * 2 * P));
+    HIP_CHECK(hipMalloc((void **)&pr.d_radius, sizeof(double) * P));
+    pr.couple_h.assign(2 * (size_t)P, -1);
+    pr.radius_h.assign(P, 0.0);
+    HIP_CHECK(hipMemcpy(pr.d_couple, pr.couple_h.data(), sizeof(int32_t) * 2 * P, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(pr.d_radius, pr.radius_h.data(), sizeof(double) * P, hipMemcpyHostToDevice));
+    int khz = 0;
+    HIP_CHECK(hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, h->device));
+    if (khz <= 0) khz = 100000;
+    pr.us_per_tick = 1e3 / (double)khz;
+    double timeout_s = 2.0;
+    { const char *to = getenv("PMAF_PEER_TIMEOUT_S"); if (to && atof(to) > 0.0) timeout_s = atof(to); }
+    PeerView v{};
+    v.world = world; v.rank = rank; v.P = P;
+    v.inbox = pr.inbox;
+    for (int r = 0; r < world; r++) v.peer[r] = pr.mapped[r];
+    v.couple = pr.d_couple; v.couple_radius = pr.d_radius;
+    v.timeout_ticks = (unsigned long long)(timeout_s * 1e3 * (double)khz);
+    HIP_CHECK(hipMemcpy(pr.d_view, &v, sizeof(v), hipMemcpyHostToDevice));
+    pr.tick = 0;
+    pr.on = true;
+  });
+}
+
+int pmaf_peer_couple(pmaf_planner *h, int32_t pop, int32_t src_rank, int32_t src_pop, double radius, const double *init_pos) {
+  return guarded([&] {
+    REQUIRE(h, "pmaf_peer_couple: NULL handle");
+    pmaf_planner::Peer &pr = h->peer;
+    if (!pr.on) fail(PMAF_ERR_STATE, "pmaf_peer_couple: no peer mailboxes connected (pmaf_peer_connect)");
+    REQUIRE(pop >= 0 && pop < h->D.P, "pmaf_peer_couple: bad population");
+    h->use_device();
+    sync(h);
+    if (src_rank >= 0) {
+      REQUIRE(src_rank < pr.world && src_pop >= 0 && src_pop < h->D.P, "pmaf_peer_couple: bad source rank / population");
+      REQUIRE(!(src_rank == pr.rank && src_pop == pop), "pmaf_peer_couple: a population cannot be coupled to itself");
+      check_range(&radius, 1, "pmaf_peer_couple: radius");
+      if (init_pos) {
+        if (pr.tick != 0) fail(PMAF_ERR_STATE, "pmaf_peer_couple: init_pos can only be given before the first pmaf_tick after pmaf_peer_connect");
+        check_range(init_pos, 3, "pmaf_peer_couple: init_pos");
+        // header "0" of the source population in this rank's own inbox (parity slot 0; its first real writer is the
+        // source's tick 2, which needs this rank's tick 1 first)
+        double slot[PMAF_PEER_SLOT] = {0};
+        slot[4] = init_pos[0]; slot[5] = init_pos[1]; slot[6] = init_pos[2]; slot[8] = 0.0;
+        HIP_CHECK(hipMemcpy(pr.inbox + (((size_t)0 * pr.world + src_rank) * h->D.P + src_pop) * PMAF_PEER_SLOT, slot,
+                            sizeof(slot), hipMemcpyHostToDevice));
+      }
+    }
+    pr.couple_h[2 * pop] = src_rank < 0 ? -1 : src_rank;
+    pr.couple_h[2 * pop + 1] = src_rank < 0 ? -1 : src_pop;
+    pr.radius_h[pop] = src_rank < 0 ? 0.0 : radius;
+    HIP_CHECK(hipMemcpy(pr.d_couple, pr.couple_h.data(), sizeof(int32_t) * 2 * h->D.P, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(pr.d_radius, pr.radius_h.data(), sizeof(double) * h->D.P, hipMemcpyHostToDevice));
+  });
+}
+
+int pmaf_peer_disconnect(pmaf_planner *h) {
+  return guarded([&] {
+    REQUIRE(h, "pmaf_peer_disconnect: NULL handle");
+    h->use_device();
+    sync(h);
+    peer_disconnect(h);
+  });
+}
+
+int pmaf_peer_read(pmaf_planner *h, double *headers, double *seq) {
+  return guarded([&] {
+    REQUIRE(h, "pmaf_peer_read: NULL handle");
+    pmaf_planner::Peer &pr = h->peer;
+    if (!pr.on) fail(PMAF_ERR_STATE, "pmaf_peer_read: no peer mailboxes connected (pmaf_peer_connect)");
+    h->use_device();
+    const int P = h->D.P;
+    std::vector<double> box(peer_inbox_doubles(pr.world, P));
+    HIP_CHECK(hipMemcpy(box.data(), pr.inbox, sizeof(double) * box.size(), hipMemcpyDeviceToHost));
+    for (int r = 0; r < pr.world; r++)
+      for (int p = 0; p < P; p++) {
+        const double *s0 = box.data() + (((size_t)0 * pr.world + r) * P + p) * PMAF_PEER_SLOT;
+        const double *s1 = box.data() + (((size_t)1 * pr.world + r) * P + p) * PMAF_PEER_SLOT;
+        const double *s = s1[8] > s0[8] ? s1 : s0;   // the newer of the two parity slots
+        if (headers) std::memcpy(headers + ((size_t)r * P + p) * PMAF_WINNER_HDR, s, sizeof(double) * PMAF_WINNER_HDR);
+        if (seq) seq[(size_t)r * P + p] = s[8];
+      }
+  });
+}
+
+int pmaf_get_peer_times_us(pmaf_planner *h, double *wait_us, double *publish_us, int32_t max_n, int32_t *n) {
+  return guarded([&] {
+    REQUIRE(h && n, "pmaf_get_peer_times_us: NULL argument");
+    pmaf_planner::Peer &pr = h->peer;
+    const size_t k = max_n > 0 ? std::min(pr.wait_us.size(), (size_t)max_n) : 0;
+    for (size_t i = 0; i < k; i++) {
+      if (wait_us) wait_us[i] = pr.wait_us[i];
+      if (publish_us) publish_us[i] = pr.pub_us[i];
+    }
+    *n = (int32_t)k;
+    pr.wait_us.clear();
+    pr.pub_us.clear();
+  });
+}
+
+int pmaf_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+  return n;
+}
+
 // ---- checkpoint / resume ----------------------------------------------------
 // The blob holds every device buffer of the handle (agents' rotation vectors,
 // known flags, paths, real agent, best-agent copy, obstacle tables ...) plus
@@ -1363,7 +1682,7 @@ int pmaf_get_exchange_times_us(pmaf_planner *h, double *out, int32_t max_n, int3
 // path buffer -- finish the exchange in flight and move them back
 static void normalise_path_buffer(pmaf_planner *h) {
   if (!h->x.c) return;
-  finish_exchange(h);
+  finish_exchanges(h);
   if (h->D.paths != h->x.paths_a) {
     HIP_CHECK(hipMemcpy(h->x.paths_a, h->x.paths_b, sizeof(double) * (size_t)h->D.P * h->D.N * h->D.cap * 3, hipMemcpyDeviceToDevice));
     h->D.paths = h->x.paths_a;
@@ -1373,7 +1692,7 @@ static void normalise_path_buffer(pmaf_planner *h) {
 struct StateHeader {
   uint64_t magic;
   int32_t abi, P, N, n_obs, cap, n_bufs;
-  int32_t cp_valid, scores_valid, rollout_pending, pad;
+  int32_t cp_valid, scores_valid, rollout_pending, stepped;
   uint64_t dev_bytes;
 };
 static const uint64_t kStateMagic = 0x504d41465f535431ull;  // "PMAF_ST1"
@@ -1400,6 +1719,7 @@ int pmaf_save_state(pmaf_planner *h, void *blob, size_t bytes) {
     hd.magic = kStateMagic; hd.abi = PMAF_ABI_VERSION;
     hd.P = h->D.P; hd.N = h->D.N; hd.n_obs = h->D.n_obs; hd.cap = h->D.cap; hd.n_bufs = (int32_t)h->allocs.size();
     hd.cp_valid = h->cp_valid; hd.scores_valid = h->scores_valid; hd.rollout_pending = h->rollout_pending;
+    hd.stepped = h->stepped;
     hd.dev_bytes = 0;
     for (size_t b : h->alloc_bytes) hd.dev_bytes += b;
     std::memcpy(w, &hd, sizeof(hd)); w += sizeof(hd);
@@ -1465,6 +1785,7 @@ int pmaf_load_state(pmaf_planner *h, const void *blob, size_t bytes) {
     h->cp_valid = hd.cp_valid != 0;
     h->scores_valid = hd.scores_valid != 0;
     h->rollout_pending = hd.rollout_pending != 0;
+    h->stepped = hd.stepped != 0;
   });
 }
 

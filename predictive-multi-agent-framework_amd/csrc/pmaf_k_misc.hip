@@ -267,6 +267,39 @@ __global__ __launch_bounds__(64) void k_manager(DevView D, CostParams CP, Manage
     }
     for (int i = lane; i < n_obs; i += 64) s_known[i] = rk[i];
   }
+  // ---- peer mailboxes: a coupled population's trailing repulsive obstacle = the source population's set-point of
+  // the PREVIOUS tick, read from this rank's own inbox (the source rank's k_manager stored it there, over xGMI when
+  // it is another GPU). The header of tick t-1 sits in parity slot (t-1) & 1; its writer cannot overwrite it before
+  // this rank has published tick t (it needs that header for its tick t+1), which happens further down.
+  unsigned long long peer_wait = 0ull;
+  int peer_status = 0;
+  const PeerView *PV = A.peer;
+  const bool peer_on = PV != nullptr && A.do_select && A.do_move && A.do_reset;
+  if (peer_on) {
+    const int src_rank = PV->couple[pop * 2], src_pop = PV->couple[pop * 2 + 1];
+    if (src_rank >= 0) {
+      const double want = A.peer_tick - 1.0;
+      const double *slot = PV->inbox + ((((size_t)((long long)want & 1) * PV->world + src_rank) * PV->P + src_pop) * PMAF_PEER_SLOT);
+      const unsigned long long t0 = wall_clock64();
+      // every lane polls the same address (one broadcast load); system scope: the writer is another agent
+      while (__hip_atomic_load(slot + 8, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != want) {
+        if (wall_clock64() - t0 > PV->timeout_ticks) { peer_status = 1; break; }
+        __builtin_amdgcn_s_sleep(2);
+      }
+      peer_wait = wall_clock64() - t0;
+      const double sx = __hip_atomic_load(slot + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      const double sy = __hip_atomic_load(slot + 5, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      const double sz = __hip_atomic_load(slot + 6, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      const double sr = PV->couple_radius[pop];
+      wave_lds_fence();  // the table rows other lanes stored above
+      if (lane == 0 && peer_status == 0) {
+        const int k = n_obs - 1;
+        const double row[7] = {sx, sy, sz, 0.0, 0.0, 0.0, sr};
+#pragma unroll
+        for (int c = 0; c < 7; c++) { smem[c * n_obs + k] = row[c]; live_dev[c * n_obs + k] = row[c]; }
+      }
+    }
+  }
   // random vectors the real agent's heuristic uses (best_agent_'s copy)
   const double *rand_g = D.best_rnd + (size_t)pop * 3 * n_obs;
 
@@ -375,28 +408,55 @@ __global__ __launch_bounds__(64) void k_manager(DevView D, CostParams CP, Manage
   // selected agent's rollout had when it was scored and the set-point the real agent moves to. Written BEFORE the
   // mailbox's sequence number (system-scope fence below): once the host has seen that number the header is visible
   // device-wide, and the host may enqueue the pack kernel + all-gather on another stream with no event in between
+  double hv[PMAF_WINNER_HDR];
+  const bool want_hdr = A.do_select && (A.winner_hdr != nullptr || peer_on);
+  if (want_hdr) {  // wave-uniform values
+    const size_t pb = (size_t)pop * N + best;
+    hv[0] = s_cost[best];
+    hv[1] = (double)best;
+    hv[2] = (double)D.n_points[pb];
+    hv[3] = (double)D.types[best];
+    hv[4] = rp.x; hv[5] = rp.y; hv[6] = rp.z;
+    hv[7] = norm(goal - rp);
+  }
   if (lane == 0 && A.winner_hdr && A.do_select) {
     double *w = A.winner_hdr + (size_t)pop * A.winner_stride;
-    const size_t pb = (size_t)pop * N + best;
-    w[0] = s_cost[best];
-    w[1] = (double)best;
-    w[2] = (double)D.n_points[pb];
-    w[3] = (double)D.types[best];
-    w[4] = rp.x; w[5] = rp.y; w[6] = rp.z;
-    w[7] = norm(goal - rp);
+#pragma unroll
+    for (int c = 0; c < PMAF_WINNER_HDR; c++) w[c] = hv[c];
+  }
+  // peer mailboxes: lane l stores the header into rank l's inbox (its own included), slot [t & 1][rank][pop];
+  // the sequence number follows behind the system-scope fence shared with the host mailbox below
+  unsigned long long peer_pub0 = 0ull;
+  double *peer_slot = nullptr;
+  if (peer_on) {
+    peer_pub0 = wall_clock64();
+    if (lane < PV->world) {
+      peer_slot = PV->peer[lane] + ((((size_t)((long long)A.peer_tick & 1) * PV->world + PV->rank) * PV->P + pop) * PMAF_PEER_SLOT);
+#pragma unroll
+      for (int c = 0; c < PMAF_WINNER_HDR; c++) __hip_atomic_store(peer_slot + c, hv[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
   }
 
   // host-visible outputs first: the caller waits for these only
-  if (lane == 0 && A.out) {
-    double *o = A.out + pop * 12;
-    o[0] = (double)best;
-    o[1] = rp.x; o[2] = rp.y; o[3] = rp.z;
-    o[4] = rv.x; o[5] = rv.y; o[6] = rv.z;
-    o[7] = norm(goal - rp);
-    o[8] = rf.x; o[9] = rf.y; o[10] = rf.z;
-    if (A.seq != 0.0) {
-      __threadfence_system();  // entries 0..10 visible to the host before the sequence number
-      *reinterpret_cast<volatile double *>(o + 11) = A.seq;
+  if (A.out) {
+    double *o = A.out + pop * PMAF_MBOX;
+    if (lane == 0) {
+      o[0] = (double)best;
+      o[1] = rp.x; o[2] = rp.y; o[3] = rp.z;
+      o[4] = rv.x; o[5] = rv.y; o[6] = rv.z;
+      o[7] = norm(goal - rp);
+      o[8] = rf.x; o[9] = rf.y; o[10] = rf.z;
+      o[12] = (double)peer_wait;
+      o[14] = (double)peer_status;
+    }
+    if (A.seq != 0.0 || peer_on) {
+      __threadfence_system();  // entries 0..10 visible to the host (and the peers' headers to them) before the sequence numbers
+      if (peer_slot) __hip_atomic_store(peer_slot + 8, A.peer_tick, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      if (lane == 0) {
+        if (A.seq != 0.0) *reinterpret_cast<volatile double *>(o + 11) = A.seq;
+        // statistics only, not ordered against the sequence number: the host may read the previous tick's value
+        if (peer_on) o[13] = (double)(wall_clock64() - peer_pub0);
+      }
     }
   }
 

@@ -7,6 +7,12 @@
 
 // doubles in front of the path of a winner record (include/pmaf.h: pmaf_winner_record_doubles)
 #define PMAF_WINNER_HDR 8
+// doubles per population in the host-visible mailbox k_manager writes (ManagerArgs::out)
+#define PMAF_MBOX 16
+// peer mailboxes (include/pmaf.h "peer mailboxes"): doubles per header slot (header[8], sequence number, padding
+// to one 128-byte line) and the largest world
+#define PMAF_PEER_SLOT 16
+#define PMAF_PEER_MAX_WORLD 64
 
 namespace pmaf {
 
@@ -79,6 +85,21 @@ struct CostParams {
 };
 
 
+// Peer mailboxes: every rank owns an INBOX in its device memory, [2 parities][world][P][PMAF_PEER_SLOT] doubles,
+// mapped into every peer process (hipIpcOpenMemHandle). k_manager of tick t on rank r stores its populations' record
+// headers + sequence number t straight into slot [t & 1][r][pop] of EVERY rank's inbox (one hop over xGMI, no
+// collective launch), and -- for a population coupled to (src_rank, src_pop) -- reads the header with sequence number
+// t - 1 from its OWN inbox (local HBM) as the position of its trailing repulsive obstacle. This struct lives in
+// device memory; k_manager gets a pointer to it.
+struct PeerView {
+  int world, rank, P, pad;
+  double *inbox;                          // this rank's inbox (== peer[rank])
+  double *peer[PMAF_PEER_MAX_WORLD];      // every rank's inbox as mapped into THIS process
+  const int32_t *couple;                  // [P][2] (src_rank, src_pop) of a coupled population, src_rank < 0: none
+  const double *couple_radius;            // [P] radius given to the coupled trailing obstacle (live list)
+  unsigned long long timeout_ticks;       // bound of the in-kernel wait for a peer's header (wall_clock64 ticks)
+};
+
 struct ManagerArgs {
   int do_select, do_move, do_reset;
   int reset_from_real;     // 1: reset to the real agent's state, 0: reset_in
@@ -89,8 +110,12 @@ struct ManagerArgs {
   double dt_real;
   const int32_t *agent_id; // [P] gains index for the real step; NULL = best_idx of this launch
   const double *reset_in;  // [P][6] pos, vel
-  double *out;             // [P][12] host-visible: best_idx, next_pos[3], next_vel[3], dist_from_goal, force[3], seq
+  double *out;             // [P][PMAF_MBOX] host-visible: best_idx, next_pos[3], next_vel[3], dist_from_goal, force[3],
+                           // seq; [12] wait for the coupled peer header, [13] peer publish (both wall_clock64
+                           // ticks), [14] peer status (0 ok, 1 the awaited header did not arrive in time)
   double seq;              // written to out[11] after the other entries are visible to the host (0: not written)
+  const PeerView *peer;    // peer mailboxes (device memory), NULL: none; used by launches with select+move+reset
+  double peer_tick;        // t: sequence number this launch publishes (it consumes t - 1)
   double *winner_hdr;      // [P][winner_stride] winner-record headers (send buffer of the sharded runs' all-gather),
   int winner_stride;       // written after a selection: {cost, idx, n_points, type, next_pos[3], goal_dist}; NULL: none
 };

@@ -91,6 +91,13 @@ SYMBOLS = {
     "pmaf_winners_wait": (C.c_int, [_V, C.POINTER(_dp), C.POINTER(C.c_size_t)]),
     "pmaf_winners_device": (_V, [_V]),
     "pmaf_get_exchange_times_us": (C.c_int, [_V, _dp, C.c_int32, _ip]),
+    "pmaf_peer_export": (C.c_int, [_V, C.c_int32, _V]),
+    "pmaf_peer_connect": (C.c_int, [_V, C.c_int32, C.c_int32, _V]),
+    "pmaf_peer_couple": (C.c_int, [_V, C.c_int32, C.c_int32, C.c_int32, C.c_double, _dp]),
+    "pmaf_peer_disconnect": (C.c_int, [_V]),
+    "pmaf_peer_read": (C.c_int, [_V, _dp, _dp]),
+    "pmaf_get_peer_times_us": (C.c_int, [_V, _dp, _dp, C.c_int32, _ip]),
+    "pmaf_device_count": (C.c_int, []),
     "pmaf_state_size": (C.c_size_t, [_V]),
     "pmaf_save_state": (C.c_int, [_V, _V, C.c_size_t]),
     "pmaf_load_state": (C.c_int, [_V, _V, C.c_size_t]),
@@ -423,6 +430,42 @@ class PmafPlanner:
         self._chk(self.L.pmaf_get_exchange_times_us(self._h, _p(out), max_n, C.byref(n)))
         return out[:n.value].copy()
 
+    # -- peer mailboxes (header-only exchange without a collective) --
+    PEER_HANDLE_BYTES = 128
+
+    def peer_export(self, world):
+        buf = (C.c_ubyte * self.PEER_HANDLE_BYTES)()
+        self._chk(self.L.pmaf_peer_export(self._h, int(world), C.cast(buf, C.c_void_p)))
+        return bytes(buf)
+
+    def peer_connect(self, world, rank, handles):
+        """handles: list of `world` byte strings from peer_export, in rank order"""
+        blob = b"".join(handles)
+        assert len(blob) == world * self.PEER_HANDLE_BYTES
+        buf = (C.c_ubyte * len(blob)).from_buffer_copy(blob)
+        self._chk(self.L.pmaf_peer_connect(self._h, int(world), int(rank), C.cast(buf, C.c_void_p)))
+        self._peer_world = world
+
+    def peer_couple(self, pop, src_rank, src_pop, radius, init_pos=None):
+        ip = _d(init_pos, (3,)) if init_pos is not None else None
+        self._chk(self.L.pmaf_peer_couple(self._h, int(pop), int(src_rank), int(src_pop), float(radius), _p(ip)))
+
+    def peer_disconnect(self):
+        self._chk(self.L.pmaf_peer_disconnect(self._h))
+
+    def peer_read(self):
+        """(headers [world][P][8], seq [world][P]) -- the newest header of every population in this rank's inbox"""
+        w = self._peer_world
+        hd, sq = np.zeros((w, self.P, 8)), np.zeros((w, self.P))
+        self._chk(self.L.pmaf_peer_read(self._h, _p(hd), _p(sq)))
+        return hd, sq
+
+    def peer_times_us(self, max_n=1 << 20):
+        w, pb = np.zeros(max_n), np.zeros(max_n)
+        n = C.c_int32(0)
+        self._chk(self.L.pmaf_get_peer_times_us(self._h, _p(w), _p(pb), max_n, C.byref(n)))
+        return w[:n.value].copy(), pb[:n.value].copy()
+
     def save_state(self):
         n = int(self.L.pmaf_state_size(self._h))
         buf = np.zeros(n, dtype=np.uint8)
@@ -551,6 +594,11 @@ class PmafComm:
             self.close()
         except Exception:
             pass
+
+
+def device_count():
+    """hipGetDeviceCount as the library sees it"""
+    return int(load_library().pmaf_device_count())
 
 
 def select_best(costs, prev_best=None):

@@ -135,6 +135,33 @@ class DualArmCoupling:
         return obs
 
 
+def connect_peers(planner, dist, world, rank):
+    """Peer mailboxes of a multi-process run (include/pmaf.h "peer mailboxes"):
+    every rank exports its handle's inbox, the 128-byte handles travel through
+    the process group, every rank maps every peer's inbox
+    (hipIpcOpenMemHandle). dist = torch.distributed (None for world == 1)."""
+    mine = planner.peer_export(world)
+    box = [mine]
+    if world > 1:
+        box = [None] * world
+        dist.all_gather_object(box, mine)
+    planner.peer_connect(world, rank, box)
+
+
+def couple_dual_arm_on_device(planner, world, rank, starts, radius=0.1):
+    """BASELINE config 4 with the set-points travelling through the peer
+    mailboxes instead of the host: arm a's trailing obstacle follows arm 1 - a.
+    world == 2: one arm per rank (population 0 of each); world == 1: both arms
+    are populations 0 / 1 of this handle. starts [2][3] = the arms' start
+    positions (what the first tick sees), as shard.DualArmCoupling."""
+    starts = np.asarray(starts, dtype=np.float64).reshape(2, 3)
+    if world == 2:
+        planner.peer_couple(0, 1 - rank, 0, radius, starts[1 - rank])
+    else:
+        planner.peer_couple(0, rank, 1, radius, starts[1])
+        planner.peer_couple(1, rank, 0, radius, starts[0])
+
+
 def all_gather_positions(local_pos, comm):
     """[P_local][3] set-points of every rank -> [world*P_local][3] (rank-major), one small all-gather"""
     local = np.ascontiguousarray(local_pos, dtype=np.float64).reshape(-1, 3)

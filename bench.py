@@ -8,34 +8,45 @@ the workload. Obstacles / agent state are resident in HBM before the timed
 region; ticks are issued back to back, each returning best index + next
 set-point to the host (the real per-tick API, not a batched open-loop shortcut).
 
-Workloads
-  default          BASELINE C2 (the metric's config): 64 agents x 200 steps x 32
-                   obstacles, one population per GPU. N > 1 (one rank per GPU,
-                   launched by torch.distributed.run): every rank plans its own
-                   population ("weak" scaling) AND the ranks all-gather their
-                   winner records once per tick -- ncclAllGather (RCCL over
-                   xGMI) enqueued by libpmaf_hip.so on a second stream, so the
-                   sharded run's collective is part of the measurement.
-  --config C5 --shard   BASELINE C5: 8 goal/obstacle scenes x 1024 agents,
-                   scenes {s : s % N == r} on rank r ("strong" scaling: the 8
-                   scenes are fixed), winner all-gather per tick.
-  --config C4      BASELINE C4: dual arm, 2 x 256 agents, each arm's repulsive
-                   sphere follows the other arm's set-point. 2 ranks: one arm per
-                   GPU, the set-points travel in the winner records; 1 rank: both
-                   arms in one handle.
-  --config C1|C3, --populations P, --dynamic   other single-GPU shapes.
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1: one rank per GPU. Launched by `torch.distributed.run` the ranks come
+from the environment; WITHOUT a launcher (`python bench.py --gpus 8`) the
+script starts its N ranks itself (re-executes under torch.distributed.run on
+127.0.0.1). --gpus must equal the world size and must not exceed
+hipGetDeviceCount() -- anything else is an error, never a silent 1-GPU run.
+
+The line's `value` is the HEADLINE workload: BASELINE C2 (64 agents x 200 steps
+x 32 obstacles), one population per GPU ("weak" scaling: every rank plans the
+same scene), with -- for N > 1 -- the winner records all-gathered once per tick
+by ncclAllGather (RCCL over xGMI), enqueued by libpmaf_hip.so beside the next
+rollout. The same invocation then times BASELINE's other configurations and
+reports them under "configs" (>= 5 blocks each, same timing rules):
+  C1          static1 scene, 16 agents x 100 steps (per-rank replicas)
+  C3          256 agents x 500 steps x 128 obstacles (per-rank replicas)
+  C5_sharded  8 goal/obstacle scenes x 1024 agents partitioned over the N ranks,
+              scene s on rank s % N: the strong-scaling curve of config 5 as the
+              driver runs N = 1, 2, 4, 8
+  C4          dual arm, 2 x 256 agents, each arm's repulsive sphere follows the
+              other arm's set-point THROUGH THE PEER MAILBOXES (no collective and
+              no host on the control path; include/pmaf.h): N = 1 both arms in
+              one handle, N >= 2 one arm per GPU on ranks 0 / 1 (hipIpc-mapped
+              inboxes over xGMI), the path table still all-gathered beside it
+--only-headline skips them; --config / --shard / --populations / --dynamic
+select another headline workload (then no sub-configurations are run).
 
 Timing: W warm-up ticks, then blocks of K ticks, each block bracketed by a
 barrier + device synchronisation on both sides; blocks are repeated until
 --min-seconds have been timed (and at least --min-blocks blocks) and the
-MEDIAN block (max over ranks) is reported, so a short `--steps 20` run gives
-the stationary figure too.
+MEDIAN block (max over ranks per block) is reported.
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -68,50 +79,42 @@ def measured_flops(pkg, scene, ticks=24):
         return {"error": "%s: %s" % (type(e).__name__, e)}
 
 
-def cpu_baseline(pkg, scene, budget_s, max_threads):
-    """Times the CPU oracle (oracle/, a scalar C restatement of the
-    reference's algorithm = kind 'port', gcc -O2) on this host: the same tick
-    sequence on the same scene -- once on one core, and with the agents'
-    rollouts spread over OpenMP threads (the reference's own parallelism is one
-    thread per agent). Thread counts 8..max are tried for a bounded time each
-    and the best one is reported with its count as `cores` (more threads than
-    ~16 lose to fork/join cost on this 0.1 ms-per-rollout workload)."""
-    os.environ.setdefault("OMP_WAIT_POLICY", "active")
-    os.environ.setdefault("OMP_PROC_BIND", "close")
-    os.environ.setdefault("OMP_PLACES", "cores")
-    from oracle import orc
-    orc.set_exp_mode(0)
-    N = scene["n_agents"]
-    obs, dt, cg, ws = scene["obstacles"], scene["dt"], scene["cost_gains"], scene["ws_limits"]
-
-    def run(nthreads, budget):
-        o = orc.OraclePlanner(scene, mgr_init_pos=scene["start"])
-        ticks, el = 0, 0.0
-        t0 = time.perf_counter()
-        while el < budget:
-            if ticks % 256 == 0:
-                o.set_initial_position(scene["start"])  # same episodes as the GPU run
-            for _ in range(8):
-                o.tick_omp(obs, dt, cg, ws, nthreads)
-            ticks += 8
-            el = time.perf_counter() - t0
-        o.close()
-        return N * ticks / el, ticks, el
-
-    v1, _, _ = run(1, budget_s * 0.3)
-    cands = [t for t in (8, 16, 32, 64, 128) if t <= max_threads] or [max_threads]
-    best = None
-    for t in cands:
-        v, ticks, el = run(t, budget_s * 0.7 / len(cands))
-        if best is None or v > best[0]:
-            best = (v, t, ticks, el)
-    return {
-        "value": best[0], "unit": "rollouts/s", "cores": best[1], "kind": "port",
-        "sample": "%d ticks (%.1f s) of the bench workload through oracle/libpmaf_oracle.so (gcc -O2 scalar C "
-                  "restatement; rollouts of the %d agents on %d OpenMP threads, best of %s threads, "
-                  "OMP_PROC_BIND=close; rest of the tick serial)" % (best[2], best[3], N, best[1], cands),
-        "value_1core": v1, "host_cpus": os.cpu_count(),
+def cpu_baseline(config, budget_s):
+    """The CPU oracle (oracle/, a scalar C restatement of the reference's
+    algorithm = kind 'port') timed on this host by oracle/cpu_bench.py in a
+    process of its own: gcc -O2 and gcc -O3 -march=native (compiled here), one
+    core and the agents' rollouts on OpenMP threads, >= 30 repetitions of a
+    fixed tick count each, median / min / max."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "cpu_bench.py"), "--config", config,
+                        "--budget", str(budget_s), "--episode", str(64 if config == "C3" else 256)], capture_output=True, text=True, timeout=60 + 6 * budget_s)
+    if r.returncode != 0:
+        return {"error": r.stderr[-400:]}
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    b = d["builds"]
+    o2, o3 = b.get("O2", {}), b.get("O3_native", {})
+    best_name, best = max(((k, v) for k, v in b.items() if "multi" in v), key=lambda kv: kv[1]["multi"]["median"])
+    out = {
+        "value": best["multi"]["median"], "unit": "rollouts/s", "cores": best["threads"], "kind": "port",
+        "cpu_model": d["cpu_model"], "host_cpus": d["host_cpus"], "build_of_value": best_name,
+        "sample": "oracle/libpmaf_oracle.so (scalar C restatement of the reference) on the bench workload %s: per build "
+                  "%d repetitions of %d ticks on 1 core and %d repetitions of %d ticks with the agents' rollouts on "
+                  "%d OpenMP threads (thread count picked by a 6-repetition probe over %s, OMP_PROC_BIND=close; rest "
+                  "of the tick serial); value = MEDIAN of the better build; builds bit-identical: %s"
+                  % (config, best["one_core"]["reps"], best["one_core"]["ticks_per_rep"], best["multi"]["reps"],
+                     best["multi"]["ticks_per_rep"], best["threads"], sorted(int(k) for k in best["probe_median_by_threads"]),
+                     d["builds_bit_identical"]),
+        "value_1core": best["one_core"]["median"], "h_eff": best["multi"].get("h_eff"),
     }
+    for tag, bb in (("O2", o2), ("O3_native", o3)):
+        if "multi" in bb:
+            out["value_" + tag] = bb["multi"]["median"]
+            out["spread_" + tag] = [bb["multi"]["min"], bb["multi"]["max"]]
+            out["threads_" + tag] = bb["threads"]
+            out["value_1core_" + tag] = bb["one_core"]["median"]
+            out["spread_1core_" + tag] = [bb["one_core"]["min"], bb["one_core"]["max"]]
+        else:
+            out["error_" + tag] = bb.get("error", "not built")
+    return out
 
 
 def kernel_name_of(cfg, n_obs):
@@ -131,6 +134,374 @@ def kernel_name_of(cfg, n_obs):
     return "k_rollout<%d>" % cfg["lanes_per_agent"]
 
 
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks (one per GPU) under torch.distributed.run
+    with the same arguments and pass their output through"""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC (RCCL, the peer mailboxes) -- see the environment notes
+    env.setdefault("OMP_NUM_THREADS", "1")
+    sys.stderr.write("bench.py: --gpus %d without a launcher: starting %d ranks under torch.distributed.run\n" % (n, n))
+    sys.stderr.flush()
+    return subprocess.call(cmd, env=env)
+
+
+class Ctx:
+    """what every workload of one invocation shares: ranks, process group, package"""
+
+    def __init__(self, args):
+        self.args = args
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.dist = None
+        # test hooks for a 1-GPU box: PMAF_BENCH_BACKEND=gloo runs torch's collectives on CPU tensors and the winner
+        # exchange over a host-transport communicator, PMAF_BENCH_SINGLE_DEVICE=1 maps every rank to device 0
+        self.backend = os.environ.get("PMAF_BENCH_BACKEND", "nccl")
+        self.single_device = os.environ.get("PMAF_BENCH_SINGLE_DEVICE") == "1"
+        if self.single_device:
+            self.local_rank = 0
+        self.red_dev = "cuda" if self.backend == "nccl" else "cpu"
+        # PMAF_BENCH_FORCE_DIST=1: torch.distributed + an RCCL communicator even for one rank
+        # -- exercises RCCL and this library's HIP runtime in one process on a 1-GPU box
+        self.force_dist = os.environ.get("PMAF_BENCH_FORCE_DIST") == "1"
+        if self.world != args.gpus:
+            raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s) (WORLD_SIZE): refusing to report a "
+                             "%d-GPU line as a %d-GPU one" % (args.gpus, self.world, self.world, args.gpus))
+        if self.force_dist and self.world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29517")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
+        if self.world > 1 or self.force_dist:
+            import torch                      # before libpmaf_hip.so: one HIP runtime per process
+            import torch.distributed as dist
+            self.dist = dist
+            if self.backend == "nccl":
+                torch.cuda.set_device(self.local_rank)
+                dist.init_process_group("nccl", device_id=torch.device("cuda", self.local_rank))
+            else:
+                dist.init_process_group(self.backend)
+        self.pkg = graft.load_package()
+        self.pkg.load_library()
+        self.n_devices = self.pkg.device_count()
+        if not self.single_device and self.world > self.n_devices:
+            raise SystemExit("bench.py: --gpus %d but hipGetDeviceCount() = %d (set PMAF_BENCH_SINGLE_DEVICE=1 to let "
+                             "several ranks share device 0 in tests)" % (self.world, self.n_devices))
+        self._groups = {}
+
+    def subgroup(self, ranks):
+        """gloo side group over `ranks` (created collectively by ALL ranks, cached)"""
+        key = tuple(ranks)
+        if key not in self._groups:
+            self._groups[key] = self.dist.new_group(ranks=list(ranks), backend="gloo")
+        return self._groups[key]
+
+    def max_over_ranks(self, x):
+        if self.dist is None:
+            return x
+        import torch
+        t = torch.tensor([x], dtype=torch.float64, device=self.red_dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def barrier(self):
+        if self.dist is not None:
+            if self.red_dev == "cuda":
+                import torch
+                torch.cuda.synchronize()
+            self.dist.barrier()
+
+
+def make_exchange_comm(ctx, ranks):
+    """the communicator of the per-tick winner-record all-gather over `ranks` (collective over ALL ranks of the job:
+    the unique id / the fall-back decision travel through the process group). Returns (comm, transport) -- (None, None)
+    on ranks outside `ranks`."""
+    pkg, dist, world = ctx.pkg, ctx.dist, ctx.world
+    n = len(ranks)
+    me = ranks.index(ctx.rank) if ctx.rank in ranks else -1
+    transport = "rccl" if ctx.backend == "nccl" else "host"
+    comm = None
+    if transport == "rccl":
+        # the library's own RCCL communicator; should its bootstrap fail on any rank (environment), every rank falls
+        # back to the host transport over a gloo side group so that the run still measures the exchange
+        import torch
+        ok = 1
+        box = [pkg.PmafComm.unique_id() if ctx.rank == ranks[0] else None]
+        if world > 1:
+            dist.broadcast_object_list(box, src=ranks[0])
+        try:
+            if os.environ.get("PMAF_BENCH_FAIL_RCCL") == "1":   # test hook for the fallback below
+                raise RuntimeError("PMAF_BENCH_FAIL_RCCL")
+            if me >= 0:
+                comm = pkg.PmafComm.rccl(n, me, box[0], ctx.local_rank)
+        except Exception as e:  # noqa: BLE001
+            sys.stderr.write("rank %d: RCCL communicator failed (%s)\n" % (ctx.rank, e))
+            comm, ok = None, 0
+        flag = torch.tensor([ok], dtype=torch.int32, device=ctx.red_dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            if comm is not None:
+                comm.close()
+                comm = None
+            transport = "host"
+    if transport == "host":
+        side = ctx.subgroup(ranks) if (n != world or ctx.backend == "nccl") else None
+
+        class _Side:  # the few calls torch_host_allgather makes, bound to the side group
+            @staticmethod
+            def get_world_size():
+                return n
+
+            @staticmethod
+            def all_gather_into_tensor(out, t):
+                return dist.all_gather_into_tensor(out, t, group=side)
+        if me >= 0:
+            comm = pkg.PmafComm.host(n, me, pkg.shard.torch_host_allgather(_Side))
+    return comm, (transport if me >= 0 else None)
+
+
+def run_workload(ctx, spec, args, full):
+    """Times one workload on the ranks it uses; every rank of the job calls this (ranks outside spec['ranks'] only
+    take part in the barriers). Returns the record on rank 0 (None elsewhere).
+    spec: config, mode ('replica' | 'shard' | 'c4'), populations, dynamic, total_populations, lanes_per_agent,
+    exchange (bool), min_seconds, min_blocks, steps, warmup."""
+    pkg, dist, world, rank = ctx.pkg, ctx.dist, ctx.world, ctx.rank
+    S = pkg.scenes
+    config, mode = spec["config"], spec["mode"]
+    steps, warmup = spec["steps"], spec["warmup"]
+    ranks = list(range(world))
+    coupled = False
+    scaling = "weak"
+    if mode == "c4":
+        arms = S.dual_arm_scenes()
+        ranks = [0, 1] if world >= 2 else [0]
+        mine = ([ranks.index(rank)] if rank in ranks else []) if world >= 2 else [0, 1]
+        scenes = [arms[a] for a in mine]
+        total_pops = 2
+        scaling = "strong"
+        coupled = True
+        workload = "C4 dual arm"
+    elif mode == "shard":
+        total_pops = spec["total_populations"]
+        if total_pops % world:
+            raise SystemExit("--shard: --total-populations must be a multiple of the number of GPUs")
+        mine = pkg.shard.partition_populations(total_pops, world, rank)
+        scenes = [S.config_scene(config, scene_id=s, dynamic=spec["dynamic"]) for s in mine]
+        scaling = "strong"
+        workload = "%s sharded" % config
+    else:
+        # weak scaling = the SAME work on every GPU: all ranks plan the same scene(s) unless --distinct-scenes
+        # (the seeded scenes differ by +-3 % in tick time, which would read as a scaling loss of the slowest one)
+        P = spec["populations"]
+        first = rank * P if args.distinct_scenes else 0
+        mine = list(range(first, first + P))
+        scenes = [S.config_scene(config, scene_id=s, dynamic=spec["dynamic"]) for s in mine]
+        total_pops = P * world
+        workload = config
+    part = rank in ranks
+    n_part = len(ranks)
+    me = ranks.index(rank) if part else -1
+
+    planner = comm = transport = None
+    exchange = spec["exchange"] and (world > 1 or ctx.force_dist)
+    if exchange:
+        comm, transport = make_exchange_comm(ctx, ranks)   # collective over all ranks
+    rec = {}
+    if part:
+        sc = scenes[0]
+        N, H, n_obs = sc["n_agents"], sc["max_prediction_steps"] - 1, sc["obstacles"].shape[0]
+        P = len(scenes)
+        starts = np.stack([s["start"] for s in scenes])
+        planner = pkg.PmafPlanner(scenes, device=ctx.local_rank, lanes_per_agent=spec["lanes_per_agent"], mgr_init_pos=starts)
+        planner.set_initial_position(starts)
+        obs = np.stack([s["obstacles"] for s in scenes])
+        dt, cg, ws = sc["dt"], sc["cost_gains"], sc["ws_limits"]
+        if comm is not None:
+            planner.attach_comm(comm)
+    # ---- C4: the set-points travel through the peer mailboxes (hipIpc-mapped inboxes, no collective) ----
+    if coupled:
+        if n_part > 1:
+            box = [None] * world
+            dist.all_gather_object(box, planner.peer_export(n_part) if part else None)
+            if part:
+                planner.peer_connect(n_part, me, [box[r] for r in ranks])
+        elif part:
+            planner.peer_connect(1, 0, [planner.peer_export(1)])
+        if part:
+            pkg.shard.couple_dual_arm_on_device(planner, n_part, me, np.stack([a["start"] for a in S.dual_arm_scenes()]))
+    ctx.barrier()
+
+    tick_no = [0]
+    # C3's 500-step rollouts (1 m of travel) reach the goal region once the real agent has advanced ~0.2 m: shorter
+    # episodes keep every timed rollout at its full horizon there
+    episode = min(args.episode, 64) if (args.episode and config == "C3") else args.episode
+
+    def one_tick(o):
+        # stationary workload: restart the episode before the real agent gets
+        # so close to the goal that rollouts stop early (cf_agent.cpp:310)
+        if episode and tick_no[0] % episode == 0:
+            planner.set_initial_position(starts)
+        tick_no[0] += 1
+        return planner.tick(o if spec["dynamic"] else None, dt, cg, ws)
+
+    def sync_all():
+        if part:
+            planner.stop()
+            if comm is not None:
+                planner.winners_wait()
+        ctx.barrier()
+
+    if part:
+        obs0 = obs.copy()
+        planner.tick(None if coupled else obs, dt, cg, ws)  # obstacles resident in HBM from here on
+        tick_no[0] += 1
+        for _ in range(warmup):
+            one_tick(obs)
+        planner.set_profiling(True)
+    sync_all()
+    if part:
+        planner.reset_kernel_stats()
+        planner.exchange_times_us()  # clear
+        if coupled:
+            planner.peer_times_us()
+
+    # ---- timed region: blocks of `steps` ticks, barrier + device sync on both sides of each ----
+    block_s, lat = [], []
+    total_timed, n_blocks, max_blocks = 0.0, 0, 10000
+    while True:
+        blk_lat = np.zeros(steps)
+        t0 = time.perf_counter()
+        if part:
+            for k in range(steps):
+                ta = time.perf_counter()
+                one_tick(obs)
+                blk_lat[k] = time.perf_counter() - ta
+                if spec["dynamic"]:
+                    # moving obstacles: advanced like dynamic_obstacle_node does, put back with the agent at every
+                    # episode start so the workload stays stationary (they would drift out of the scene otherwise)
+                    if episode and tick_no[0] % episode == 0:
+                        obs = obs0.copy()
+                    else:
+                        obs = np.stack([S.advance_live_obstacles(o) for o in obs])
+            planner.stop()
+            if comm is not None:
+                planner.winners_wait()
+            if dist is not None and ctx.red_dev == "cuda":
+                import torch
+                torch.cuda.synchronize()
+        el = ctx.max_over_ranks((time.perf_counter() - t0) if part else 0.0)   # the all-reduce closes the block
+        block_s.append(el)
+        lat.append(blk_lat)
+        total_timed += el
+        n_blocks += 1
+        # same decision on every rank (el is reduced). At least min_blocks blocks, so that the median is one of
+        # several blocks and a single slow block (a clock or scheduling hiccup on the box) cannot move it
+        if (total_timed >= spec["min_seconds"] and n_blocks >= spec["min_blocks"]) or n_blocks >= max_blocks:
+            break
+        sync_all()
+    elapsed = float(np.median(block_s))
+    mine_rec = None
+    if part:
+        lat = np.concatenate(lat)
+        kernel_ms, launches, agent_steps = planner.kernel_stats()
+        cfg = planner.launch_config()
+        ag_us = planner.exchange_times_us() if comm is not None else np.zeros(0)
+        pw, pp = planner.peer_times_us() if coupled else (np.zeros(0), np.zeros(0))
+        # set-point latency of a tick issued on an idle stream (the previous rollout has finished, as in a 100 Hz
+        # control loop): host call -> best index and next set-point on the host. Outside the timed region.
+        idle = np.zeros(0)
+        if full and not (coupled and n_part > 1):
+            idle = np.zeros(100)
+            for k in range(idle.size):
+                planner.stop()
+                ta = time.perf_counter()
+                one_tick(obs)
+                idle[k] = time.perf_counter() - ta
+            planner.stop()
+        mine_rec = dict(tick_us=float(np.median(lat) * 1e6), tick_p99=float(np.percentile(lat, 99) * 1e6),
+                        ag_us=float(np.median(ag_us)) if ag_us.size else None,
+                        ag_p99=float(np.percentile(ag_us, 99)) if ag_us.size else None, ag_n=int(ag_us.size),
+                        kernel_us=kernel_ms / max(launches, 1) * 1e3, steps_per_launch=agent_steps / max(launches, 1),
+                        peer_wait=[float(np.median(pw)), float(np.percentile(pw, 99))] if pw.size else None,
+                        peer_pub=float(np.median(pp)) if pp.size else None, peer_n=int(pw.size),
+                        collective_world=comm.world if comm is not None else None)
+    per_rank = [mine_rec]
+    if dist is not None and world > 1:
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine_rec)
+    ctx.barrier()                        # nobody unmaps an inbox a peer may still store into
+    if part:
+        if coupled:
+            planner.peer_disconnect()
+        if comm is not None:
+            planner.attach_comm(None)
+            comm.close()
+        planner.close()
+    if rank != 0:
+        return None
+
+    used = [r for r in per_rank if r is not None]
+    r0 = used[0]
+    rollouts = N * total_pops * steps
+    value = rollouts / elapsed
+    avg_kernel_s = r0["kernel_us"] * 1e-6
+    bytes_per_launch = P * algorithmic_bytes_per_tick(N, H, n_obs)
+    achieved = bytes_per_launch / avg_kernel_s / 1e9
+    steps_per_launch = r0["steps_per_launch"]
+    kernel_name = kernel_name_of(cfg, n_obs)
+    rec = {
+        "rollouts_per_s": value, "ms_per_tick": elapsed / steps * 1e3, "scaling": scaling, "gpus_used": n_part,
+        "workload": "%s: %d agents x %d-step horizon, %d sphere obstacles + repulsive sentinel, %d population(s) per GPU "
+                    "(%d in the job) on %d GPU(s), %s obstacles, one pmaf_tick per step%s%s"
+                    % (workload, N, H, n_obs - 1, P, total_pops, n_part, "moving" if spec["dynamic"] else "static",
+                       ", winner records all-gathered once per tick (%s)" % ("RCCL" if transport == "rccl" else "host transport")
+                       if comm is not None else "",
+                       ", set-points through the peer mailboxes (%s)" % ("hipIpc-mapped inboxes of the two ranks" if n_part > 1
+                                                                         else "the handle's own inbox") if coupled else ""),
+        "agents": N, "horizon": H, "obstacles": n_obs - 1, "populations_per_gpu": P, "populations_total": total_pops,
+        "h_eff": steps_per_launch / (N * P),
+        "agent_steps_per_s": sum(u["steps_per_launch"] for u in used) * steps / elapsed,
+        "blocks": n_blocks, "block_ticks": steps, "timed_s": total_timed,
+        "block_ms": {"median": elapsed * 1e3, "min": float(np.min(block_s)) * 1e3, "max": float(np.max(block_s)) * 1e3},
+        "tick_latency_us": {"median": r0["tick_us"], "p99": r0["tick_p99"], "per_rank_median": [u["tick_us"] for u in used],
+                            "note": "back-to-back ticks: each call waits for the previous rollout"},
+        "allgather_us": None if comm is None else {
+            "median": r0["ag_us"], "p99": r0["ag_p99"], "n": r0["ag_n"], "per_rank_median": [u["ag_us"] for u in used],
+            "transport": transport, "collective_world": r0["collective_world"],
+            "note": ("device time between the events around ncclAllGather on the exchange stream (includes the "
+                     "wait for the slowest rank); off the rollout's critical path") if transport == "rccl" else
+                    "host transport: wall time of the all-gather callback (gloo), run when the table is asked for"},
+        "header_exchange_us": None if not coupled else {
+            "wait_median": r0["peer_wait"][0] if r0["peer_wait"] else None,
+            "wait_p99": r0["peer_wait"][1] if r0["peer_wait"] else None,
+            "publish_median": r0["peer_pub"], "n": r0["peer_n"],
+            "per_rank_wait_median": [u["peer_wait"][0] if u["peer_wait"] else None for u in used],
+            "note": "peer mailboxes: wait = time the manager kernel of a tick spent waiting for the other arm's header of "
+                    "the previous tick (all the coupling costs the control path), publish = its stores into the peers' "
+                    "inboxes incl. the system-scope fence; device clock; no winners_wait on the tick path"},
+        "kernel": kernel_name, "avg_kernel_us": r0["kernel_us"], "per_rank_kernel_us": [u["kernel_us"] for u in used],
+        "lanes_per_agent": cfg["lanes_per_agent"], "rollout_blocks": cfg["n_blocks"],
+        "algorithmic_bytes_per_launch": bytes_per_launch, "hbm_achieved_gbs": achieved, "hbm_frac": achieved / HBM_PEAK_GBS,
+    }
+    if full:
+        rec["_idle"] = idle
+        rec["_scene"] = sc
+        rec["_P"] = P
+        rec["_transport"] = transport
+        rec["_has_comm"] = comm is not None
+    return rec
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -145,7 +516,7 @@ def main():
     ap.add_argument("--no-exchange", action="store_true", help="N > 1: no winner-record all-gather (independent replicas)")
     ap.add_argument("--lanes-per-agent", type=int, default=0)
     ap.add_argument("--dynamic", action="store_true", help="moving obstacles, re-uploaded every tick")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline time budget (0 = skip)")
+    ap.add_argument("--cpu-seconds", type=float, default=11.0, help="CPU-baseline time budget (0 = skip)")
     ap.add_argument("--flop-ticks", type=int, default=24, help="ticks of the instrumented-oracle flop count (0 = skip)")
     ap.add_argument("--min-blocks", type=int, default=5, help="time at least this many blocks of --steps ticks")
     ap.add_argument("--min-seconds", type=float, default=1.0,
@@ -156,249 +527,81 @@ def main():
     ap.add_argument("--episode", type=int, default=256,
                     help="ticks per episode: the real agent is put back at the start every EPISODE ticks so every "
                          "timed rollout runs its full horizon (stationary workload; 0 = never)")
+    ap.add_argument("--only-headline", action="store_true", help="skip the C1 / C3 / C5-sharded / C4 sub-configurations")
+    ap.add_argument("--sub-steps", type=int, default=0, help="ticks per block of the sub-configurations (default min(steps, 50))")
+    ap.add_argument("--sub-seconds", type=float, default=0.25, help="minimum timed seconds per sub-configuration")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="start the ranks, build the process group and the exchange communicator, all-gather through it "
+                         "once and print the launch plan -- no planner, no GPU work (CPU test of the multi-rank plumbing)")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    dist = None
-    # test hooks for a 1-GPU box: PMAF_BENCH_BACKEND=gloo runs torch's collectives on CPU tensors and the winner
-    # exchange over a host-transport communicator, PMAF_BENCH_SINGLE_DEVICE=1 maps every rank to device 0
-    backend = os.environ.get("PMAF_BENCH_BACKEND", "nccl")
-    if os.environ.get("PMAF_BENCH_SINGLE_DEVICE") == "1":
-        local_rank = 0
-    red_dev = "cuda" if backend == "nccl" else "cpu"
-    # PMAF_BENCH_FORCE_DIST=1: torch.distributed + an RCCL communicator even for one rank
-    # -- exercises RCCL and this library's HIP runtime in one process on a 1-GPU box
-    force_dist = os.environ.get("PMAF_BENCH_FORCE_DIST") == "1"
-    if force_dist and world == 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29517")
-        os.environ.setdefault("RANK", "0")
-        os.environ.setdefault("WORLD_SIZE", "1")
-    if world > 1 or force_dist:
-        import torch
-        import torch.distributed as dist
-        if backend == "nccl":
-            torch.cuda.set_device(local_rank)
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend)
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))
 
-    pkg = graft.load_package()
-    pkg.load_library()
-    S = pkg.scenes
-
-    # ---- workload ----
-    coupling = None
-    scaling = "weak"
-    if args.config == "C4":
-        arms = S.dual_arm_scenes()
-        if world == 2:
-            mine = [rank]
-        elif world == 1:
-            mine = [0, 1]
-        else:
-            raise SystemExit("--config C4 runs on 1 GPU (both arms in one handle) or 2 GPUs (one arm per GPU)")
-        scenes = [arms[a] for a in mine]
-        total_pops = 2
-        scaling = "strong"
-        coupling = pkg.shard.DualArmCoupling(np.stack([s["obstacles"] for s in arms]), 0.1)
-        workload = "C4 dual arm"
-    elif args.shard:
-        total_pops = args.total_populations
-        if total_pops % world:
-            raise SystemExit("--shard: --total-populations must be a multiple of the number of GPUs")
-        mine = pkg.shard.partition_populations(total_pops, world, rank)
-        scenes = [S.config_scene(args.config, scene_id=s, dynamic=args.dynamic) for s in mine]
-        scaling = "strong"
-        workload = "%s sharded" % args.config
-    else:
-        # weak scaling = the SAME work on every GPU: all ranks plan the same scene(s) unless --distinct-scenes
-        # (the seeded scenes differ by +-3 % in tick time, which would read as a scaling loss of the slowest one)
-        first = rank * args.populations if args.distinct_scenes else 0
-        mine = list(range(first, first + args.populations))
-        scenes = [S.config_scene(args.config, scene_id=s, dynamic=args.dynamic) for s in mine]
-        total_pops = args.populations * world
-        workload = args.config
-    sc = scenes[0]
-    N, H, n_obs = sc["n_agents"], sc["max_prediction_steps"] - 1, sc["obstacles"].shape[0]
-    P = len(scenes)
-    starts = np.stack([s["start"] for s in scenes])
-    planner = pkg.PmafPlanner(scenes, device=local_rank, lanes_per_agent=args.lanes_per_agent, mgr_init_pos=starts)
-    planner.set_initial_position(starts)
-    obs = np.stack([s["obstacles"] for s in scenes])
-    dt, cg, ws = sc["dt"], sc["cost_gains"], sc["ws_limits"]
-
-    # ---- the sharded runs' collective: winner records all-gathered once per tick ----
-    comm = None
-    exchange = (world > 1 or force_dist) and not args.no_exchange
-    transport = None
-    if exchange:
-        transport = "rccl" if backend == "nccl" else "host"
-        if transport == "rccl":
-            # the library's own RCCL communicator; should its bootstrap fail on any rank (environment), every rank
-            # falls back to the host transport over a gloo side group so that the run still measures the exchange
-            import torch
-            ok = 1
-            try:
-                if os.environ.get("PMAF_BENCH_FAIL_RCCL") == "1":   # test hook for the fallback below
-                    raise RuntimeError("PMAF_BENCH_FAIL_RCCL")
-                comm = pkg.shard.make_comm(dist, world, rank, backend="rccl", device=local_rank)
-            except Exception as e:  # noqa: BLE001
-                sys.stderr.write("rank %d: RCCL communicator failed (%s)\n" % (rank, e))
-                comm, ok = None, 0
-            flag = torch.tensor([ok], dtype=torch.int32, device=red_dev)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            if int(flag.item()) == 0:
-                if comm is not None:
-                    comm.close()
-                transport = "host"
-                side = dist.new_group(backend="gloo")
-
-                class _Side:  # the few calls torch_host_allgather makes, bound to the gloo group
-                    @staticmethod
-                    def get_world_size():
-                        return world
-
-                    @staticmethod
-                    def all_gather_into_tensor(out, t):
-                        return dist.all_gather_into_tensor(out, t, group=side)
-                comm = pkg.PmafComm.host(world, rank, pkg.shard.torch_host_allgather(_Side))
-        else:
-            comm = pkg.shard.make_comm(dist, world, rank, backend="host", device=local_rank)
-        planner.attach_comm(comm)
-
-    tick_no = [0]
-    arm_pos = [np.stack([a["start"] for a in S.dual_arm_scenes()])] if coupling is not None else None
-
-    def one_tick(o):
-        # stationary workload: restart the episode before the real agent gets
-        # so close to the goal that rollouts stop early (cf_agent.cpp:310)
-        if args.episode and tick_no[0] % args.episode == 0:
-            planner.set_initial_position(starts)
-            if coupling is not None:
-                arm_pos[0] = np.stack([a["start"] for a in S.dual_arm_scenes()])
-        tick_no[0] += 1
-        if coupling is not None:
-            # each arm's repulsive sphere = the other arm's last set-point; with one arm per GPU the set-points
-            # come out of the winner records all-gathered behind the previous tick
-            o = coupling.coupled_obstacles(arm_pos[0])[mine]
-            b = planner.tick(o, dt, cg, ws)
-            if comm is not None:
-                tab = planner.winners_wait()          # [world][P][rec]
-                arm_pos[0] = tab[:, 0, 4:7].copy()
-            else:
-                arm_pos[0] = planner.last_next_pos.copy()
-            return b
-        return planner.tick(o if args.dynamic else None, dt, cg, ws)
-
-    def sync_all():
-        planner.stop()
-        if comm is not None:
-            planner.winners_wait()
+    ctx = Ctx(args)
+    rank, world, dist = ctx.rank, ctx.world, ctx.dist
+    if args.dry_run:
+        who = [(rank, ctx.local_rank, os.getpid())]
+        got = None
         if dist is not None:
-            import torch
-            if red_dev == "cuda":
-                torch.cuda.synchronize()
+            who = [None] * world
+            dist.all_gather_object(who, (rank, ctx.local_rank, os.getpid()))
+            comm, transport = make_exchange_comm(ctx, list(range(world)))
+            got = comm.allgather(np.array([float(rank)])).reshape(-1).tolist()
+            collective_world = comm.world
+            comm.close()
             dist.barrier()
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "n_gpus": world, "ranks": who, "devices_visible": ctx.n_devices,
+                              "transport": transport if got is not None else None,
+                              "collective_world": collective_world if got is not None else None,
+                              "allgather_of_ranks": got}), flush=True)
+        return
+    default_headline = (args.config == "C2" and not args.shard and args.populations == 1 and not args.dynamic
+                        and args.lanes_per_agent == 0)
+    head_spec = dict(config=args.config, mode="c4" if args.config == "C4" else "shard" if args.shard else "replica",
+                     populations=args.populations, dynamic=args.dynamic, total_populations=args.total_populations,
+                     lanes_per_agent=args.lanes_per_agent, exchange=not args.no_exchange, steps=args.steps,
+                     warmup=args.warmup, min_seconds=args.min_seconds, min_blocks=args.min_blocks)
+    head = run_workload(ctx, head_spec, args, full=True)
 
-    def max_over_ranks(x):
-        if dist is None:
-            return x
-        import torch
-        t = torch.tensor([x], dtype=torch.float64, device=red_dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        return float(t.item())
+    subs = {}
+    if default_headline and not args.only_headline:
+        sst = args.sub_steps or min(args.steps, 50)
+        base = dict(populations=1, dynamic=False, total_populations=8, lanes_per_agent=0, exchange=True, steps=sst,
+                    warmup=min(args.warmup, 10), min_seconds=args.sub_seconds, min_blocks=max(5, args.min_blocks))
+        plan = [("C1", dict(base, config="C1", mode="replica")),
+                ("C3", dict(base, config="C3", mode="replica"))]
+        if 8 % world == 0:
+            plan.append(("C5_sharded", dict(base, config="C5", mode="shard")))
+        plan.append(("C4", dict(base, config="C4", mode="c4")))
+        for name, spec in plan:
+            r = run_workload(ctx, spec, args, full=False)
+            if rank == 0:
+                subs[name] = r
+        if rank == 0 and 8 % world != 0:
+            subs["C5_sharded"] = {"skipped": "8 scenes do not divide over %d GPUs" % world}
 
-    obs0 = obs.copy()
-    planner.tick(obs, dt, cg, ws)  # obstacles resident in HBM from here on
-    for _ in range(args.warmup):
-        one_tick(obs)
-    planner.set_profiling(True)
-    sync_all()
-    planner.reset_kernel_stats()
-    planner.exchange_times_us()  # clear
-
-    # ---- timed region: blocks of `steps` ticks, barrier + device sync on both sides of each ----
-    block_s, lat = [], []
-    total_timed, n_blocks, max_blocks = 0.0, 0, 10000
-    while True:
-        blk_lat = np.zeros(args.steps)
-        t0 = time.perf_counter()
-        for k in range(args.steps):
-            ta = time.perf_counter()
-            one_tick(obs)
-            blk_lat[k] = time.perf_counter() - ta
-            if args.dynamic:
-                # moving obstacles: advanced like dynamic_obstacle_node does, put back with the agent at every
-                # episode start so the workload stays stationary (they would drift out of the scene otherwise)
-                if args.episode and tick_no[0] % args.episode == 0:
-                    obs = obs0.copy()
-                else:
-                    obs = np.stack([S.advance_live_obstacles(o) for o in obs])
-        planner.stop()
-        if comm is not None:
-            planner.winners_wait()
-        if dist is not None and red_dev == "cuda":
-            import torch
-            torch.cuda.synchronize()
-        el = max_over_ranks(time.perf_counter() - t0)   # the all-reduce is the closing barrier of the block
-        block_s.append(el)
-        lat.append(blk_lat)
-        total_timed += el
-        n_blocks += 1
-        # same decision on every rank (el is reduced). At least --min-blocks blocks, so that the median is one of
-        # several blocks and a single slow block (a clock or scheduling hiccup on the box) cannot move it
-        if (total_timed >= args.min_seconds and n_blocks >= args.min_blocks) or n_blocks >= max_blocks:
-            break
-        sync_all()
-    elapsed = float(np.median(block_s))
-    lat = np.concatenate(lat)
-    kernel_ms, launches, agent_steps = planner.kernel_stats()
-    cfg = planner.launch_config()
-    ag_us = planner.exchange_times_us() if comm is not None else np.zeros(0)
-    # set-point latency of a tick issued on an idle stream (the previous rollout
-    # has finished, as in a 100 Hz control loop): host call -> best index and
-    # next set-point on the host. Outside the timed region.
-    idle = np.zeros(100)
-    for k in range(idle.size):
-        planner.stop()
-        ta = time.perf_counter()
-        one_tick(obs)
-        idle[k] = time.perf_counter() - ta
-    planner.stop()
-    per_rank_tick_us = [float(np.median(lat) * 1e6)]
-    per_rank_ag_us = [float(np.median(ag_us)) if ag_us.size else None]
-    if dist is not None and world > 1:
-        box = [None] * world
-        dist.all_gather_object(box, (per_rank_tick_us[0], per_rank_ag_us[0]))
-        per_rank_tick_us = [b[0] for b in box]
-        per_rank_ag_us = [b[1] for b in box]
-    if comm is not None:
-        planner.attach_comm(None)
-        comm.close()
-    planner.close()
-
+    line = None
     if rank == 0:
-        rollouts = N * total_pops * args.steps
-        value = rollouts / elapsed
-        avg_kernel_s = kernel_ms / max(launches, 1) * 1e-3
-        bytes_per_launch = P * algorithmic_bytes_per_tick(N, H, n_obs)
-        achieved = bytes_per_launch / avg_kernel_s / 1e9
-        steps_per_launch = agent_steps / max(launches, 1)
-        kernel_name = kernel_name_of(cfg, n_obs)
+        idle, sc, P = head.pop("_idle"), head.pop("_scene"), head.pop("_P")
+        transport, has_comm = head.pop("_transport"), head.pop("_has_comm")
+        N, H, n_obs = head["agents"], head["horizon"], head["obstacles"] + 1
+        kernel_name, avg_kernel_s = head["kernel"], head["avg_kernel_us"] * 1e-6
+        steps_per_launch = head["h_eff"] * N * P
         # exact flop count of this workload from the instrumented oracle
-        fl = measured_flops(pkg, sc, args.flop_ticks) if args.flop_ticks > 0 else {"error": "skipped"}
+        fl = measured_flops(ctx.pkg, sc, args.flop_ticks) if args.flop_ticks > 0 else {"error": "skipped"}
         if "flops_per_agent_step" in fl:
             flops_step, flop_src = fl["flops_per_agent_step"], "measured"
         else:
             M = n_obs - 1   # SURVEY 8(d) estimate as the fall-back
             flops_step, flop_src = 110 + 47 * M + 12 * M + 65 * (M / 4.0), "SURVEY 8(d) estimate (flop count unavailable)"
         flops = flops_step * steps_per_launch
-        # HBM traffic per launch of this kernel from the committed PMC passes
-        # (tools/gpu_prof.sh + tools/traffic_from_pmc.py); PMC counters cannot be
-        # collected from inside the timed run itself
+        # HBM traffic per launch of this kernel from the committed PMC passes (tools/gpu_prof.sh +
+        # tools/traffic_from_pmc.py); PMC counters cannot be collected from inside the timed run itself
         traffic = traffic_src = pmc = None
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
@@ -411,52 +614,42 @@ def main():
         except (OSError, ValueError, KeyError):
             traffic = None
         out = {
-            "metric": "agent_rollouts_per_s", "value": value, "unit": "rollouts/s",
+            "metric": "agent_rollouts_per_s", "value": head["rollouts_per_s"], "unit": "rollouts/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-            "scaling": scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "%s: %d agents x %d-step horizon, %d sphere obstacles + repulsive sentinel, "
-                                   "%d population(s) per GPU (%d in the job), %s obstacles, one pmaf_tick per step%s"
-                                   % (workload, N, H, n_obs - 1, P, total_pops, "moving" if args.dynamic else "static",
-                                      ", winner records all-gathered once per tick (%s)" %
-                                      ("RCCL" if transport == "rccl" else "host transport") if comm is not None else ""),
+            "ms_per_step": head["ms_per_tick"], "higher_is_better": True,
+            "scaling": head["scaling"], "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": head["workload"],
                        "agents": N, "horizon": H, "obstacles": n_obs - 1, "populations_per_gpu": P,
-                       "populations_total": total_pops,
-                       "parallelism": "population-per-gpu x%d (%s)" % (world, "sharded scenes" if scaling == "strong" else
+                       "populations_total": head["populations_total"],
+                       "parallelism": "population-per-gpu x%d (%s)" % (world, "sharded scenes" if head["scaling"] == "strong" else
                                                                       "distinct scenes" if args.distinct_scenes else
                                                                       "same scene on every GPU"),
-                       "collective": None if comm is None else
+                       "collective": None if not has_comm else
                        "%s of %d B winner records per rank per tick, second stream, overlapped with the "
                        "rollout" % ("ncclAllGather" if transport == "rccl" else "host-transport all-gather",
                                     P * (8 + 3 * (H + 1)) * 8),
-                       "lanes_per_agent": cfg["lanes_per_agent"], "rollout_blocks": cfg["n_blocks"],
+                       "collective_world": head["allgather_us"]["collective_world"] if head["allgather_us"] else None,
+                       "devices_visible": ctx.n_devices,
+                       "lanes_per_agent": head["lanes_per_agent"], "rollout_blocks": head["rollout_blocks"],
                        "arithmetic": "f64, hand-expanded IEEE div/sqrt sequences (default policy; bit-identical to "
                                      "the CPU oracle)"},
-            "timing": {"blocks": n_blocks, "block_ticks": args.steps, "timed_s": total_timed,
-                       "block_ms": {"median": elapsed * 1e3, "min": float(np.min(block_s)) * 1e3,
-                                    "max": float(np.max(block_s)) * 1e3},
+            "timing": {"blocks": head["blocks"], "block_ticks": args.steps, "timed_s": head["timed_s"],
+                       "block_ms": head["block_ms"],
                        "note": "value / ms_per_step = MEDIAN block of `steps` ticks (max over ranks per block)"},
-            "agent_steps_per_s": steps_per_launch * world * args.steps / elapsed,
-            "h_eff": steps_per_launch / (N * P),
-            "tick_latency_us": {"median": float(np.median(lat) * 1e6), "p99": float(np.percentile(lat, 99) * 1e6),
-                                "per_rank_median": per_rank_tick_us,
-                                "note": "back-to-back ticks: each call waits for the previous rollout"},
-            "setpoint_latency_us": {"median": float(np.median(idle) * 1e6), "p99": float(np.percentile(idle, 99) * 1e6),
-                                    "note": "tick issued on an idle stream: host call -> best index + next set-point "
-                                            "on the host (the new rollout then runs asynchronously)"},
-            "allgather_us": None if comm is None else {
-                "median": float(np.median(ag_us)) if ag_us.size else None,
-                "p99": float(np.percentile(ag_us, 99)) if ag_us.size else None,
-                "n": int(ag_us.size), "per_rank_median": per_rank_ag_us,
-                "transport": transport,
-                "note": ("device time between the events around ncclAllGather on the exchange stream (includes the "
-                         "wait for the slowest rank); off the rollout's critical path") if transport == "rccl" else
-                        "host transport: wall time of the all-gather callback (gloo), run when the table is asked for"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+            "agent_steps_per_s": head["agent_steps_per_s"],
+            "h_eff": head["h_eff"],
+            "tick_latency_us": head["tick_latency_us"],
+            "setpoint_latency_us": None if not idle.size else {
+                "median": float(np.median(idle) * 1e6), "p99": float(np.percentile(idle, 99) * 1e6),
+                "note": "tick issued on an idle stream: host call -> best index + next set-point "
+                        "on the host (the new rollout then runs asynchronously)"},
+            "allgather_us": head["allgather_us"],
+            "header_exchange_us": head["header_exchange_us"],
+            "roofline": {"bound": "hbm", "achieved": head["hbm_achieved_gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": head["hbm_frac"], "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": kernel_name,
-                         "avg_kernel_us": avg_kernel_s * 1e6,
-                         "algorithmic_bytes_per_launch": bytes_per_launch,
+                         "avg_kernel_us": head["avg_kernel_us"],
+                         "algorithmic_bytes_per_launch": head["algorithmic_bytes_per_launch"],
                          "note": "FP64-VALU/latency-bound ODE integration; HBM fraction is structurally tiny "
                                  "(SURVEY.md 8d): see fp64_valu"},
             "fp64_valu": {"achieved_tflops": flops / avg_kernel_s / 1e12, "peak_tflops": FP64_VALU_PEAK_TF,
@@ -467,8 +660,10 @@ def main():
                           "flop_count": fl,
                           "pmc": pmc, "pmc_source": traffic_src},
         }
+        if subs:
+            out["configs"] = subs
         if args.cpu_seconds > 0 and world == 1:  # reported at N = 1 only
-            out["cpu_baseline"] = cpu_baseline(pkg, sc, args.cpu_seconds, max(1, min(N, os.cpu_count() or 1)))
+            out["cpu_baseline"] = cpu_baseline(args.config if args.config in ("C1", "C2", "C3", "C5") else "C2", args.cpu_seconds)
         else:
             out["cpu_baseline"] = None
         line = json.dumps(out)

@@ -218,9 +218,13 @@ def test_adopting_the_applications_own_nccl_communicator(pmaf, scenes):
 # ---------------------------------------------------------------------------
 # two processes on GPU 0 (host-transport communicator over gloo)
 # ---------------------------------------------------------------------------
-def _setup_worker(rank, world, port):
+def _setup_worker(rank, world, port, multi_gpu=False, comm_ranks=None):
+    """multi_gpu=False: every rank on GPU 0, host-transport communicator over gloo (RCCL refuses two ranks on one
+    device); multi_gpu=True: rank r on GPU r, the library's own RCCL communicator (unique id through gloo).
+    comm_ranks: the ranks the communicator spans (default all)."""
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch  # noqa: F401  (before libpmaf_hip.so: one HIP runtime per process)
     import torch.distributed as dist
     import __graft_entry__ as graft
@@ -228,16 +232,26 @@ def _setup_worker(rank, world, port):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    comm = pkg.shard.make_comm(dist, world, rank, backend="host")
+    comm_ranks = list(range(world)) if comm_ranks is None else comm_ranks
+    comm = None
+    if not multi_gpu:
+        assert comm_ranks == list(range(world))
+        comm = pkg.shard.make_comm(dist, world, rank, backend="host")
+    else:
+        torch.cuda.set_device(rank)
+        box = [pkg.PmafComm.unique_id() if rank == comm_ranks[0] else None]
+        dist.broadcast_object_list(box, src=comm_ranks[0])
+        if rank in comm_ranks:
+            comm = pkg.PmafComm.rccl(len(comm_ranks), comm_ranks.index(rank), box[0], rank)
     return pkg, dist, comm
 
 
-def _pop_worker(rank, world, port, n_scenes, ticks, q):
-    pkg, dist, comm = _setup_worker(rank, world, port)
+def _pop_worker(rank, world, port, n_scenes, ticks, q, multi_gpu=False):
+    pkg, dist, comm = _setup_worker(rank, world, port, multi_gpu)
     mine = pkg.shard.partition_populations(n_scenes, world, rank)
     scs = [pkg.scenes.synthetic_scene(12, 60, 8, 8, s) for s in mine]
     starts = np.stack([s["start"] for s in scs])
-    hip = pkg.PmafPlanner(scs, device=0, mgr_init_pos=starts)
+    hip = pkg.PmafPlanner(scs, device=rank if multi_gpu else 0, mgr_init_pos=starts)
     hip.set_initial_position(starts)
     hip.attach_comm(comm)
     sc = scs[0]
@@ -253,12 +267,12 @@ def _pop_worker(rank, world, port, n_scenes, ticks, q):
     dist.destroy_process_group()
 
 
-def _spawn(target, world, *args):
+def _spawn(target, world, *args, **kw):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=target, args=(r, world, port) + args + (q,)) for r in range(world)]
+    procs = [ctx.Process(target=target, args=(r, world, port) + args + (q,), kwargs=kw) for r in range(world)]
     for p in procs:
         p.start()
     got = [q.get(timeout=280) for _ in range(world)]
@@ -268,13 +282,9 @@ def _spawn(target, world, *args):
     return got
 
 
-@pytest.mark.timeout(400)
-def test_population_sharding_two_ranks_hip_planner(pmaf, oracle, scenes):
-    """4 scenes over 2 ranks, HIP planner + attached exchange on every rank:
-    both ranks end with the same table and it equals the unsharded oracles'"""
-    world, n_scenes, ticks = 2, 4, 6
-    res = dict(_spawn(_pop_worker, world, n_scenes, ticks))
-    np.testing.assert_array_equal(res[0], res[1])
+def _check_population_table(pmaf, oracle, scenes, res, world, n_scenes, ticks):
+    for r in range(1, world):
+        np.testing.assert_array_equal(res[0], res[r])
     cap = 61
     for s in range(n_scenes):
         sc = scenes.synthetic_scene(12, 60, 8, 8, s)
@@ -288,6 +298,114 @@ def test_population_sharding_two_ranks_hip_planner(pmaf, oracle, scenes):
         np.testing.assert_array_equal(rec["path"], paths[b, :n[b]])
         assert rec["cost"] == o.costs()[b]
         np.testing.assert_array_equal(rec["next_pos"], o.real_state()[0])
+
+
+@pytest.mark.timeout(400)
+def test_population_sharding_two_ranks_hip_planner(pmaf, oracle, scenes):
+    """4 scenes over 2 ranks, HIP planner + attached exchange on every rank:
+    both ranks end with the same table and it equals the unsharded oracles'"""
+    world, n_scenes, ticks = 2, 4, 6
+    res = dict(_spawn(_pop_worker, world, n_scenes, ticks))
+    _check_population_table(pmaf, oracle, scenes, res, world, n_scenes, ticks)
+
+
+def _n_gpus(pmaf):
+    return min(pmaf.device_count(), 8)
+
+
+@pytest.mark.timeout(900)
+def test_rccl_population_sharding_n_ranks(pmaf, oracle, scenes):
+    """One rank per GPU on min(hipGetDeviceCount(), 8) GPUs, the library's own
+    RCCL communicator (ncclAllGather over xGMI) carrying the per-tick winner
+    records: 2 scenes per rank, every rank's gathered table equals every other
+    rank's and the per-population oracles. Needs >= 2 GPUs."""
+    world = _n_gpus(pmaf)
+    if world < 2:
+        pytest.skip("needs >= 2 GPUs for an N-rank RCCL communicator (this box has %d); the same worker runs with the "
+                    "host transport in test_population_sharding_two_ranks_hip_planner" % pmaf.device_count())
+    n_scenes, ticks = 2 * world, 6
+    res = dict(_spawn(_pop_worker, world, n_scenes, ticks, multi_gpu=True))
+    _check_population_table(pmaf, oracle, scenes, res, world, n_scenes, ticks)
+
+
+def _dual_peer_worker(rank, world, port, ticks, q, multi_gpu=False):
+    """BASELINE C4, one arm per rank on ranks 0 / 1: set-points through the peer mailboxes (hipIpc), the path table
+    through the 2-rank communicator; further ranks of the job only take part in the rendezvous"""
+    pkg, dist, comm = _setup_worker(rank, world, port, multi_gpu, comm_ranks=[0, 1] if multi_gpu else None)
+    arms = pkg.scenes.dual_arm_scenes(64, 150, 24)
+    out, tab = None, None
+    hip = None
+    if rank < 2:
+        sc = arms[rank]
+        hip = pkg.PmafPlanner(sc, device=rank if multi_gpu else 0, mgr_init_pos=sc["start"])
+        hip.set_initial_position(sc["start"])
+        hip.attach_comm(comm)
+    box = [None] * world
+    dist.all_gather_object(box, hip.peer_export(2) if hip is not None else None)
+    if hip is not None:
+        hip.peer_connect(2, rank, box[:2])
+        pkg.shard.couple_dual_arm_on_device(hip, 2, rank, np.stack([a["start"] for a in arms]))
+    dist.barrier()
+    if hip is not None:
+        out = []
+        for t in range(ticks):
+            hip.tick(None, sc["dt"], sc["cost_gains"], sc["ws_limits"])
+            out.append(hip.real_state()[0].copy())
+        hip.stop()
+        tab = hip.winners_wait().copy()
+        out = np.stack(out)
+    q.put((rank, (out, tab)))
+    dist.barrier()
+    if hip is not None:
+        hip.peer_disconnect()
+        hip.attach_comm(None)
+        hip.close()
+    if comm is not None:
+        comm.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_rccl_c4_one_arm_per_gpu(pmaf, oracle, scenes):
+    """BASELINE config 4 on real GPUs: arm r on GPU r (ranks 0 / 1 of a
+    min(hipGetDeviceCount(), 8)-rank job), set-points through hipIpc-mapped peer
+    inboxes over xGMI, winner records through a 2-rank RCCL communicator; equals
+    two coupled oracles bit for bit. Needs >= 2 GPUs (the one-GPU form of the same
+    worker: tests/test_peer_gpu.py)."""
+    world = _n_gpus(pmaf)
+    if world < 2:
+        pytest.skip("needs >= 2 GPUs (this box has %d); two processes on one GPU run the same protocol in "
+                    "tests/test_peer_gpu.py::test_peer_mailbox_two_processes_ipc_one_arm_per_rank" % pmaf.device_count())
+    _check_dual_peer(pmaf, oracle, scenes, dict(_spawn(_dual_peer_worker, world, 200, multi_gpu=True)), world, 200)
+
+
+@pytest.mark.timeout(400)
+def test_c4_one_arm_per_rank_peer_mailboxes_two_ranks_one_gpu(pmaf, oracle, scenes):
+    """the worker of test_rccl_c4_one_arm_per_gpu with both ranks on GPU 0 (host-transport communicator for the path
+    table, hipIpc between the two processes for the set-points)"""
+    _check_dual_peer(pmaf, oracle, scenes, dict(_spawn(_dual_peer_worker, 2, 200)), 2, 200)
+
+
+def _check_dual_peer(pmaf, oracle, scenes, res, world, ticks):
+    arms = scenes.dual_arm_scenes(64, 150, 24)
+    oras = []
+    for s in arms:
+        o = oracle.OraclePlanner(s, mgr_init_pos=s["start"])
+        o.set_initial_position(s["start"])
+        oras.append(o)
+    coupling = pmaf.shard.DualArmCoupling(np.stack([s["obstacles"] for s in arms]), 0.1)
+    pos = np.stack([s["start"] for s in arms])
+    for t in range(ticks):
+        obs = coupling.coupled_obstacles(pos)
+        for i, o in enumerate(oras):
+            o.tick(obs[i], arms[i]["dt"], arms[i]["cost_gains"], arms[i]["ws_limits"])
+        pos = np.stack([o.real_state()[0] for o in oras])
+        for r in (0, 1):
+            np.testing.assert_array_equal(res[r][0][t], pos[r])
+    np.testing.assert_array_equal(res[0][1], res[1][1])
+    np.testing.assert_array_equal(res[0][1][:, 0, 4:7], pos)
+    for r in range(2, world):
+        assert res[r] == (None, None)
 
 
 def _dual_worker(rank, world, port, ticks, q):
@@ -417,6 +535,35 @@ def test_bench_multi_rank_modes_on_one_gpu(args, n_ranks):
     assert out["allgather_us"]["n"] >= 12 and out["allgather_us"]["median"] is not None
     assert len(out["tick_latency_us"]["per_rank_median"]) == n_ranks
     assert out["h_eff"] == out["config"]["horizon"]
+
+
+@pytest.mark.timeout(900)
+def test_bench_self_spawns_its_ranks_and_reports_every_config():
+    """`python bench.py --gpus 2` WITHOUT a launcher (two ranks sharing GPU 0 under the test hooks): the script starts
+    its ranks itself, the line says n_gpus = 2 and carries the C1 / C3 / C5-sharded / C4 sub-records -- C4 with the
+    set-points through the peer mailboxes (header_exchange_us, no winners_wait on the tick path)"""
+    import json
+    import subprocess
+    env = dict(os.environ, PMAF_BENCH_BACKEND="gloo", PMAF_BENCH_SINGLE_DEVICE="1")
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "3",
+                        "--min-seconds", "0.05", "--sub-seconds", "0.02", "--flop-ticks", "0"],
+                       capture_output=True, text=True, timeout=800, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["n_gpus"] == 2 and out["config"]["collective_world"] == 2
+    cfgs = out["configs"]
+    assert set(cfgs) == {"C1", "C3", "C5_sharded", "C4"}
+    for name, c in cfgs.items():
+        assert c["rollouts_per_s"] > 0 and c["blocks"] >= 5 and c["h_eff"] == c["horizon"], name
+        assert c["allgather_us"]["n"] >= 10 and c["kernel"].startswith("k_rollout")
+    assert cfgs["C5_sharded"]["populations_total"] == 8 and cfgs["C5_sharded"]["populations_per_gpu"] == 4
+    hx = cfgs["C4"]["header_exchange_us"]
+    assert hx["n"] >= 50 and hx["wait_median"] is not None and cfgs["C4"]["gpus_used"] == 2
+    # a launcher whose world differs from --gpus is refused
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"],
+                         capture_output=True, text=True, timeout=120, env=dict(env, WORLD_SIZE="1", RANK="0"), cwd=ROOT)
+    assert bad.returncode != 0 and "refusing" in bad.stderr
 
 
 @pytest.mark.timeout(600)

@@ -143,7 +143,8 @@ __device__ __forceinline__ void rollout_w64_body(const DevView &D, const CostPar
       F.x = attr ? Fa.x : F.x; F.y = attr ? Fa.y : F.y; F.z = attr ? Fa.z : F.z;
       acc = F;
       double az = sqn(F);
-      if ((C.mass != 1.0) || (az >= C.zacc_gt)) {
+      // (wave-uniform and rare: __any makes the branch a scalar one the block placement can move out of line)
+      if (PMAF_RARE(__any((C.mass != 1.0) || (az >= C.zacc_gt)))) {
         if (C.mass != 1.0) { acc = F / C.mass; az = sqn(acc); }
         if (az >= C.zacc_gt) acc = acc * (13.0 / __builtin_sqrt(az));  // norm(acc) > 13.0
       }

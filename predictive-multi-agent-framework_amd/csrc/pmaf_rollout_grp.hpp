@@ -132,10 +132,10 @@ __device__ __forceinline__ void circ_and_scale_grp(bool act, int sub, int grp, i
     const bool in_shell = live && (d < C.shell);
     if (__any(in_shell)) {
       const bool need_latch = in_shell && !((known_bits >> t) & 1u);
-      if (__any(need_latch)) {
+      if (PMAF_RARE(__any(need_latch))) {
         V3 cpos = op;
         const bool srch = need_latch && (type == T_OBST || type == T_GOALOBST);
-        if (__any(srch)) cpos = closest_other_grp<LPA, TILES, MATH>(srch, t, sub, grp, M, O);
+        if (PMAF_RARE(__any(srch))) cpos = closest_other_grp<LPA, TILES, MATH>(srch, t, sub, grp, M, O);
         if (need_latch) {
           V3 rot = calc_rot_vec_c<MATH>(type, p, goal, n_obs, op, cpos, mk(O.qx[t], O.qy[t], O.qz[t]));
           rot_g[i] = rot.x; rot_g[n_obs + i] = rot.y; rot_g[2 * n_obs + i] = rot.z;

@@ -176,6 +176,19 @@ struct SecTimers {};
 #define PMAF_CNT(ST, k, v)
 #endif
 
+// Block layout of the step (round 3): a lone in-order wave pays for every TAKEN branch with an instruction-fetch
+// restart, and the compiler lays a conditional block out inline (branch taken to skip it) unless it knows the block is
+// cold. The step's rare blocks (first-contact latch, acceleration clamp, lists of more than 16 terms, nothing inside
+// the shell) are therefore wave-uniform conditions marked unlikely: the common path falls through.
+#ifndef PMAF_EXPECT
+#define PMAF_EXPECT 1
+#endif
+#if PMAF_EXPECT
+#define PMAF_RARE(c) __builtin_expect(!!(c), 0)
+#else
+#define PMAF_RARE(c) (c)
+#endif
+
 template <int TILES>
 struct LaneObstacles {
   V3 p[TILES], v[TILES];
@@ -306,7 +319,7 @@ __device__ __forceinline__ void circ_and_scale_w64(int lane, V3 p, V3 v, double 
     any_in = any_in || in_t[t];
   }
   PMAF_SEC(ST, 1);
-  if (!__any(any_in) || (ablate & 4)) return;  // nothing inside the shell: F stays 0, scale stays 1
+  if (PMAF_RARE(!__any(any_in) || (ablate & 4))) return;  // nothing inside the shell: F stays 0, scale stays 1
   PMAF_CNT(ST, 0, 1);
 
   // ---- first contact: latch the rotation vector (:92-96, rare) ----
@@ -314,7 +327,7 @@ __device__ __forceinline__ void circ_and_scale_w64(int lane, V3 p, V3 v, double 
   for (int t = 0; t < TILES; t++) {
     const int i = t * 64 + lane;
     const bool need_latch = in_t[t] && !((known_bits >> t) & 1u);
-    if (__any(need_latch)) {
+    if (PMAF_RARE(__any(need_latch))) {
       V3 cpos = O.p[t];
       if (type == T_OBST || type == T_GOALOBST) cpos = closest_other_w64<TILES, MATH>(need_latch, t, lane, M, O);
       if (need_latch) {
@@ -373,6 +386,23 @@ __device__ __forceinline__ void circ_and_scale_w64(int lane, V3 p, V3 v, double 
     e[0] = 0.0; e[1] = 0.0; e[2] = 0.0;
   }
   PMAF_CNT(ST, 1, count);
+#ifndef PMAF_SUM_HOIST
+#define PMAF_SUM_HOIST 3
+#endif
+#ifndef PMAF_SUM_FMAC1
+#define PMAF_SUM_FMAC1 0
+#endif
+  // The first chunk of the list is fetched HERE, in front of the attractor-scaling chain (round 3): issued behind the
+  // compaction stores (a wave's DS instructions execute in order), its LDS round trip runs under that chain instead
+  // of in front of the sum, where the disassembly showed ds_read / s_waitcnt lgkmcnt(0) back to back. (An empty list
+  // reads the all-zero padding chunk: the sum below needs no `count > 0` test for it.)
+  constexpr bool HOIST1 = DPPSUM && TILES == 1 && (PMAF_SUM_HOIST & 1);
+  constexpr bool HOISTN = DPPSUM && TILES >= 2 && (PMAF_SUM_HOIST & 2);
+  double e_first = 0.0;
+  if (HOIST1 || HOISTN) {
+    wave_lds_fence();
+    e_first = clist[lane];
+  }
 
   // ---- attractorForceScaling value (:212-226), branchless ----
   double sc;
@@ -389,6 +419,9 @@ __device__ __forceinline__ void circ_and_scale_w64(int lane, V3 p, V3 v, double 
     } else {
       bi = wave_min64_i(cand ? best_i : 0x7fffffff);
     }
+    // (the chunk fetched above is not touched before the closest-obstacle reduction is through: the scheduler, left
+    // alone, starts the sum ten instructions behind the ds_read and waits for it there)
+    if (HOIST1 && (PMAF_SUM_HOIST & 4)) asm("" : "+v"(e_first) : "s"(bi));
     const bool stall = (dot(g, v) <= 0.0) && (zv < C.zv09_lt) && (dg > 0.15);  // norm(v) < vmax - 0.1 vmax
     // (shell == 0: nothing is ever inside it, bi stays "none" and w is discarded)
     const double w1 = 1 - portable_exp<MATH>(-MT::div_pos(MT::sqrt_pos(m), C.shell), EK);  // m >= 1e-5
@@ -418,7 +451,7 @@ __device__ __forceinline__ void circ_and_scale_w64(int lane, V3 p, V3 v, double 
   // feeds a single v_add_f64 that advances all three component sums at once (row 0 sums x, row 1 y, row 2 z). The
   // moves do not depend on the accumulator, so the dependent chain is ONE add per entry; entries past the end of the
   // list are +0.0 (exact no-op; skipping them in groups of 4 or 8 costs more in branches than the adds: measured).
-  wave_lds_fence();
+  if (!(HOIST1 || HOISTN)) wave_lds_fence();
   {
     double acc = 0.0;
     if (TILES >= 2) {
@@ -430,10 +463,14 @@ __device__ __forceinline__ void circ_and_scale_w64(int lane, V3 p, V3 v, double 
     // Measured (one box): C3 1248.7 -> 1230.9 us, 200 / 256 obstacles 1270 -> 1197 / 1382 -> 1297 us per launch; the
     // one-slot kernel gains nothing (C2 279.1 vs 279.2 us: the block cannot be interleaved with the scaling chain) and
     // keeps the compiler-visible builtin form.
+    // Round 3: the next chunk's ds_read is in flight while this chunk is added (one register pair more).
     double one = 1.0;
     asm volatile("" : "+v"(one));
+    double e = HOISTN ? e_first : 0.0;
     for (int c16 = 0; c16 < count; c16 += 16) {
-      const double e = clist[(c16 << 2) + lane];
+      double en = 0.0;
+      if (HOISTN) en = clist[((c16 + 16) << 2) + lane];   // (behind the last chunk: padding / scratch, never used)
+      else e = clist[(c16 << 2) + lane];
 #define PMAF_FM(K) "v_fmac_f64_dpp %0, %1, %2 row_newbcast:" #K " row_mask:0xf bank_mask:0xf\n\t"
       asm volatile("s_nop 4\n\t"
                    PMAF_FM(0) PMAF_FM(1) PMAF_FM(2) PMAF_FM(3) PMAF_FM(4) PMAF_FM(5) PMAF_FM(6) PMAF_FM(7)
@@ -441,15 +478,50 @@ __device__ __forceinline__ void circ_and_scale_w64(int lane, V3 p, V3 v, double 
                    "s_nop 1"
                    : "+v"(acc) : "v"(e), "v"(one));
 #undef PMAF_FM
+      if (HOISTN) e = en;
     }
+    } else {
+#define PMAF_BC(K) acc = acc + __builtin_amdgcn_update_dpp(e, e, 0x150 + K, 0xf, 0xf, true);
+#define PMAF_BC16 PMAF_BC(0) PMAF_BC(1) PMAF_BC(2) PMAF_BC(3) PMAF_BC(4) PMAF_BC(5) PMAF_BC(6) PMAF_BC(7) \
+                  PMAF_BC(8) PMAF_BC(9) PMAF_BC(10) PMAF_BC(11) PMAF_BC(12) PMAF_BC(13) PMAF_BC(14) PMAF_BC(15)
+    if (HOIST1) {
+      // the first chunk unconditionally, in the block of the scaling chain (its 16 dependent adds interleave with that
+      // chain's instructions; no branch, no loop for the common list of <= 16 terms); longer lists continue in a loop
+#if PMAF_SUM_FMAC1
+      {
+        // round 3: move + add fused here too (v_fmac_f64_dpp acc += row_newbcast:k(e) * 1.0, exact) -- as SIXTEEN separate
+        // statements, so that the scheduler still interleaves them with the scaling chain (the single block of the
+        // multi-slot kernels could not be, which is why the fused form did not pay here in round 2). Hazards: the DPP
+        // source e comes out of the ds_read, not out of a VALU instruction (2 wait states otherwise; the s_nop in front
+        // of the first one covers a copy the register allocator might place there), EXEC is only written by SALU
+        // instructions on this path (a VALU write would need 5).
+        double one = 1.0;
+        asm volatile("" : "+v"(one));
+        double e = e_first;
+        asm volatile("s_nop 1" : "+v"(e));
+#define PMAF_FM1(K) asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:" #K " row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(e), "v"(one));
+        PMAF_FM1(0) PMAF_FM1(1) PMAF_FM1(2) PMAF_FM1(3) PMAF_FM1(4) PMAF_FM1(5) PMAF_FM1(6) PMAF_FM1(7)
+        PMAF_FM1(8) PMAF_FM1(9) PMAF_FM1(10) PMAF_FM1(11) PMAF_FM1(12) PMAF_FM1(13) PMAF_FM1(14) PMAF_FM1(15)
+#undef PMAF_FM1
+      }
+#else
+      { const double e = e_first; PMAF_BC16 }
+#endif
+      // (keeps the rest of the scaling chain in THIS block, in front of the rare loop: left alone the compiler sinks
+      // it behind the loop, where it can no longer interleave with the 16 dependent adds)
+      if (PMAF_SUM_HOIST & 8) asm volatile("" : : "v"(sc), "v"(acc));
+      for (int c16 = 16; PMAF_RARE(c16 < count); c16 += 16) {
+        const double e = clist[(c16 << 2) + lane];
+        PMAF_BC16
+      }
     } else {
     for (int c16 = 0; c16 < count; c16 += 16) {
       const double e = clist[(c16 << 2) + lane];
-#define PMAF_BC(K) acc = acc + __builtin_amdgcn_update_dpp(e, e, 0x150 + K, 0xf, 0xf, true);
-      PMAF_BC(0) PMAF_BC(1) PMAF_BC(2) PMAF_BC(3) PMAF_BC(4) PMAF_BC(5) PMAF_BC(6) PMAF_BC(7)
-      PMAF_BC(8) PMAF_BC(9) PMAF_BC(10) PMAF_BC(11) PMAF_BC(12) PMAF_BC(13) PMAF_BC(14) PMAF_BC(15)
-#undef PMAF_BC
+      PMAF_BC16
     }
+    }
+#undef PMAF_BC16
+#undef PMAF_BC
     }
     F = mk(readlane_d(acc, 0), readlane_d(acc, 16), readlane_d(acc, 32));
   }

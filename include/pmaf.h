@@ -401,6 +401,12 @@ int pmaf_reset_kernel_stats(pmaf_planner *h);
 int pmaf_get_launch_config(pmaf_planner *h, int32_t *lanes_per_agent,
                            int32_t *n_blocks, int32_t *lds_bytes);
 
+/* Measurement tooling (tools/slackprof): from now on the handle's rollout launches run `kernel_name` out of the code
+ * object file at `code_object_path` (same arguments, grid and LDS as the built-in wave-per-agent kernel: the product
+ * kernel's own assembly with delay instructions inserted); NULL path = back to the built-in kernels. Wave-per-agent
+ * handles only. */
+int pmaf_debug_external_rollout(pmaf_planner *h, const char *code_object_path, const char *kernel_name);
+
 /* Self-test of the device arithmetic the parity argument rests on: evaluates
  * op over n elements ON THE GPU (0: a/b, 1: sqrt(a), 2: the kernels' portable exp(a), 3: a*b,
  * 4: a+b; 5: the kernels' guarded sqrt, 6: guarded divide, 7 / 8: vector /

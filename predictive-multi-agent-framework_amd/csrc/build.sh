@@ -27,7 +27,7 @@ mkdir -p "$OBJ"
 # kept next to the library. The group kernel's throughput rests on TWO waves per
 # SIMD (<= 256 VGPRs; it sits at ~252, and one innocent-looking variant landed
 # on 268: occupancy 1, +50 % time), so tests/test_abi.py checks the record.
-KFLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -mllvm -amdgpu-sched-strategy=max-ilp \
+KFLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -mllvm -amdgpu-sched-strategy=max-ilp -mllvm -amdgpu-atomic-optimizer-strategy=None \
   -Wall -Wno-unused-function -Rpass-analysis=kernel-resource-usage ${PMAF_EXTRA_FLAGS} ${PMAF_EXTRA_KFLAGS}"   # PMAF_EXTRA_KFLAGS: kernel objects only
 HFLAGS="-O2 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function -D__HIP_PLATFORM_AMD__ -I$ROCM/include ${PMAF_EXTRA_FLAGS}"
 

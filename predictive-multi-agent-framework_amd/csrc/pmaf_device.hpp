@@ -338,6 +338,11 @@ __device__ __forceinline__ ObsTab carve_obstab(double *base, int n_obs) {
 }
 
 // ---- cross-lane helpers -------------------------------------------------
+// wave votes straight on the predicate (round 3): HIP's __any / __ballot take an int, and the bool -> int -> "!= 0"
+// round trip stays in the code as v_cndmask + v_cmp_ne_u32 per vote (seen in the step loop's disassembly); for a lone
+// wave every instruction is an issue slot
+__device__ __forceinline__ unsigned long long wave_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+__device__ __forceinline__ bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
 __device__ __forceinline__ double readlane_d(double v, int lane) {
   int lo = __double2loint(v), hi = __double2hiint(v);
   lo = __builtin_amdgcn_readlane(lo, lane);

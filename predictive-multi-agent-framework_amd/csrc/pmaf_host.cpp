@@ -62,6 +62,8 @@ struct pmaf_planner {
   bool dpp_sum = true;         // w64 kernels: ordered force sum by the DPP chain (M > 20) or LDS batches
   int n_blocks = 0;
   size_t lds_rollout = 0, lds_manager = 0;
+  hipModule_t ext_mod = nullptr;       // pmaf_debug_external_rollout: a rollout kernel loaded from a code object file
+  hipFunction_t ext_fn = nullptr;
   hipStream_t stream = nullptr;
   hipEvent_t ev_mgr = nullptr;
   uint64_t mailbox_seq = 0;     // sequence number of the last pmaf_tick (mailbox entry 11)
@@ -280,7 +282,16 @@ static void launch_rollout(pmaf_planner *h) {
   const int M = h->D.n_obs - 1;
   const int tiles64 = (M >= 62 && M <= 64) ? 2 : (M + 63) / 64;
   bool ok;
-  if (h->lpa == 64 && tiles64 <= 4 && !h->force_generic)
+  if (h->ext_fn) {
+    // measurement tooling (tools/slackprof): the same launch with a kernel out of an external code object -- the
+    // product kernel's own assembly with delay instructions inserted; events as marker packets around it
+    void *args[] = {(void *)&h->D, (void *)&h->cp};
+    if (e0) HIP_CHECK(hipEventRecord(e0, h->stream));
+    HIP_CHECK(hipModuleLaunchKernel(h->ext_fn, (unsigned)h->D.N, (unsigned)h->D.P, 1, 64, 1, 1, (unsigned)h->lds_rollout,
+                                    h->stream, args, nullptr));
+    if (e1) HIP_CHECK(hipEventRecord(e1, h->stream));
+    ok = true;
+  } else if (h->lpa == 64 && tiles64 <= 4 && !h->force_generic)
     // ordered force sum: DPP chain from ~20 field obstacles up (lists long enough to need several LDS round trips),
     // LDS batches below (pmaf_rollout_w64.hpp, tools/msweep.py)
     ok = pmaf_k_launch_w64(h->D, h->cp, tiles64, h->math, h->dpp_sum, h->lds_rollout, h->stream, e0, e1);
@@ -679,7 +690,8 @@ int pmaf_create(const pmaf_params *prm, pmaf_planner **out) {
       h->lds_rollout = sizeof(double) * (off + (64 * 4 + 8 + 64) * 4 + 8 * 4);
     }
     // table | known flags | costs | the tuned real step's list (64 * 4 + 8 + 64 entries of 4 doubles)
-    h->lds_manager = sizeof(double) * (7 * (size_t)n_obs + ((size_t)n_obs + 1) / 2 + (size_t)N + 1 + (64 * 4 + 8 + 64) * 4);
+    // (+ 2: the wave-minimum cell of circ_and_scale_w64 behind the list)
+    h->lds_manager = sizeof(double) * (7 * (size_t)n_obs + ((size_t)n_obs + 1) / 2 + (size_t)N + 1 + (64 * 4 + 8 + 64) * 4 + 2);
     REQUIRE(h->lds_rollout <= 160 * 1024, "pmaf_create: obstacle table does not fit in LDS");
     REQUIRE(h->lds_manager <= 160 * 1024,
             "pmaf_create: n_agents + obstacle table exceed the manager kernel's LDS budget (160 KB: 8 B per agent, 60 B per obstacle)");
@@ -824,6 +836,7 @@ int pmaf_destroy(pmaf_planner *h) {
   detach_comm(h);
   peer_disconnect(h);
   if (h->d_send1) (void)hipFree(h->d_send1);
+  if (h->ext_mod) (void)hipModuleUnload(h->ext_mod);
   for (void *p : h->allocs) (void)hipFree(p);
   for (void *p : h->scratch) (void)hipFree(p);
   if (h->h_out) (void)hipHostFree(h->h_out);
@@ -1836,6 +1849,20 @@ int pmaf_debug_math(int32_t op, int32_t n, const double *a, const double *b, dou
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipMemcpy(out, dout, sizeof(double) * n, hipMemcpyDeviceToHost));
     (void)hipFree(da); (void)hipFree(db); (void)hipFree(dout);
+  });
+}
+
+int pmaf_debug_external_rollout(pmaf_planner *h, const char *code_object_path, const char *kernel_name) {
+  return guarded([&] {
+    REQUIRE(h, "pmaf_debug_external_rollout: NULL handle");
+    h->use_device();
+    sync(h);
+    if (h->ext_mod) { (void)hipModuleUnload(h->ext_mod); h->ext_mod = nullptr; h->ext_fn = nullptr; }
+    if (!code_object_path) return;
+    REQUIRE(kernel_name, "pmaf_debug_external_rollout: kernel name required");
+    REQUIRE(h->lpa == 64, "pmaf_debug_external_rollout: wave-per-agent launches only (grid N x P, one wave per block)");
+    HIP_CHECK(hipModuleLoad(&h->ext_mod, code_object_path));
+    HIP_CHECK(hipModuleGetFunction(&h->ext_fn, h->ext_mod, kernel_name));
   });
 }
 

@@ -74,11 +74,11 @@ __global__ __launch_bounds__(64) void k_rollout_grp(DevView D, CostParams CP) {
   const double k_attr = D.k_attr[pa], k_circ = D.k_circ[pa], k_repel = D.k_repel[pa], k_damp = D.k_damp[pa];
   double *path = D.paths + pa * (size_t)D.cap * 3;
   const double zsent_lt = D.zsent_lt[pop];
-  const bool sent_reachable = __any(sentinel_reachable(p, sent_p, sent_v, zsent_lt, C, D.cap));  // wave-uniform
+  const bool sent_reachable = wave_any(sentinel_reachable(p, sent_p, sent_v, zsent_lt, C, D.cap));  // wave-uniform
   bool moving = false;
 #pragma unroll
   for (int t = 0; t < TILES; t++) moving = moving || !(O.v[t].x == 0.0 && O.v[t].y == 0.0 && O.v[t].z == 0.0);
-  moving = __any(moving);
+  moving = wave_any(moving);
   bool advance = true;
 
   int clist_off = 7 * n_obs + (n_obs + 1) / 2;
@@ -101,14 +101,14 @@ __global__ __launch_bounds__(64) void k_rollout_grp(DevView D, CostParams CP) {
   const bool younger = ((lin_block / (unsigned)D.n_simds) & 1u) != 0u;
   while (true) {
     const bool run = active && (dg > 0.1) && (n < D.cap);  // B/src/cf_agent.cpp:310-311, per agent
-    if (!__any(run)) break;
+    if (!wave_any(run)) break;
     unsigned long long clk = 0ull;
     if (shared_simd) clk = wall_clock64();
     const bool gate = !(dg < C.approach || (zv < C.zvhalf_lt && z_init < C.zinit_lt));  // :315-317
     const V3 verr = attractor_velocity_error<MATH>(v, g, C, k_attr, k_damp);
     V3 F = mk(0.0, 0.0, 0.0);
     double scale = 1.0;
-    if (__any(run && gate))
+    if (wave_any(run && gate))
       circ_and_scale_grp<LPA, TILES, MATH>(run && gate, sub, grp, type, p, v, zv, goal, g, dg, C, k_circ, n_obs, rot_g,
                                      known_bits, O, clist, lane_min, F, scale);
     V3 new_pos;

@@ -107,7 +107,7 @@ __device__ __forceinline__ void rollout_w64_body(const DevView &D, const CostPar
   bool moving = false;  // any field obstacle with a non-zero (or NaN) velocity component
 #pragma unroll
   for (int t = 0; t < TILES; t++) moving = moving || !(O.v[t].x == 0.0 && O.v[t].y == 0.0 && O.v[t].z == 0.0);
-  moving = __any(moving);
+  moving = wave_any(moving);
   bool advance = true;
   V3 repel = mk(0.0, 0.0, 0.0);  // repelForce of the coming step (depends on the step's start state only)
   if (sent_reachable) repel = sentinel_repel(p, C, k_repel, sent_p, sent_r, zsent_lt);
@@ -123,7 +123,11 @@ __device__ __forceinline__ void rollout_w64_body(const DevView &D, const CostPar
     double scale = 1.0;
     PMAF_SEC(ST, 0);
     // (called with the gate closed too: the sweep's few compares then find no obstacle -- one branch less in the step)
+#ifdef PMAF_ABLATION   // timing experiments only (PMAF_ABLATE=8: no sweep in the multi-slot kernels)
     if (PRE || (gate && !(D.ablate & 8)))
+#else
+    if (PRE || gate)
+#endif
       circ_and_scale_w64<TILES, TYPE, MATH, PRE, DPPSUM>(lane, p, v, zv, goal, g, dg, gn, C, k_circ, n_obs, rot_g, known_bits,
                                                  O, clist, lane_min, F, scale, ST, EK, D.ablate, 0, s_pre, ron_pre,
                                                  gate);
@@ -144,7 +148,7 @@ __device__ __forceinline__ void rollout_w64_body(const DevView &D, const CostPar
       acc = F;
       double az = sqn(F);
       // (wave-uniform and rare: __any makes the branch a scalar one the block placement can move out of line)
-      if (PMAF_RARE(__any((C.mass != 1.0) || (az >= C.zacc_gt)))) {
+      if (PMAF_RARE(wave_any((C.mass != 1.0) || (az >= C.zacc_gt)))) {
         if (C.mass != 1.0) { acc = F / C.mass; az = sqn(acc); }
         if (az >= C.zacc_gt) acc = acc * (13.0 / __builtin_sqrt(az));  // norm(acc) > 13.0
       }
@@ -309,6 +313,10 @@ bool PMAF_CAT(pmaf_k_launch_w64_m, PMAF_W64_MATH)(const DevView &D, const CostPa
   const dim3 g64((unsigned)D.N, (unsigned)D.P), block(64);
 #define PMAF_L(K) hipExtLaunchKernelGGL(K, g64, block, (unsigned)lds, s, e0, e1, 0, D, cp)
   // one slot per lane: both ordered-sum variants (the host picks by obstacle count); two / four slots: DPP only
+#ifdef PMAF_ONLY_W64_1_DPP   // tools/slackprof: a translation unit that holds the C2 kernel alone (same ISA as the product's)
+  if (tiles <= 1 && dppsum) { PMAF_L((k_rollout_w64<1, PMAF_W64_MATH, true>)); return true; }
+  return false;
+#endif
   if (tiles <= 1 && !dppsum) PMAF_L((k_rollout_w64<1, PMAF_W64_MATH, false>));
   else if (tiles <= 1) PMAF_L((k_rollout_w64<1, PMAF_W64_MATH, true>));
   else if (tiles == 2) PMAF_L((k_rollout_w64<2, PMAF_W64_MATH, true>));

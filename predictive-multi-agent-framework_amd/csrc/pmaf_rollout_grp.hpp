@@ -9,7 +9,7 @@
 // reductions by DPP (quad_perm, row_half_mirror, row_mirror) + ds_swizzle.
 // Per-agent values are held replicated in the group's lanes; per-agent control
 // flow (loop guard, gate, scaling cases, agent type) is predicated, with
-// wave-level __any() guards around the expensive regions. Against the w64
+// wave-level wave_any() guards around the expensive regions. Against the w64
 // kernel this divides the redundantly executed per-agent ("scalar") part and
 // the idle lanes of the sweep by 64/LPA, which is what matters once the chip
 // is full of waves (FP64-VALU issue bound).
@@ -59,7 +59,7 @@ __device__ __forceinline__ V3 closest_other_grp(bool srch, int t, int sub, int g
   const int lane = grp * LPA + sub;
   const unsigned long long gmask = ((1ull << LPA) - 1ull) << (grp * LPA);
   V3 cpos = mk(0.0, 0.0, 0.0);
-  unsigned long long pend = __ballot(srch);
+  unsigned long long pend = wave_ballot(srch);
   while (pend) {
     const unsigned long long gp = pend & gmask;
     const bool has = gp != 0ull;
@@ -89,7 +89,7 @@ __device__ __forceinline__ V3 closest_other_grp(bool srch, int t, int sub, int g
     }
     const bool served = has && (lane == L);
     if (served) cpos = cp;
-    pend &= ~__ballot(served);
+    pend &= ~wave_ballot(served);
   }
   return cpos;
 }
@@ -130,12 +130,12 @@ __device__ __forceinline__ void circ_and_scale_grp(bool act, int sub, int grp, i
     const bool live = valid && !skip;
     if (live && d < lane_min) lane_min = d;
     const bool in_shell = live && (d < C.shell);
-    if (__any(in_shell)) {
+    if (wave_any(in_shell)) {
       const bool need_latch = in_shell && !((known_bits >> t) & 1u);
-      if (PMAF_RARE(__any(need_latch))) {
+      if (PMAF_RARE(wave_any(need_latch))) {
         V3 cpos = op;
         const bool srch = need_latch && (type == T_OBST || type == T_GOALOBST);
-        if (PMAF_RARE(__any(srch))) cpos = closest_other_grp<LPA, TILES, MATH>(srch, t, sub, grp, M, O);
+        if (PMAF_RARE(wave_any(srch))) cpos = closest_other_grp<LPA, TILES, MATH>(srch, t, sub, grp, M, O);
         if (need_latch) {
           V3 rot = calc_rot_vec_c<MATH>(type, p, goal, n_obs, op, cpos, mk(O.qx[t], O.qy[t], O.qz[t]));
           rot_g[i] = rot.x; rot_g[n_obs + i] = rot.y; rot_g[2 * n_obs + i] = rot.z;
@@ -150,7 +150,7 @@ __device__ __forceinline__ void circ_and_scale_grp(bool act, int sub, int grp, i
       const V3 cur = current_vector<MATH, true>(type, rv, g, ron, rot);
       const V3 c = MT::div(k_circ, d * d) * cross(nv, cross(cur, nv));
       const bool has_c = in_shell && (vn != 0);
-      const unsigned long long m = __ballot(has_c);
+      const unsigned long long m = wave_ballot(has_c);
       if (has_c) {
         double *e = clist + (size_t)(count + __popcll(m & below)) * 4;
         e[0] = c.x; e[1] = c.y; e[2] = c.z;
@@ -159,11 +159,11 @@ __device__ __forceinline__ void circ_and_scale_grp(bool act, int sub, int grp, i
     }
   }
   const double m = group_min_dpp<LPA>(best_d);
-  if (__any(count > 0)) {
+  if (wave_any(count > 0)) {
     wave_lds_fence();
     // F = ((0 + c_0) + c_1) + ... per group; a group that has run out of terms adds +0.0 (exact no-op)
     // (lanes past their group's last term read the group's all-zero slot)
-    for (int k = 0; __any(k < count); k += 4) {
+    for (int k = 0; wave_any(k < count); k += 4) {
 #pragma unroll
       for (int j = 0; j < 4; j++) {
         const int idx = ((k + j) < count) ? (k + j) : (LPA * TILES);
@@ -176,7 +176,7 @@ __device__ __forceinline__ void circ_and_scale_grp(bool act, int sub, int grp, i
     wave_lds_fence();
   }
   const bool want_scale = act && (sqn(F) >= C.zf_gt);  // norm(F) > 1e-5
-  if (__any(want_scale)) {
+  if (wave_any(want_scale)) {
     const bool cand = (best_i != 0x7fffffff) && (best_d == m);
     const int bi = group_min_dpp_i<LPA>(cand ? best_i : 0x7fffffff);
     const int src = grp * LPA + ((bi == 0x7fffffff) ? 0 : (bi & (LPA - 1)));
@@ -211,7 +211,7 @@ __device__ __forceinline__ void path_cost_terms_grp(int sub, int grp, bool activ
   cost_ws = 0.0;
   path_len = 0.0;
   const unsigned long long gmask = ((1ull << LPA) - 1ull) << (grp * LPA);
-  for (int base = 0; __any(active && base < n); base += LPA) {
+  for (int base = 0; wave_any(active && base < n); base += LPA) {
     const int k = base + sub;
     const bool valid = active && (k < n);
     const bool has_seg = valid && (k > 0);
@@ -225,8 +225,8 @@ __device__ __forceinline__ void path_cost_terms_grp(int sub, int grp, bool activ
     for (int j = 0; j < LPA; j++) path_len += list[j];
     wave_lds_fence();
     const bool out = valid && ((q.x > ws[0]) | (q.x < ws[1]) | (q.y > ws[2]) | (q.y < ws[3]) | (q.z > ws[4]) | (q.z < ws[5]));
-    unsigned long long gm = __ballot(out) & gmask;  // this group's points outside the box, in path order
-    while (__any(gm != 0ull)) {  // rare
+    unsigned long long gm = wave_ballot(out) & gmask;  // this group's points outside the box, in path order
+    while (wave_any(gm != 0ull)) {  // rare
       const int L = gm ? (__ffsll((long long)gm) - 1) : (grp * LPA + sub);
       const V3 ql = shfl_v3(q, L);
       if (gm) ws_cost_add(cost_ws, ql, ws, k_workspace);

@@ -218,7 +218,7 @@ template <int TILES, int MATH>
 __device__ __forceinline__ V3 closest_other_w64(bool need_latch, int t, int lane, int M,
                                                 const LaneObstacles<TILES> &O) {
   V3 cpos = mk(0.0, 0.0, 0.0);
-  unsigned long long pend = __ballot(need_latch);
+  unsigned long long pend = wave_ballot(need_latch);
   while (pend) {
     const int L = __ffsll((long long)pend) - 1;  // wave-uniform
     pend &= pend - 1;
@@ -319,15 +319,38 @@ __device__ __forceinline__ void circ_and_scale_w64(int lane, V3 p, V3 v, double 
     any_in = any_in || in_t[t];
   }
   PMAF_SEC(ST, 1);
-  if (PMAF_RARE(!__any(any_in) || (ablate & 4))) return;  // nothing inside the shell: F stays 0, scale stays 1
+#ifdef PMAF_ABLATION   // timing experiments only (PMAF_ABLATE=4): no in-shell block
+  if (ablate & 4) return;
+#endif
+  if (PMAF_RARE(!wave_any(any_in))) return;  // nothing inside the shell: F stays 0, scale stays 1
   PMAF_CNT(ST, 0, 1);
+#ifndef PMAF_LDS_MIN
+#define PMAF_LDS_MIN 1
+#endif
+  // Round 3: the wave minimum of the lanes' closest distances (attractorForceScaling's min_dist) through ONE LDS cell:
+  // every lane stores the start value, then applies an atomic unsigned-64 minimum with its own distance (non-negative
+  // doubles order like their bit patterns; a minimum is exact and order-independent), and the scaling chain reads the
+  // cell back -- three DS instructions issued here, their latency under the circular terms, instead of the two 6-stage
+  // DPP reductions (12 dependent v_min_u32_dpp + read-backs) in the middle of the step. For a lone wave every
+  // instruction is a 4-cycle issue slot (tools/slackprof.py), whatever unit executes it.
+  constexpr int MIN_CELL = (64 * 4 + 8 + 64) * 4;   // the double right behind the list area (pmaf_host.cpp: lds_rollout / lds_manager)
+  unsigned long long *min_cell = reinterpret_cast<unsigned long long *>(clist + MIN_CELL);
+  // (kernels with long lists only: with the few obstacles of the LDS-batch variant -- C1: nine -- there is not enough
+  // work between the atomic and the read to cover the round trip: C1 136.7 -> 140.6 us, measured)
+  constexpr bool LDSMIN = PMAF_LDS_MIN && DPPSUM;
+  if (LDSMIN) {
+    wave_lds_fence();
+    *reinterpret_cast<double *>(min_cell) = C.shell;   // every lane, same address, same value
+    __hip_atomic_fetch_min(min_cell, (unsigned long long)__double_as_longlong(best_d), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
 
   // ---- first contact: latch the rotation vector (:92-96, rare) ----
 #pragma unroll
   for (int t = 0; t < TILES; t++) {
     const int i = t * 64 + lane;
     const bool need_latch = in_t[t] && !((known_bits >> t) & 1u);
-    if (PMAF_RARE(__any(need_latch))) {
+    if (PMAF_RARE(wave_any(need_latch))) {
       V3 cpos = O.p[t];
       if (type == T_OBST || type == T_GOALOBST) cpos = closest_other_w64<TILES, MATH>(need_latch, t, lane, M, O);
       if (need_latch) {
@@ -346,7 +369,7 @@ __device__ __forceinline__ void circ_and_scale_w64(int lane, V3 p, V3 v, double 
   int count = 0;
 #pragma unroll
   for (int t = 0; t < TILES; t++) {
-    if (TILES > 2 && !__any(in_t[t])) continue;  // no term from this slot (wave-uniform; 2 slots: both in one block)
+    if (TILES > 2 && !wave_any(in_t[t])) continue;  // no term from this slot (wave-uniform; 2 slots: both in one block)
     const V3 rot = mk(O.rx[t], O.ry[t], O.rz[t]);
     const V3 rv = rv_t[t];
     // |rv| is only divided by, and compared with 0: sqrt(z) != 0 <=> z != 0 (for z == 0 the term is discarded, has_c)
@@ -362,7 +385,7 @@ __device__ __forceinline__ void circ_and_scale_w64(int lane, V3 p, V3 v, double 
 #endif
     const bool has_c = in_t[t] && (zrv != 0);   // vel_norm != 0, B/src/cf_agent.cpp:98
     // compact the contributing terms, ascending obstacle index
-    const unsigned long long m = __ballot(has_c);
+    const unsigned long long m = wave_ballot(has_c);
     if (DPPSUM) {
       // row-transposed list: 16 entries per chunk of 64 doubles, [x0..x15 | y0..y15 | z0..z15 | -], so that ONE
       // conflict-free ds_read hands lane 16 r + k component r of entry k (see the sum below); lanes without a term
@@ -410,11 +433,17 @@ __device__ __forceinline__ void circ_and_scale_w64(int lane, V3 p, V3 v, double 
   sc = 1.0;
 #else
   {
-    const double m = wave_min64(best_d);
+    double m;
+    if (LDSMIN) {
+      wave_lds_fence();
+      m = __longlong_as_double((long long)__hip_atomic_load(min_cell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+    } else {
+      m = wave_min64(best_d);
+    }
     const bool cand = (best_i != 0x7fffffff) && (best_d == m);
     int bi;
     if (TILES == 1) {  // obstacle index == lane: lowest candidate lane wins
-      const unsigned long long bm = __ballot(cand);
+      const unsigned long long bm = wave_ballot(cand);
       bi = bm ? (__ffsll((long long)bm) - 1) : 0x7fffffff;
     } else {
       bi = wave_min64_i(cand ? best_i : 0x7fffffff);
@@ -595,7 +624,7 @@ __device__ __forceinline__ void path_cost_terms_w64(int lane, const double *path
     for (int j = 0; j < 64; j++) path_len += list[j];
     wave_lds_fence();
     const bool out = valid && ((q.x > ws[0]) | (q.x < ws[1]) | (q.y > ws[2]) | (q.y < ws[3]) | (q.z > ws[4]) | (q.z < ws[5]));
-    unsigned long long m = __ballot(out);
+    unsigned long long m = wave_ballot(out);
     while (m) {  // rare
       const int L = __ffsll((long long)m) - 1;
       m &= m - 1;

@@ -106,6 +106,7 @@ SYMBOLS = {
     "pmaf_reset_kernel_stats": (C.c_int, [_V]),
     "pmaf_get_launch_config": (C.c_int, [_V, _ip, _ip, _ip]),
     "pmaf_debug_math": (C.c_int, [C.c_int32, C.c_int32, _dp, _dp, _dp]),
+    "pmaf_debug_external_rollout": (C.c_int, [_V, C.c_char_p, C.c_char_p]),
 }
 
 
@@ -491,6 +492,11 @@ class PmafPlanner:
 
     def reset_kernel_stats(self):
         self._chk(self.L.pmaf_reset_kernel_stats(self._h))
+
+    def external_rollout(self, code_object_path, kernel_name=None):
+        """measurement tooling: run the rollout launches out of an external code object (None: built-in again)"""
+        self._chk(self.L.pmaf_debug_external_rollout(
+            self._h, code_object_path.encode() if code_object_path else None, kernel_name.encode() if kernel_name else None))
 
     def launch_config(self):
         a, b, c = C.c_int32(0), C.c_int32(0), C.c_int32(0)

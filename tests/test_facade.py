@@ -84,6 +84,31 @@ def test_facade_node_sequence_matches_oracle(pmaf, oracle, scenes, tmp_path, hip
         oracle.set_exp_mode(0)
 
 
+def test_eigen_branch_api_shape():
+    """The PMAF_USE_EIGEN branch of the facade headers through a compiler. API-SHAPE check only:
+    tests/cpp/eigen_api_check/eigen3/Eigen/Dense declares -- implements nothing of -- the Eigen::Matrix members the
+    facade and a node-style caller use, with Eigen 3.3's documented signatures; `g++ -fsyntax-only` over every facade
+    header, the C++ test drivers and the reference's call forms (node_style_caller.cpp). It pins no numerics and is no
+    substitute for test_facade_compiles_against_real_eigen_if_present (skipped here: no Eigen3 in the image)."""
+    chk = os.path.join(ROOT, "tests", "cpp", "eigen_api_check")
+    base = ["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-Werror", "-DPMAF_USE_EIGEN", "-I" + chk,
+            "-I" + os.path.join(chk, "eigen3"), "-I" + os.path.join(ROOT, "include")]
+    units = [os.path.join(ROOT, "tests", "cpp", "facade_tick.cpp"), os.path.join(ROOT, "tests", "cpp", "consumer_check.cpp"),
+             os.path.join(ROOT, "tools", "plan_task.cpp"), os.path.join(chk, "node_style_caller.cpp")]
+    for u in units:
+        r = subprocess.run(base + [u], capture_output=True)
+        assert r.returncode == 0, u + "\n" + r.stderr.decode()
+    for hdr in ("cf_manager.h", "obstacle.h", "planner_node.h", "setpoint_consumer.h", "ros_messages.h"):
+        r = subprocess.run(base + ["-x", "c++", "-"], input=('#include "bimanual_planning_ros/%s"\n' % hdr).encode(),
+                           capture_output=True)
+        assert r.returncode == 0, hdr + "\n" + r.stderr.decode()
+    # the check bites: a call form Eigen does not offer (a std::vector where the 6-vector is expected) is rejected
+    bad = '#include "bimanual_planning_ros/cf_manager.h"\nint f(ghostplanner::cfplanner::CfManager &m, std::vector<ghostplanner::cfplanner::Obstacle> &o) {\n' \
+          '  return m.evaluateAgents(o, 1, 1, 1, 1, std::vector<double>(6, 0.0)); }\n'
+    r = subprocess.run(base + ["-x", "c++", "-"], input=bad.encode(), capture_output=True)
+    assert r.returncode != 0
+
+
 def test_facade_compiles_against_real_eigen_if_present():
     """the PMAF_USE_EIGEN branch (a ROS box): compile-only, skipped where no
     Eigen3 is installed (this image has none)"""

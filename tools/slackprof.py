@@ -4,15 +4,16 @@ Neither thread trace nor PC sampling is usable on this pool (rocprofv3 --att nee
 not ship; --pc-sampling-beta-enabled: "not supported on any of the agents", profiles/r3_pc_sampling_unavailable.txt),
 so where a lone in-order wave waits is MEASURED the other way round: the product kernel's own assembly (hipcc -S, the
 flags of csrc/build.sh; the assembled code object's disassembly equals the product's instruction for instruction) is
-rebuilt once per instruction of the hot loop with a 64-cycle delay (4 x s_nop 15) in front of that instruction, and run
+rebuilt once per instruction of the hot loop with a delay of 64 issue slots (4 x s_nop 15 = 256 cycles) in front of that instruction, and run
 on the same rollouts through pmaf_debug_external_rollout. Per variant the tool reads the per-agent rollout durations
 (device wall clock, CfAgent::prediction_time_) of the agents that run this loop.
 
-Reading: a wave issues in order. A delay in front of instruction i costs its full 64 cycles per step if the wave was
-issue-bound from there on, and less if instructions at or behind i would have waited anyway for results that were
-issued BEFORE i (the wait absorbs the delay). slack(i) = 64 - measured extra cycles per step is therefore the waiting
-time, downstream of i, on producers upstream of i; where slack drops from one instruction to the next, that instruction
-(or the one it feeds) is where the wave actually waited, by about the size of the drop.
+Reading: a wave issues in order, at most one instruction per issue slot (4 cycles) whatever unit executes it. A delay
+in front of instruction i costs its full 64 slots per step if the wave was issue-bound from there on, and less if
+instructions at or behind i would have waited anyway for results that were issued BEFORE i (the wait absorbs the
+delay). slack(i) = 64 - measured extra slots per step is therefore the waiting time, downstream of i, on producers
+upstream of i; where slack drops from one instruction to the next, that instruction (or the one it feeds) is where the
+wave actually waited, by about the size of the drop.
 
 usage: python tools/slackprof.py <out.txt> [--type random|goal|had|...] [--stride 1] [--config C2]
 """
@@ -34,7 +35,10 @@ CSRC = os.path.join(ROOT, "predictive-multi-agent-framework_amd", "csrc")
 KFLAGS = ("--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -mllvm "
           "-amdgpu-sched-strategy=max-ilp -mllvm -amdgpu-atomic-optimizer-strategy=None --cuda-device-only -S -DPMAF_W64_MATH=2").split()
 TYPE_AGENT = {"had": [0], "goal": [1], "obst": [2], "goalobst": [3], "vel": [4], "random": None}
-DELAY = ["\ts_nop 15\n"] * 4      # 64 cycles
+# `s_nop N` holds the wave for N + 1 ISSUE SLOTS; for a lone wave a slot is 4 cycles (the SIMD's issue arbiter visits a
+# wave every fourth cycle: the first run of this tool measured 103.8 ns per step for these four instructions = 256
+# cycles at 2.47 GHz). All figures below are in issue slots of 4 cycles.
+DELAY = ["\ts_nop 15\n"] * 4      # 64 slots = 256 cycles
 DELAY_CYCLES = 64.0
 
 
@@ -169,13 +173,17 @@ def main():
             os.remove(co)
         sys.stderr.write("%d / %d positions, %.0f s\n" % (min(b + B, len(idx)), len(idx), time.time() - t_start))
     d = np.array([r[1] for r in res]) / H                       # extra ns per step
-    full = np.percentile(d, 98)                                  # ns per step of a fully exposed 64-cycle delay
+    # what 64 slots cost when nothing can absorb them: a second delay right behind a first one at the loop head
+    two = assemble((lambda sv: (open(sv[0], "w").writelines(lines[:h0 + 1] + DELAY + DELAY + lines[h0 + 1:]), sv)[1])(
+        (os.path.join(args.work, "v_two.s"), os.path.join(args.work, "v_two.co"))))
+    full = (run(two)[0] - run(heads[j])[0]) / H                  # ns per step of a fully exposed 64-slot delay
     cyc = d / full * DELAY_CYCLES
     slack = DELAY_CYCLES - cyc
     step_cycles = t_base / H / full * DELAY_CYCLES
-    out.write("# profiled loop: %d instructions; one step = %.1f ns = %.0f cycles (a fully exposed 64-cycle delay costs %.2f ns "
-              "per step => %.2f GHz)\n" % (n0, t_base / H, step_cycles, full, DELAY_CYCLES / full))
-    out.write("# columns: position, extra cycles per step of a 64-cycle delay in front of the instruction, slack = 64 - extra,\n"
+    out.write("# profiled loop: %d instructions in its extent; one step = %.1f ns = %.0f issue slots of 4 cycles (a fully exposed "
+              "64-slot delay costs %.2f ns per step => %.2f GHz); slots per step beyond one per executed instruction = bubbles\n"
+              % (n0, t_base / H, step_cycles, full, 4 * DELAY_CYCLES / full))
+    out.write("# columns: position, extra slots per step of a 64-slot delay in front of the instruction, slack = 64 - extra,\n"
               "#          drop = slack(i) - slack(i+1) (>0: the wave waited about that long at / right behind i), instruction\n")
     drops = []
     for n, ((k, _), c, s) in enumerate(zip(res, cyc, slack)):
@@ -184,10 +192,14 @@ def main():
     order = np.argsort(-np.array(drops))
     out.write("# ---- top 25 waits (largest drops of slack) ----\n")
     for n in order[:25]:
-        out.write("#  pos %3d  drop %5.1f cycles  slack %5.1f -> %5.1f  %s\n"
+        out.write("#  pos %3d  drop %5.1f slots  slack %5.1f -> %5.1f  %s\n"
                   % (n * args.stride, drops[n], slack[n], slack[n] - drops[n], lines[res[n][0]].strip()))
-    out.write("# total of the positive drops: %.0f cycles of %.0f per step; instructions with slack < 4 cycles (issue-bound): %d of %d\n"
-              % (sum(x for x in drops if x > 0), step_cycles, int((slack < 4).sum()), len(slack)))
+    executed = int((cyc > 8).sum())   # positions the hot path really runs through (a delay in a cold block costs nothing)
+    out.write("# positions on the executed path: %d of %d; step = %.0f slots => %.0f bubble slots per step (%.0f %%); "
+              "largest slack anywhere: %.1f slots (no single long wait: the bubbles are one-slot waits of an instruction "
+              "issued right behind its producer); positions with slack < 2 slots: %d\n"
+              % (executed, len(slack), step_cycles, step_cycles - executed, 100.0 * (step_cycles - executed) / step_cycles,
+                 float(slack[cyc > 8].max()), int(((slack < 2) & (cyc > 8)).sum())))
     out.write("# ---- all positions ----\n")
     for n, ((k, _), c, s) in enumerate(zip(res, cyc, slack)):
         out.write("%4d %6.1f %6.1f %6.1f  %s\n" % (n * args.stride, c, s, drops[n], lines[k].strip()))

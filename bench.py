@@ -346,11 +346,15 @@ def run_workload(ctx, spec, args, full):
     # episodes keep every timed rollout at its full horizon there
     episode = min(args.episode, 64) if (args.episode and config == "C3") else args.episode
 
-    def one_tick(o):
-        # stationary workload: restart the episode before the real agent gets
-        # so close to the goal that rollouts stop early (cf_agent.cpp:310)
+    def maybe_restart_episode():
+        # stationary workload: restart the episode before the real agent gets so close to the goal that rollouts stop
+        # early (cf_agent.cpp:310). Inside the timed blocks (it is part of the work), but OUTSIDE the per-tick latency
+        # samples: set_initial_position waits for the running rollout and launches a kernel of its own, which is not
+        # what "latency of a tick" means (it was the p99 of the round-2 line: one restart among 100 samples)
         if episode and tick_no[0] % episode == 0:
             planner.set_initial_position(starts)
+
+    def one_tick(o):
         tick_no[0] += 1
         return planner.tick(o if spec["dynamic"] else None, dt, cg, ws)
 
@@ -366,6 +370,7 @@ def run_workload(ctx, spec, args, full):
         planner.tick(None if coupled else obs, dt, cg, ws)  # obstacles resident in HBM from here on
         tick_no[0] += 1
         for _ in range(warmup):
+            maybe_restart_episode()
             one_tick(obs)
         planner.set_profiling(True)
     sync_all()
@@ -383,6 +388,7 @@ def run_workload(ctx, spec, args, full):
         t0 = time.perf_counter()
         if part:
             for k in range(steps):
+                maybe_restart_episode()
                 ta = time.perf_counter()
                 one_tick(obs)
                 blk_lat[k] = time.perf_counter() - ta
@@ -423,6 +429,7 @@ def run_workload(ctx, spec, args, full):
         if full and not (coupled and n_part > 1):
             idle = np.zeros(100)
             for k in range(idle.size):
+                maybe_restart_episode()
                 planner.stop()
                 ta = time.perf_counter()
                 one_tick(obs)

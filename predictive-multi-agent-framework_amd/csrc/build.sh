@@ -29,7 +29,8 @@ mkdir -p "$OBJ"
 # on 268: occupancy 1, +50 % time), so tests/test_abi.py checks the record.
 KFLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -mllvm -amdgpu-sched-strategy=max-ilp -mllvm -amdgpu-atomic-optimizer-strategy=None \
   -Wall -Wno-unused-function -Rpass-analysis=kernel-resource-usage ${PMAF_EXTRA_FLAGS} ${PMAF_EXTRA_KFLAGS}"   # PMAF_EXTRA_KFLAGS: kernel objects only
-HFLAGS="-O2 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function -D__HIP_PLATFORM_AMD__ -I$ROCM/include ${PMAF_EXTRA_FLAGS}"
+# PMAF_EXTRA_HFLAGS / PMAF_EXTRA_LDFLAGS: host objects / link line only (sanitizer builds: tools/asan.sh)
+HFLAGS="-O2 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function -D__HIP_PLATFORM_AMD__ -I$ROCM/include ${PMAF_EXTRA_FLAGS} ${PMAF_EXTRA_HFLAGS}"
 
 DEPS_K="pmaf_types.hpp pmaf_device.hpp pmaf_rollout_w64.hpp pmaf_rollout_grp.hpp"
 pids=()
@@ -41,6 +42,7 @@ kcompile() {  # kcompile <object stem> <source> [defines...]
   [ -f "$o" ] || stale=1
   for d in $src $DEPS_K build.sh; do [ "$d" -nt "$o" ] && stale=1; done
   [ -n "$PMAF_EXTRA_FLAGS$PMAF_EXTRA_KFLAGS" ] && stale=1
+  [ "$OUT" != "../lib" ] && [ ! -f "$o" ] && stale=1
   [ "$stale" = 0 ] && return 0
   ( $HIPCC $KFLAGS "$@" -c "$src" -o "$o" 2> "$OBJ/$stem.log" ) &
   pids+=($!); names+=("$stem")
@@ -63,7 +65,7 @@ done
 for n in "${names[@]}"; do grep -E -A3 "warning:|error:" "$OBJ/$n.log" >&2 || true; done
 $HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT/libpmaf_hip.so" \
   "$OBJ"/k_w64_m2.o "$OBJ"/k_w64_m0.o "$OBJ"/k_w64_m1.o "$OBJ"/k_grp_m2.o "$OBJ"/k_grp_m0.o "$OBJ"/k_misc.o \
-  "$OBJ"/host.o "$OBJ"/shard.o -L"$ROCM/lib" -lrccl -Wl,-rpath,"$ROCM/lib"
+  "$OBJ"/host.o "$OBJ"/shard.o -L"$ROCM/lib" -lrccl -Wl,-rpath,"$ROCM/lib" ${PMAF_EXTRA_LDFLAGS}
 # (the log of an object that was up to date is the one of its last compile)
 cat "$OBJ"/k_*.log | grep "kernel-resource-usage" | sed -e 's/^[^ ]* remark: *//' -e 's/ \[-Rpass-analysis=kernel-resource-usage\]//' > "$OUT/resource_usage.txt"
 echo "built $OUT/libpmaf_hip.so"

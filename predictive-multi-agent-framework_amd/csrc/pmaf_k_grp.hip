@@ -122,6 +122,7 @@ __global__ __launch_bounds__(64) void k_rollout_grp(DevView D, CostParams CP) {
       dg = Mth<MATH>::norm(g);
       zv = sqn(v);
       z_init = sqn(p - init_pos);
+      PMAF_BOUND(n < D.cap);
       if (sub == 0) { path[n * 3] = p.x; path[n * 3 + 1] = p.y; path[n * 3 + 2] = p.z; }
       n++;
       ran = true;

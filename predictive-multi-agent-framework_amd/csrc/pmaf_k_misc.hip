@@ -91,6 +91,7 @@ __global__ __launch_bounds__(64) void k_rollout(DevView D, CostParams CP) {
       p = new_pos;
       v = nv;
       ws_cost_add(cost_ws, p, CP.ws, CP.k_workspace);
+      PMAF_BOUND(n < D.cap);
       if (sub == 0) { path[n * 3] = p.x; path[n * 3 + 1] = p.y; path[n * 3 + 2] = p.z; }
       n++;
       ran = true;
@@ -670,7 +671,8 @@ __global__ __launch_bounds__(64) void k_plan_steps(DevView D, PlanArgs A) {
       if (active) {
         p = new_pos;
         v = nv;
-        if (sub == 0) { path[n * 3] = p.x; path[n * 3 + 1] = p.y; path[n * 3 + 2] = p.z; }
+        PMAF_BOUND(n < D.cap);
+      if (sub == 0) { path[n * 3] = p.x; path[n * 3 + 1] = p.y; path[n * 3 + 2] = p.z; }
         n++;
       }
     }

@@ -202,6 +202,7 @@ __device__ __forceinline__ void rollout_w64_body(const DevView &D, const CostPar
     z_init = sqn(p - init_pos);
     // every lane stores the (wave-uniform) point to the same address: one transaction, and no exec-masked block
     // in the middle of the tail
+    PMAF_BOUND(n < D.cap);
     path[n * 3] = p.x; path[n * 3 + 1] = p.y; path[n * 3 + 2] = p.z;
     n++;
     ran = true;

@@ -152,6 +152,7 @@ __device__ __forceinline__ void circ_and_scale_grp(bool act, int sub, int grp, i
       const bool has_c = in_shell && (vn != 0);
       const unsigned long long m = wave_ballot(has_c);
       if (has_c) {
+        PMAF_BOUND(count + __popcll(m & below) < LPA * TILES);
         double *e = clist + (size_t)(count + __popcll(m & below)) * 4;
         e[0] = c.x; e[1] = c.y; e[2] = c.z;
       }

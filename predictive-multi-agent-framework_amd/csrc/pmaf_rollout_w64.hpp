@@ -284,6 +284,8 @@ __device__ __forceinline__ void circ_and_scale_w64(int lane, V3 p, V3 v, double 
   constexpr int BATCH = 8;                 // list entries summed per LDS round trip (10, 12, 16 measured: no gain)
   constexpr int SCRATCH = 64 * TILES + BATCH;
   constexpr int SUM_SCRATCH = (4 * TILES + 1) * 64;  // PMAF_SUM_DPP: 4 TILES chunks of 64 doubles + the padding chunk
+  constexpr int MIN_CELL_BOUND = (64 * 4 + 8 + 64) * 4;   // doubles of the list area (the wave-minimum cell sits behind it)
+  (void)MIN_CELL_BOUND;
   (void)SCRATCH; (void)SUM_SCRATCH;
   const int M = n_obs - 1;
   double best_d = C.shell;
@@ -393,9 +395,11 @@ __device__ __forceinline__ void circ_and_scale_w64(int lane, V3 p, V3 v, double 
       const int sl = count + lane_rank(m);
       const int idx = has_c ? (((sl >> 4) << 6) + (sl & 15)) : (SUM_SCRATCH + lane);
       const int st = has_c ? 16 : 64;
+      PMAF_BOUND(sl < 64 * TILES && idx + 2 * st < MIN_CELL_BOUND);
       clist[idx] = c.x; clist[idx + st] = c.y; clist[idx + 2 * st] = c.z;
     } else {
       const int slot = has_c ? (count + lane_rank(m)) : (SCRATCH + lane);
+      PMAF_BOUND(slot * 4 + 2 < MIN_CELL_BOUND);
       double *e = clist + (size_t)slot * 4;
       e[0] = c.x; e[1] = c.y; e[2] = c.z;
     }

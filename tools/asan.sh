@@ -1,0 +1,38 @@
+#!/bin/bash
+# Sanitizer / debug-bounds builds of the library (SURVEY.md section 5 "race detection / sanitizers": the reference has
+# none). Build here (no GPU needed), run on the GPU box:  gpurun -- bash tools/asan.sh run
+#   lib_asan/    host side (pmaf_host.cpp, pmaf_shard.cpp) with -fsanitize=address,undefined; product kernels
+#   lib_bounds/  kernels with -DPMAF_DEBUG_BOUNDS (every path / list / slot index checked, the wave traps)
+set -e
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+cd "$R/predictive-multi-agent-framework_amd/csrc"
+if [ "${1:-build}" = build ]; then
+  PMAF_OUT=../lib_asan PMAF_EXTRA_HFLAGS="-fsanitize=address,undefined -fno-omit-frame-pointer -g" \
+    PMAF_EXTRA_LDFLAGS="-L$(dirname $(g++ -print-file-name=libasan.so)) -lasan -lubsan" bash build.sh
+  PMAF_OUT=../lib_bounds PMAF_EXTRA_KFLAGS="-DPMAF_DEBUG_BOUNDS" bash build.sh
+  exit 0
+fi
+cd "$R"
+mkdir -p gpurun_out
+OUT=gpurun_out/r3_asan.txt
+ASAN_SO=$(g++ -print-file-name=libasan.so)
+UBSAN_SO=$(g++ -print-file-name=libubsan.so)
+export ASAN_OPTIONS=detect_leaks=0:protect_shadow_gap=0:abort_on_error=0:halt_on_error=0:log_path=/tmp/asan_log
+export UBSAN_OPTIONS=print_stacktrace=1:log_path=/tmp/ubsan_log
+{
+  echo "# host side under AddressSanitizer + UndefinedBehaviorSanitizer (lib_asan/, LD_PRELOAD=$ASAN_SO)"
+  echo "# ASAN_OPTIONS=$ASAN_OPTIONS"
+  echo "== tests/test_abi.py + lifecycle / leak / checkpoint / stepping / exchange tests"
+  PMAF_LIB_PATH=$R/predictive-multi-agent-framework_amd/lib_asan/libpmaf_hip.so LD_PRELOAD="$ASAN_SO $UBSAN_SO" \
+    python -m pytest tests/test_abi.py tests/test_peer_gpu.py tests/test_shard_gpu.py tests/test_parity_gpu.py -q -x -p no:cacheprovider \
+    -k "abi or symbol or validation or lifecycle or leak or checkpoint or stepping or attached or one_rank or peer_mailbox_couples or peer_mailbox_two_handles or missing_header or step_api" 2>&1 | grep -E "passed|failed|error" | tail -3
+  echo "== tools/fuzz_api.py 1000 trials"
+  PMAF_LIB_PATH=$R/predictive-multi-agent-framework_amd/lib_asan/libpmaf_hip.so LD_PRELOAD="$ASAN_SO $UBSAN_SO" \
+    python tools/fuzz_api.py 1000 31 2>&1 | tail -2
+  echo "== sanitizer reports (files /tmp/asan_log.* /tmp/ubsan_log.*):"
+  ls /tmp/asan_log.* /tmp/ubsan_log.* 2>/dev/null | wc -l
+  cat /tmp/asan_log.* /tmp/ubsan_log.* 2>/dev/null | grep -E "ERROR|runtime error|SUMMARY" | sort | uniq -c | head -20
+  echo "# kernels with -DPMAF_DEBUG_BOUNDS (lib_bounds/): the GPU parity suite"
+  PMAF_LIB_PATH=$R/predictive-multi-agent-framework_amd/lib_bounds/libpmaf_hip.so python -m pytest tests/test_parity_gpu.py -q -x -p no:cacheprovider 2>&1 | tail -3
+} > $OUT 2>&1
+cat $OUT

@@ -427,7 +427,7 @@ def run_workload(ctx, spec, args, full):
         # control loop): host call -> best index and next set-point on the host. Outside the timed region.
         idle = np.zeros(0)
         if full and not (coupled and n_part > 1):
-            idle = np.zeros(100)
+            idle = np.zeros(500)
             for k in range(idle.size):
                 maybe_restart_episode()
                 planner.stop()
@@ -647,7 +647,8 @@ def main():
             "h_eff": head["h_eff"],
             "tick_latency_us": head["tick_latency_us"],
             "setpoint_latency_us": None if not idle.size else {
-                "median": float(np.median(idle) * 1e6), "p99": float(np.percentile(idle, 99) * 1e6),
+                "median": float(np.median(idle) * 1e6), "p90": float(np.percentile(idle, 90) * 1e6),
+                "p99": float(np.percentile(idle, 99) * 1e6), "max": float(np.max(idle) * 1e6), "n": int(idle.size),
                 "note": "tick issued on an idle stream: host call -> best index + next set-point "
                         "on the host (the new rollout then runs asynchronously)"},
             "allgather_us": head["allgather_us"],

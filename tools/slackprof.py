@@ -173,16 +173,23 @@ def main():
             os.remove(co)
         sys.stderr.write("%d / %d positions, %.0f s\n" % (min(b + B, len(idx)), len(idx), time.time() - t_start))
     d = np.array([r[1] for r in res]) / H                       # extra ns per step
-    # what 64 slots cost when nothing can absorb them: a second delay right behind a first one at the loop head
+    # one issue slot = 4 cycles of the core clock, measured while a lone wave computes (tools/clockrate.hip: s_memtime
+    # against the 100 MHz wall clock); a fully exposed 64-slot delay must then cost 64 slots (printed as a check)
+    exe = os.path.join(args.work, "clockrate")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", os.path.join(ROOT, "tools", "clockrate.hip"), "-o", exe],
+                          stderr=subprocess.DEVNULL)
+    ghz = float(subprocess.run([exe], capture_output=True, text=True, check=True).stdout.split()[-1])
+    full = DELAY_CYCLES * 4.0 / ghz                              # ns per step of a fully exposed 64-slot delay
     two = assemble((lambda sv: (open(sv[0], "w").writelines(lines[:h0 + 1] + DELAY + DELAY + lines[h0 + 1:]), sv)[1])(
         (os.path.join(args.work, "v_two.s"), os.path.join(args.work, "v_two.co"))))
-    full = (run(two)[0] - run(heads[j])[0]) / H                  # ns per step of a fully exposed 64-slot delay
+    check = (run(two)[0] - run(heads[j])[0]) / H / full * DELAY_CYCLES   # slots a second 64-slot delay at the head costs
     cyc = d / full * DELAY_CYCLES
     slack = DELAY_CYCLES - cyc
     step_cycles = t_base / H / full * DELAY_CYCLES
-    out.write("# profiled loop: %d instructions in its extent; one step = %.1f ns = %.0f issue slots of 4 cycles (a fully exposed "
-              "64-slot delay costs %.2f ns per step => %.2f GHz); slots per step beyond one per executed instruction = bubbles\n"
-              % (n0, t_base / H, step_cycles, full, 4 * DELAY_CYCLES / full))
+    out.write("# profiled loop: %d instructions in its extent; one step = %.1f ns = %.0f issue slots of 4 cycles (64 slots = "
+              "%.2f ns at the measured core clock of %.3f GHz); slots per step beyond one per executed instruction = bubbles\n"
+              % (n0, t_base / H, step_cycles, full, ghz))
+    out.write("# check: a second 64-slot delay right behind a first one at the loop head costs %.1f slots per step\n" % check)
     out.write("# columns: position, extra slots per step of a 64-slot delay in front of the instruction, slack = 64 - extra,\n"
               "#          drop = slack(i) - slack(i+1) (>0: the wave waited about that long at / right behind i), instruction\n")
     drops = []

@@ -127,7 +127,9 @@ def kernel_name_of(cfg, n_obs):
         dpp = t > 1 or (n_obs - 1) > 20
         if os.environ.get("PMAF_SUM"):
             dpp = t > 1 or os.environ["PMAF_SUM"].startswith("d")
-        return "k_rollout_w64<%d, 2, %s>" % (t, "true" if dpp else "false")  # <TILES, MATH_XACT, DPPSUM>
+        # <TILES, MATH_XACT, DPPSUM, PLAIN>; the bench scenes have k_attr != 0 and unit mass = the PLAIN step
+        plain = os.environ.get("PMAF_PLAIN_STEP", "1")[:1] != "0"
+        return "k_rollout_w64<%d, 2, %s, %s>" % (t, "true" if dpp else "false", "true" if plain else "false")
     if cfg["lanes_per_agent"] in (8, 16, 32) and (n_obs - 2) // cfg["lanes_per_agent"] + 1 <= 4 and not generic:
         tl = (n_obs - 2) // cfg["lanes_per_agent"] + 1
         return "k_rollout_grp<%d, %d, 2>" % (cfg["lanes_per_agent"], 1 if tl <= 1 else 2 if tl == 2 else 4)
@@ -198,6 +200,7 @@ class Ctx:
             raise SystemExit("bench.py: --gpus %d but hipGetDeviceCount() = %d (set PMAF_BENCH_SINGLE_DEVICE=1 to let "
                              "several ranks share device 0 in tests)" % (self.world, self.n_devices))
         self._groups = {}
+        self.comms = {}      # exchange communicators by rank set (make_exchange_comm)
 
     def subgroup(self, ranks):
         """gloo side group over `ranks` (created collectively by ALL ranks, cached)"""
@@ -229,6 +232,8 @@ def make_exchange_comm(ctx, ranks):
     pkg, dist, world = ctx.pkg, ctx.dist, ctx.world
     n = len(ranks)
     me = ranks.index(ctx.rank) if ctx.rank in ranks else -1
+    if tuple(ranks) in ctx.comms:        # one communicator per set of ranks and invocation (ncclCommInitRank is not free)
+        return ctx.comms[tuple(ranks)]
     transport = "rccl" if ctx.backend == "nccl" else "host"
     comm = None
     if transport == "rccl":
@@ -267,7 +272,8 @@ def make_exchange_comm(ctx, ranks):
                 return dist.all_gather_into_tensor(out, t, group=side)
         if me >= 0:
             comm = pkg.PmafComm.host(n, me, pkg.shard.torch_host_allgather(_Side))
-    return comm, (transport if me >= 0 else None)
+    ctx.comms[tuple(ranks)] = (comm, (transport if me >= 0 else None))
+    return ctx.comms[tuple(ranks)]
 
 
 def run_workload(ctx, spec, args, full):
@@ -451,8 +457,7 @@ def run_workload(ctx, spec, args, full):
         if coupled:
             planner.peer_disconnect()
         if comm is not None:
-            planner.attach_comm(None)
-            comm.close()
+            planner.attach_comm(None)     # (the communicator itself is kept for the next workload on the same ranks)
         planner.close()
     if rank != 0:
         return None
@@ -559,6 +564,7 @@ def main():
             got = comm.allgather(np.array([float(rank)])).reshape(-1).tolist()
             collective_world = comm.world
             comm.close()
+            ctx.comms.clear()
             dist.barrier()
             dist.destroy_process_group()
         if rank == 0:
@@ -684,6 +690,9 @@ def main():
         except OSError:
             pass
 
+    for comm, _ in ctx.comms.values():
+        if comm is not None:
+            comm.close()
     # the JSON line is the last thing written by the job: every rank empties its
     # buffers before the final barrier, rank 0 prints after it
     flush_all()

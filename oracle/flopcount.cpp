@@ -40,6 +40,12 @@ static inline cdouble sqrt(cdouble a) { g_flops++; return cdouble(sqrt(a.v)); }
 static inline cdouble exp(cdouble a) { g_flops++; return cdouble(exp(a.v)); }
 static inline cdouble fabs(cdouble a) { return cdouble(fabs(a.v)); }
 static inline bool isnan(cdouble a) { return std::isnan(a.v); }
+// pmaf_portable_exp's operations (exp mode 1; the count uses mode 0, where exp() is ONE operation): they only have to compile
+static inline cdouble fma(cdouble a, cdouble b, cdouble c) { g_flops += 2; return cdouble(fma(a.v, b.v, c.v)); }
+static inline cdouble rint(cdouble a) { g_flops++; return cdouble(rint(a.v)); }
+static inline cdouble ldexp(cdouble a, int k) { g_flops++; return cdouble(ldexp(a.v, k)); }
+static inline cdouble fmin(cdouble a, cdouble b) { g_flops++; return cdouble(fmin(a.v, b.v)); }
+static inline cdouble fmax(cdouble a, cdouble b) { g_flops++; return cdouble(fmax(a.v, b.v)); }
 
 #define PMAF_FLOPCOUNT 1
 #define double cdouble

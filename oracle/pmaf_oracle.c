@@ -59,9 +59,9 @@ static inline v3 vcross(v3 a, v3 b) {
  * exp(): the reference calls std::exp (B/src/cf_agent.cpp:220), i.e. the
  * platform libm, whose last bit differs between libms (glibc vs numpy vs ROCm
  * OCML disagree on 4-6 % of arguments). Mode 0 (default) keeps libm exp: the
- * reference-faithful restatement. Mode 1 uses pmaf_portable_exp below, the
- * table-free argument-reduction + rational-polynomial algorithm of Sun's
- * fdlibm e_exp.c (error < 1 ulp), written with plain IEEE + - * / only, so it
+ * reference-faithful restatement. Mode 1 uses pmaf_portable_exp below, a
+ * table-free argument reduction + polynomial (error < 1 ulp) written with
+ * correctly rounded IEEE operations only (* rint fma ldexp), so it
  * gives the same bits on every IEEE platform; the HIP kernels use the same
  * function (csrc/pmaf_device.hpp), which makes kernel-vs-oracle comparisons
  * bit-exact in mode 1.
@@ -71,26 +71,24 @@ void orc_set_exp_mode(int mode) { g_exp_mode = mode; }
 int orc_get_exp_mode(void) { return g_exp_mode; }
 
 double pmaf_portable_exp(double x) {
+  /* Cody-Waite reduction by two FMAs, degree-11 Horner polynomial on FMAs (coefficients: oracle/exp_poly.py),
+   * scaling by ldexp; every operation is correctly rounded IEEE (fma() is exact-then-rounded with or without
+   * hardware FMA), so the bits equal csrc/pmaf_device.hpp:portable_exp on gfx950. Worst error 0.81 ulp. */
   const double ln2HI = 6.93147180369123816490e-01, ln2LO = 1.90821492927058770002e-10,
                invln2 = 1.44269504088896338700e+00,
-               P1 = 1.66666666666666019037e-01, P2 = -2.77777777770155933842e-03,
-               P3 = 6.61375632143793436117e-05, P4 = -1.65339022054652515390e-06,
-               P5 = 4.13813679705723846039e-08;
-  const double ax = fabs(x);
-  if (ax > 708.0) return (x > 0) ? HUGE_VAL : 0.0;        /* outside the path's range */
-  if (ax < 3.725290298461914e-09) return 1.0 + x;         /* |x| < 2^-28 */
-  /* k = 0 for |x| <= 0.5 ln2, else round(x / ln2); one formula for all k */
-  const int k = (ax > 0.34657359027997264) ? (int)(invln2 * x + ((x < 0) ? -0.5 : 0.5)) : 0;
-  const double t = (double)k;
-  const double hi = x - t * ln2HI;
-  const double lo = t * ln2LO;
-  const double r = hi - lo;
-  const double r2 = r * r;
-  const double c = r - r2 * (P1 + r2 * (P2 + r2 * (P3 + r2 * (P4 + r2 * P5))));
-  const double y = 1.0 - ((lo - (r * c) / (2.0 - c)) - hi);
-  union { uint64_t u; double d; } two_k;
-  two_k.u = (uint64_t)(1023 + k) << 52;                   /* 2^k, exact scaling */
-  return y * two_k.d;
+               c3 = 0x1.5555555555555p-3, c4 = 0x1.5555555554cb8p-5, c5 = 0x1.1111111110e6bp-7,
+               c6 = 0x1.6c16c1738ed26p-10, c7 = 0x1.a01a01a4b26ffp-13, c8 = 0x1.a019c9ab128cfp-16,
+               c9 = 0x1.71de17e78d069p-19, c10 = 0x1.2880393b27194p-22, c11 = 0x1.af2360fb197fap-26;
+  if (x != x) return x;                                   /* NaN */
+  const double xs = fmin(fmax(x, -708.0), 710.0);         /* outside: >= 3.3e-308 / +inf (ldexp overflow) */
+  const double kf = rint(xs * invln2);                    /* round to nearest even (default rounding mode) */
+  double r = fma(-kf, ln2HI, xs);
+  r = fma(-kf, ln2LO, r);
+  double p = c11;
+  p = fma(p, r, c10); p = fma(p, r, c9); p = fma(p, r, c8); p = fma(p, r, c7); p = fma(p, r, c6);
+  p = fma(p, r, c5); p = fma(p, r, c4); p = fma(p, r, c3); p = fma(p, r, 0.5); p = fma(p, r, 1.0);
+  p = fma(p, r, 1.0);
+  return ldexp(p, (int)kf);
 }
 static inline double orc_exp(double x) { return g_exp_mode ? pmaf_portable_exp(x) : exp(x); }
 

@@ -275,54 +275,104 @@ template <> struct Mth<MATH_FAST> {
   static __device__ __forceinline__ V3 normalized(V3 a) { double s; V3 u; norm_unit(a, s, u); return u; }
 };
 
-// exp() of attractorForceScaling (B/src/cf_agent.cpp:220). The reference
-// calls the platform libm, whose last bit is not portable; this is the
-// table-free fdlibm e_exp.c algorithm (< 1 ulp) in plain IEEE + - * /, the
-// same function as oracle/pmaf_oracle.c:pmaf_portable_exp, so it produces
-// identical bits on the host and on gfx950.
-// Written without branches (selects only): the rollout kernels place it in one
-// straight-line region together with independent vector work so that a lone
-// wave's in-order issue can fill the latency of this dependent chain.
-// The constants come in a struct so that a kernel can hold them in VGPRs
-// across its step loop (exp_consts_in_vgprs): as literals they are scalar
-// values the compiler keeps in -- and spills from -- the SGPR file.
+// exp() of attractorForceScaling (B/src/cf_agent.cpp:220). The reference calls the platform libm, whose last bit is
+// not portable; this is a table-free exp in correctly rounded IEEE operations only (multiply, round-to-nearest-even
+// integer, fused multiply-add, ldexp), the same function as oracle/pmaf_oracle.c:pmaf_portable_exp, so it produces
+// identical bits on the host and on gfx950. Round 3 (second form): Cody-Waite reduction r = x - k ln2 by two FMAs,
+// degree-11 polynomial in Horner form on FMAs (c0 = c1 = 1, c2 = 1/2 exact, c3..c11 fitted on |r| <= ln2 / 2:
+// oracle/exp_poly.py; worst error 0.81 ulp over the reduced range), scaling by v_ldexp_f64 -- 21 instructions where the
+// fdlibm-style rational form (rounds 1-2) took 38, on the step's dependent chain where every instruction is an issue
+// slot. Arguments are clamped to [-708, 710] (below: >= 3.3e-308 instead of a subnormal / 0 -- attractorForceScaling
+// only forms 1 - exp(x); above: ldexp overflows to +inf as exp does); NaN propagates.
+// The constants come in a struct so that a kernel can hold them in VGPRs across its step loop (exp_consts_in_vgprs):
+// as literals they are scalar values the compiler keeps in -- and spills from -- the SGPR file.
 struct ExpK {
-  double ln2HI, ln2LO, invln2, P1, P2, P3, P4, P5;
+  double ln2HI, ln2LO, invln2, c3, c4, c5, c6, c7, c8, c9, c10, c11;
 };
 __device__ __forceinline__ ExpK exp_consts() {
   ExpK K;
   K.ln2HI = 6.93147180369123816490e-01; K.ln2LO = 1.90821492927058770002e-10; K.invln2 = 1.44269504088896338700e+00;
-  K.P1 = 1.66666666666666019037e-01; K.P2 = -2.77777777770155933842e-03; K.P3 = 6.61375632143793436117e-05;
-  K.P4 = -1.65339022054652515390e-06; K.P5 = 4.13813679705723846039e-08;
+  K.c3 = 0x1.5555555555555p-3; K.c4 = 0x1.5555555554cb8p-5; K.c5 = 0x1.1111111110e6bp-7; K.c6 = 0x1.6c16c1738ed26p-10;
+  K.c7 = 0x1.a01a01a4b26ffp-13; K.c8 = 0x1.a019c9ab128cfp-16; K.c9 = 0x1.71de17e78d069p-19;
+  K.c10 = 0x1.2880393b27194p-22; K.c11 = 0x1.af2360fb197fap-26;
   return K;
 }
 __device__ __forceinline__ ExpK exp_consts_in_vgprs() {
   ExpK K = exp_consts();
-  asm volatile("" : "+v"(K.ln2HI), "+v"(K.ln2LO), "+v"(K.invln2), "+v"(K.P1), "+v"(K.P2), "+v"(K.P3), "+v"(K.P4), "+v"(K.P5));
+  asm volatile("" : "+v"(K.ln2HI), "+v"(K.ln2LO), "+v"(K.invln2), "+v"(K.c3), "+v"(K.c4), "+v"(K.c5), "+v"(K.c6), "+v"(K.c7),
+               "+v"(K.c8), "+v"(K.c9), "+v"(K.c10), "+v"(K.c11));
   return K;
 }
-template <int MATH = MATH_IEEE>
-__device__ __forceinline__ double portable_exp(double x, const ExpK &K) {
-  const double ax = fabs(x);
-  const bool big = ax > 708.0;                    // outside the path's range: +inf / 0
-  const bool tiny = ax < 3.725290298461914e-09;   // |x| < 2^-28: 1 + x
-  const double xs = big ? 0.0 : x;                // keeps k in range; the result is replaced below
-  // k = 0 for |x| <= 0.5 ln2, else round(x / ln2); one formula for all k
-  // (for k = 0: hi = x, lo = 0, and 1 - ((0 - q) - x) == 1 - (-q - x), the
-  // k == 0 branch of the classic formulation, bit for bit)
-  const int kr = (int)(K.invln2 * xs + ((xs < 0) ? -0.5 : 0.5));
-  const int k = (ax > 0.34657359027997264) ? kr : 0;
-  const double t = (double)k;
-  const double hi = xs - t * K.ln2HI;
-  const double lo = t * K.ln2LO;
-  const double r = hi - lo;
-  const double r2 = r * r;
-  const double c = r - r2 * (K.P1 + r2 * (K.P2 + r2 * (K.P3 + r2 * (K.P4 + r2 * K.P5))));
-  const double y = 1.0 - ((lo - Mth<MATH>::div_pos(r * c, 2.0 - c)) - hi);  // |r| <= 0.35: 2 - c >= 1.6
-  const double res = y * __longlong_as_double((long long)(1023 + k) << 52);
-  const double special = big ? ((x > 0) ? __builtin_huge_val() : 0.0) : (1.0 + x);
-  return (big || tiny) ? special : res;
+// the same constants as a table (kernels that have no registers to hold twelve more loop-invariant doubles -- the
+// group kernel sits at its two-waves-per-SIMD VGPR budget -- keep the table in LDS and fetch the constants right where
+// the chain uses them: exp_consts_from_lds; volatile, so the compiler cannot hoist the twelve reads out of the step loop
+// and back into registers)
+constexpr int EXPK_N = 12;
+__device__ __forceinline__ void exp_consts_to_lds(double *tab, int lane) {
+  const ExpK K = exp_consts();
+  double mine = K.ln2HI;
+  mine = (lane == 1) ? K.ln2LO : mine; mine = (lane == 2) ? K.invln2 : mine; mine = (lane == 3) ? K.c3 : mine;
+  mine = (lane == 4) ? K.c4 : mine; mine = (lane == 5) ? K.c5 : mine; mine = (lane == 6) ? K.c6 : mine;
+  mine = (lane == 7) ? K.c7 : mine; mine = (lane == 8) ? K.c8 : mine; mine = (lane == 9) ? K.c9 : mine;
+  mine = (lane == 10) ? K.c10 : mine; mine = (lane == 11) ? K.c11 : mine;
+  if (lane < EXPK_N) tab[lane] = mine;
 }
+struct ExpKLds {   // every constant is read from the table at the point of use (a handful of VGPRs live at a time)
+  unsigned off;    // LDS byte address of the table
+  // the address passes through an empty asm together with the running value: the compiler can neither hoist the
+  // read out of the step loop (address unknown) nor issue it before the chain reaches this point (at most `ahead`
+  // constants in flight instead of twelve at once)
+  __device__ __forceinline__ void tie(double &p) { asm volatile("" : "+v"(off), "+v"(p)); }
+  __device__ __forceinline__ double get(int i) const {
+    typedef const __attribute__((address_space(3))) double *lds_cptr;
+    return reinterpret_cast<lds_cptr>(static_cast<uintptr_t>(off))[i];
+  }
+};
+__device__ __forceinline__ ExpKLds exp_consts_from_lds(const double *tab) {
+  typedef const __attribute__((address_space(3))) double *lds_cptr;
+  ExpKLds K;
+  K.off = (unsigned)reinterpret_cast<uintptr_t>((lds_cptr)tab);
+  return K;
+}
+struct ExpKRegs {  // the constants as values (literals / SGPRs, or VGPRs with exp_consts_in_vgprs)
+  const ExpK K;
+  __device__ __forceinline__ void tie(double &) {}
+  __device__ __forceinline__ double get(int i) const {
+    switch (i) {
+      case 0: return K.ln2HI; case 1: return K.ln2LO; case 2: return K.invln2; case 3: return K.c3; case 4: return K.c4;
+      case 5: return K.c5; case 6: return K.c6; case 7: return K.c7; case 8: return K.c8; case 9: return K.c9;
+      case 10: return K.c10; default: return K.c11;
+    }
+  }
+};
+template <int MATH, class KT>
+__device__ __forceinline__ double portable_exp_k(double x, KT K) {
+  double xs0 = x;
+  K.tie(xs0);
+  x = xs0;
+  const double xs = __builtin_fmin(__builtin_fmax(x, -708.0), 710.0);   // v_max_f64 / v_min_f64 (a NaN is replaced: see below)
+  const double kf = __builtin_rint(xs * K.get(2));                      // v_rndne_f64: k = round-to-nearest-even(x / ln2)
+  double r = __builtin_fma(-kf, K.get(0), xs);                          // k * ln2HI is exact (ln2HI has 21 trailing zero bits)
+  r = __builtin_fma(-kf, K.get(1), r);
+  K.tie(r);
+  double p = K.get(11);
+#pragma unroll
+  for (int i = 10; i >= 3; i--) {
+    if (i == 7 || i == 4) K.tie(p);   // table variant: the next three / four constants are fetched from here on
+    p = __builtin_fma(p, r, K.get(i));
+  }
+  p = __builtin_fma(p, r, 0.5);
+  p = __builtin_fma(p, r, 1.0); p = __builtin_fma(p, r, 1.0);
+  const double res = __builtin_ldexp(p, (int)kf);                       // v_cvt_i32_f64 + v_ldexp_f64
+  // NaN in, NaN out (the clamp above returns its other operand for a NaN): only the high word needs replacing
+  const long long bits = __double_as_longlong(res);
+  const long long nan_bits = (bits & 0xffffffffLL) | 0x7ff8000000000000LL;
+  return __longlong_as_double((x != x) ? nan_bits : bits);
+}
+template <int MATH = MATH_IEEE>
+__device__ __forceinline__ double portable_exp(double x, const ExpK &K) { return portable_exp_k<MATH, ExpKRegs>(x, ExpKRegs{K}); }
+template <int MATH = MATH_IEEE>
+__device__ __forceinline__ double portable_exp(double x, const ExpKLds &K) { return portable_exp_k<MATH, ExpKLds>(x, K); }
 template <int MATH = MATH_IEEE>
 __device__ __forceinline__ double portable_exp(double x) { return portable_exp<MATH>(x, exp_consts()); }
 

@@ -58,6 +58,7 @@ struct pmaf_planner {
   int lpa = 64;
   int math = MATH_XACT;        // arithmetic policy of the w64 rollout kernels (pmaf_device.hpp)
   bool force_generic = false;  // PMAF_FORCE_GENERIC=1: always use the generic k_rollout<LPA>
+  bool plain_step = false;     // every k_attr != 0 and unit mass: the wave-per-agent kernels' PLAIN step (pmaf_k_w64.hip)
   bool blocking_wait = false;  // PMAF_FLAG_BLOCKING_WAIT: pmaf_tick sleeps on an event instead of spinning on the mailbox
   bool dpp_sum = true;         // w64 kernels: ordered force sum by the DPP chain (M > 20) or LDS batches
   int n_blocks = 0;
@@ -294,7 +295,7 @@ static void launch_rollout(pmaf_planner *h) {
   } else if (h->lpa == 64 && tiles64 <= 4 && !h->force_generic)
     // ordered force sum: DPP chain from ~20 field obstacles up (lists long enough to need several LDS round trips),
     // LDS batches below (pmaf_rollout_w64.hpp, tools/msweep.py)
-    ok = pmaf_k_launch_w64(h->D, h->cp, tiles64, h->math, h->dpp_sum, h->lds_rollout, h->stream, e0, e1);
+    ok = pmaf_k_launch_w64(h->D, h->cp, tiles64, h->math, h->dpp_sum, h->plain_step, h->lds_rollout, h->stream, e0, e1);
   else if (!h->force_generic && (h->lpa == 32 || h->lpa == 16 || h->lpa == 8) && (M + h->lpa - 1) / h->lpa <= 4)
     // (the opt-in fast arithmetic exists for the w64 kernels only)
     ok = pmaf_k_launch_grp(h->D, h->cp, h->lpa, (M + h->lpa - 1) / h->lpa, h->math == MATH_IEEE ? MATH_IEEE : MATH_XACT,
@@ -774,6 +775,9 @@ int pmaf_create(const pmaf_params *prm, pmaf_planner **out) {
     h->upload(D.obs_start, soa.data(), soa.size());
     h->upload(D.obs_live, soa.data(), soa.size());
     h->upload(ka, prm->k_attr, PN); h->upload(kc, prm->k_circ, PN);
+    h->plain_step = (prm->agent_mass == 1.0);
+    for (size_t i = 0; i < PN; i++) h->plain_step = h->plain_step && (prm->k_attr[i] != 0.0);
+    { const char *ps = getenv("PMAF_PLAIN_STEP"); if (ps && ps[0] == '0') h->plain_step = false; }   // tests / timing: the general step
     h->upload(kr, prm->k_repel, PN); h->upload(kd, prm->k_damp, PN);
     std::vector<int32_t> ty(N);
     static const int layout[5] = {PMAF_HAD_HEURISTIC, PMAF_GOAL_HEURISTIC, PMAF_OBSTACLE_HEURISTIC,

@@ -28,6 +28,7 @@ constexpr unsigned POP_ROTATE = 8;
 template <int LPA, int TILES, int MATH>
 __global__ __launch_bounds__(64) void k_rollout_grp(DevView D, CostParams CP) {
   extern __shared__ double smem[];
+  __shared__ double s_expk[EXPK_N];   // portable_exp's constants (pmaf_device.hpp: exp_consts_from_lds)
   constexpr int APW = 64 / LPA;
   const unsigned long long t_begin = wall_clock64();
   const int lane = threadIdx.x;
@@ -85,6 +86,7 @@ __global__ __launch_bounds__(64) void k_rollout_grp(DevView D, CostParams CP) {
   clist_off += clist_off & 1;
   double *clist = smem + clist_off + (size_t)grp * ((LPA * TILES + 1) * 4);
   if (sub < 4) clist[(size_t)LPA * TILES * 4 + sub] = 0.0;  // the group's all-zero list entry
+  exp_consts_to_lds(s_expk, lane);
   wave_lds_fence();
 
   double lane_min = C.shell;
@@ -110,7 +112,7 @@ __global__ __launch_bounds__(64) void k_rollout_grp(DevView D, CostParams CP) {
     double scale = 1.0;
     if (wave_any(run && gate))
       circ_and_scale_grp<LPA, TILES, MATH>(run && gate, sub, grp, type, p, v, zv, goal, g, dg, C, k_circ, n_obs, rot_g,
-                                     known_bits, O, clist, lane_min, F, scale);
+                                     known_bits, O, clist, lane_min, F, scale, s_expk);
     V3 new_pos;
     V3 nv = v;
     finish_step_w64<MATH>(p, nv, verr, F, scale, C, k_attr, k_repel, k_damp, sent_p, sent_r, zsent_lt, new_pos,

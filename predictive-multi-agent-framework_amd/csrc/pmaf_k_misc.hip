@@ -738,17 +738,17 @@ __global__ void k_eval_obstacle_distance(DevView D, const double *obs, double *o
 // ---------------------------------------------------------------------------
 // launch interface (pmaf_types.hpp)
 // ---------------------------------------------------------------------------
-bool pmaf_k_launch_w64_m0(const DevView &, const CostParams &, int, bool, size_t, hipStream_t, hipEvent_t, hipEvent_t);
-bool pmaf_k_launch_w64_m1(const DevView &, const CostParams &, int, bool, size_t, hipStream_t, hipEvent_t, hipEvent_t);
-bool pmaf_k_launch_w64_m2(const DevView &, const CostParams &, int, bool, size_t, hipStream_t, hipEvent_t, hipEvent_t);
+bool pmaf_k_launch_w64_m0(const DevView &, const CostParams &, int, bool, bool, size_t, hipStream_t, hipEvent_t, hipEvent_t);
+bool pmaf_k_launch_w64_m1(const DevView &, const CostParams &, int, bool, bool, size_t, hipStream_t, hipEvent_t, hipEvent_t);
+bool pmaf_k_launch_w64_m2(const DevView &, const CostParams &, int, bool, bool, size_t, hipStream_t, hipEvent_t, hipEvent_t);
 bool pmaf_k_launch_grp_m0(const DevView &, const CostParams &, int, int, int, size_t, hipStream_t, hipEvent_t, hipEvent_t);
 bool pmaf_k_launch_grp_m2(const DevView &, const CostParams &, int, int, int, size_t, hipStream_t, hipEvent_t, hipEvent_t);
 
-bool pmaf_k_launch_w64(const DevView &D, const CostParams &cp, int tiles, int math, bool dppsum, size_t lds,
+bool pmaf_k_launch_w64(const DevView &D, const CostParams &cp, int tiles, int math, bool dppsum, bool plain, size_t lds,
                        hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
-  if (math == MATH_FAST) return pmaf_k_launch_w64_m1(D, cp, tiles, dppsum, lds, s, e0, e1);
-  if (math == MATH_IEEE) return pmaf_k_launch_w64_m0(D, cp, tiles, dppsum, lds, s, e0, e1);
-  return pmaf_k_launch_w64_m2(D, cp, tiles, dppsum, lds, s, e0, e1);
+  if (math == MATH_FAST) return pmaf_k_launch_w64_m1(D, cp, tiles, dppsum, plain, lds, s, e0, e1);
+  if (math == MATH_IEEE) return pmaf_k_launch_w64_m0(D, cp, tiles, dppsum, plain, lds, s, e0, e1);
+  return pmaf_k_launch_w64_m2(D, cp, tiles, dppsum, plain, lds, s, e0, e1);
 }
 
 bool pmaf_k_launch_grp(const DevView &D, const CostParams &cp, int lpa, int tiles, int math, int n_blocks, size_t lds,

@@ -18,7 +18,20 @@ using namespace pmaf;
 // carries no type dispatch (the type is uniform per wave)
 // SENT: 0 = the repulsive obstacle cannot come into range during this rollout (decided by the caller, one-slot kernel
 // only: the step loop then has no block for it), 1 = it can, 2 = decide here at run time (the other kernels)
-template <int TILES, int TYPE, int MATH, int SENT = 2, bool DPPSUM = false>
+// PLAIN: every agent of the launch has k_attr != 0 and the agents have unit mass (the reference's defaults and every
+// shipped task file; decided by the host at pmaf_create): the step then carries neither the `k_attr != 0` select nor the
+// division by the mass -- for a lone wave every instruction is an issue slot
+template <int TILES>
+__device__ __forceinline__ auto w64_exp_consts(double *tab, int lane) {
+  if constexpr (TILES >= 2) {
+    exp_consts_to_lds(tab, lane);
+    wave_lds_fence();
+    return exp_consts_from_lds(tab);
+  } else {
+    return exp_consts_in_vgprs();
+  }
+}
+template <int TILES, int TYPE, int MATH, int SENT = 2, bool DPPSUM = false, bool PLAIN = false>
 __device__ __forceinline__ void rollout_w64_body(const DevView &D, const CostParams &CP, const int lane,
                                                  const int pop, const int a) {
   extern __shared__ double smem[];
@@ -32,7 +45,11 @@ __device__ __forceinline__ void rollout_w64_body(const DevView &D, const CostPar
   { double *f = reinterpret_cast<double *>(&C);
     for (int i = 0; i < (int)(sizeof(PopConst) / sizeof(double)); i++) asm volatile("" : "+v"(f[i])); }
   // (two and four slots per lane have no VGPRs to spare for the exp coefficients: measured)
-  const ExpK EK = (TILES >= 2) ? exp_consts() : exp_consts_in_vgprs();
+  // portable_exp's twelve constants: pinned in VGPRs in the one-slot kernel; the multi-slot kernels sit at the
+  // 256-VGPR ceiling and fetch them from an LDS table right where the chain uses them (one box, C3: 1151 -> 1128 us
+  // against literals / SGPRs; the one-slot kernel the other way round, C2 243 against 264 us: profiles/r3_ab_exp.txt)
+  __shared__ double s_expk[EXPK_N];
+  const auto EK = w64_exp_consts<TILES>(s_expk, lane);
   const size_t pa = (size_t)pop * D.N + a;
   const double *src = D.obs_start + (size_t)pop * 7 * n_obs;
   const int32_t *ks = D.known_start + (size_t)pop * n_obs;
@@ -128,7 +145,7 @@ __device__ __forceinline__ void rollout_w64_body(const DevView &D, const CostPar
 #else
     if (PRE || gate)
 #endif
-      circ_and_scale_w64<TILES, TYPE, MATH, PRE, DPPSUM>(lane, p, v, zv, goal, g, dg, gn, C, k_circ, n_obs, rot_g, known_bits,
+      circ_and_scale_w64<TILES, TYPE, MATH, PRE, DPPSUM, decltype(EK)>(lane, p, v, zv, goal, g, dg, gn, C, k_circ, n_obs, rot_g, known_bits,
                                                  O, clist, lane_min, F, scale, ST, EK, D.ablate, 0, s_pre, ron_pre,
                                                  gate);
     PMAF_SEC(ST, 5);
@@ -139,7 +156,12 @@ __device__ __forceinline__ void rollout_w64_body(const DevView &D, const CostPar
     F = F + (mk(0.0, 0.0, 0.0) + repel);
     // attractorForce (:183-193), updatePositionAndVelocity (:253-258): a = F / mass, |a| <= 13
     V3 acc;
-    if (PRE) {
+    if (PLAIN) {
+      F = F + (scale * k_damp) * verr;
+      acc = F;
+      const double az = sqn(F);
+      if (PMAF_RARE(wave_any(az >= C.zacc_gt))) acc = acc * (13.0 / __builtin_sqrt(az));  // norm(acc) > 13.0
+    } else if (PRE) {
       // one slot per lane: as few blocks as possible between the force sum and the tail -- the k_attr == 0 case is a
       // select, and unit mass without clamp (the common case) skips ONE rare block instead of two
       const V3 Fa = F + (scale * k_damp) * verr;
@@ -262,7 +284,7 @@ __device__ __forceinline__ void rollout_w64_body(const DevView &D, const CostPar
   }
 }
 
-template <int TILES, int MATH, bool DPPSUM>
+template <int TILES, int MATH, bool DPPSUM, bool PLAIN>
 __global__ __launch_bounds__(64) void k_rollout_w64(DevView D, CostParams CP) {
   const int lane = threadIdx.x;
   const int pop = blockIdx.y;
@@ -278,8 +300,8 @@ __global__ __launch_bounds__(64) void k_rollout_w64(DevView D, CostParams CP) {
     const PopConst C0 = D.C;
     const bool reach = sentinel_reachable(p0, sp, sv, D.zsent_lt[pop], C0, D.cap);
 #define PMAF_BODY(T) \
-    if (reach) rollout_w64_body<TILES, T, MATH, 1, DPPSUM>(D, CP, lane, pop, a); \
-    else rollout_w64_body<TILES, T, MATH, 0, DPPSUM>(D, CP, lane, pop, a)
+    if (reach) rollout_w64_body<TILES, T, MATH, 1, DPPSUM, PLAIN>(D, CP, lane, pop, a); \
+    else rollout_w64_body<TILES, T, MATH, 0, DPPSUM, PLAIN>(D, CP, lane, pop, a)
     switch (D.types[a]) {
       case T_GOAL: PMAF_BODY(T_GOAL); break;
       case T_OBST: PMAF_BODY(T_OBST); break;
@@ -293,12 +315,12 @@ __global__ __launch_bounds__(64) void k_rollout_w64(DevView D, CostParams CP) {
     return;
   }
   switch (D.types[a]) {
-    case T_GOAL: rollout_w64_body<TILES, T_GOAL, MATH, 2, DPPSUM>(D, CP, lane, pop, a); break;
-    case T_OBST: rollout_w64_body<TILES, T_OBST, MATH, 2, DPPSUM>(D, CP, lane, pop, a); break;
-    case T_GOALOBST: rollout_w64_body<TILES, T_GOALOBST, MATH, 2, DPPSUM>(D, CP, lane, pop, a); break;
-    case T_VEL: rollout_w64_body<TILES, T_VEL, MATH, 2, DPPSUM>(D, CP, lane, pop, a); break;
-    case T_RANDOM: rollout_w64_body<TILES, T_RANDOM, MATH, 2, DPPSUM>(D, CP, lane, pop, a); break;
-    case T_HAD: rollout_w64_body<TILES, T_HAD, MATH, 2, DPPSUM>(D, CP, lane, pop, a); break;
+    case T_GOAL: rollout_w64_body<TILES, T_GOAL, MATH, 2, DPPSUM, PLAIN>(D, CP, lane, pop, a); break;
+    case T_OBST: rollout_w64_body<TILES, T_OBST, MATH, 2, DPPSUM, PLAIN>(D, CP, lane, pop, a); break;
+    case T_GOALOBST: rollout_w64_body<TILES, T_GOALOBST, MATH, 2, DPPSUM, PLAIN>(D, CP, lane, pop, a); break;
+    case T_VEL: rollout_w64_body<TILES, T_VEL, MATH, 2, DPPSUM, PLAIN>(D, CP, lane, pop, a); break;
+    case T_RANDOM: rollout_w64_body<TILES, T_RANDOM, MATH, 2, DPPSUM, PLAIN>(D, CP, lane, pop, a); break;
+    case T_HAD: rollout_w64_body<TILES, T_HAD, MATH, 2, DPPSUM, PLAIN>(D, CP, lane, pop, a); break;
     default: break;
   }
 }
@@ -310,19 +332,22 @@ __global__ __launch_bounds__(64) void k_rollout_w64(DevView D, CostParams CP) {
 #define PMAF_CAT2(a, b) a##b
 #define PMAF_CAT(a, b) PMAF_CAT2(a, b)
 bool PMAF_CAT(pmaf_k_launch_w64_m, PMAF_W64_MATH)(const DevView &D, const CostParams &cp, int tiles, bool dppsum,
-                                                  size_t lds, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
+                                                  bool plain, size_t lds, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
   const dim3 g64((unsigned)D.N, (unsigned)D.P), block(64);
 #define PMAF_L(K) hipExtLaunchKernelGGL(K, g64, block, (unsigned)lds, s, e0, e1, 0, D, cp)
   // one slot per lane: both ordered-sum variants (the host picks by obstacle count); two / four slots: DPP only
 #ifdef PMAF_ONLY_W64_1_DPP   // tools/slackprof: a translation unit that holds the C2 kernel alone (same ISA as the product's)
-  if (tiles <= 1 && dppsum) { PMAF_L((k_rollout_w64<1, PMAF_W64_MATH, true>)); return true; }
+  if (tiles <= 1 && dppsum && plain) { PMAF_L((k_rollout_w64<1, PMAF_W64_MATH, true, true>)); return true; }
   return false;
 #endif
-  if (tiles <= 1 && !dppsum) PMAF_L((k_rollout_w64<1, PMAF_W64_MATH, false>));
-  else if (tiles <= 1) PMAF_L((k_rollout_w64<1, PMAF_W64_MATH, true>));
-  else if (tiles == 2) PMAF_L((k_rollout_w64<2, PMAF_W64_MATH, true>));
-  else if (tiles <= 4) PMAF_L((k_rollout_w64<4, PMAF_W64_MATH, true>));
+#define PMAF_LP(T, S) do { if (plain) PMAF_L((k_rollout_w64<T, PMAF_W64_MATH, S, true>)); \
+                           else PMAF_L((k_rollout_w64<T, PMAF_W64_MATH, S, false>)); } while (0)
+  if (tiles <= 1 && !dppsum) PMAF_LP(1, false);
+  else if (tiles <= 1) PMAF_LP(1, true);
+  else if (tiles == 2) PMAF_LP(2, true);
+  else if (tiles <= 4) PMAF_LP(4, true);
   else return false;
+#undef PMAF_LP
 #undef PMAF_L
   return true;
 }

@@ -103,7 +103,7 @@ __device__ __forceinline__ void circ_and_scale_grp(bool act, int sub, int grp, i
                                                    V3 goal, V3 g, double dg, const PopConst &C, double k_circ,
                                                    int n_obs, double *rot_g, unsigned &known_bits,
                                                    LaneObstacles<TILES> &O, double *clist, double &lane_min, V3 &F,
-                                                   double &scale) {
+                                                   double &scale, const double *exp_tab) {
   typedef Mth<MATH> MT;
   const int M = n_obs - 1;
   const V3 gn = MT::div3(g, (dg > 0.0) ? dg : 1.0);  // goal_vec.normalized(): x / 1.0 == x
@@ -191,7 +191,7 @@ __device__ __forceinline__ void circ_and_scale_grp(bool act, int sub, int grp, i
     } else if (dot(g, v) <= 0.0 && zv < C.zv09_lt && dg > 0.15) {
       sc = 0.0;
     } else {
-      const double w1 = 1 - portable_exp<MATH>(-MT::div(MT::sqrt(m), C.shell));
+      const double w1 = 1 - portable_exp<MATH>(-MT::div(MT::sqrt(m), C.shell), exp_consts_from_lds(exp_tab));
       double w2 = 1 - MT::div(gr, dg * sb);
       w2 = w2 * w2;
       sc = w1 * w2;

@@ -268,12 +268,12 @@ __device__ __forceinline__ V3 closest_other_w64(bool need_latch, int t, int lane
 // ds_read per 16 entries, one dependent add per entry for all three components). Measured crossover at M ~ 20
 // field obstacles (tools/msweep.py, 64 agents x 200 steps): M = 16 274 vs 282 us, M = 32 301 vs 287 us, M = 61 353 vs
 // 326 us; C3 (M = 128, ~57 terms per step) 1603 -> 1322 us. The host picks per launch (pmaf_host.cpp).
-template <int TILES, int TYPE, int MATH, bool PRE = false, bool DPPSUM = false>
+template <int TILES, int TYPE, int MATH, bool PRE = false, bool DPPSUM = false, class KT = ExpK>
 __device__ __forceinline__ void circ_and_scale_w64(int lane, V3 p, V3 v, double zv, V3 goal, V3 g, double dg, V3 gn,
                                                    const PopConst &C, double k_circ,
                                                    int n_obs, double *rot_g, unsigned &known_bits,
                                                    LaneObstacles<TILES> &O, double *clist, double &lane_min,
-                                                   V3 &F, double &scale, SecTimers &ST, const ExpK &EK,
+                                                   V3 &F, double &scale, SecTimers &ST, const KT &EK,
                                                    const int ablate = 0, const int rtype = 0,
                                                    const double s_pre = 0.0, const V3 ron_pre = V3{0.0, 0.0, 0.0},
                                                    const bool gate = true) {

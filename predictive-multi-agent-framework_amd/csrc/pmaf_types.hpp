@@ -134,11 +134,12 @@ struct PlanArgs {
 // ---------------------------------------------------------------------------
 // launch interface: implemented in pmaf_k_w64.hip / pmaf_k_grp.hip / pmaf_k_misc.hip
 // ---------------------------------------------------------------------------
-// k_rollout_w64<TILES, MATH, DPPSUM> on grid (N, P); tiles in {1,2,4}; dppsum: the ordered force sum by the DPP
+// k_rollout_w64<TILES, MATH, DPPSUM, PLAIN> on grid (N, P); tiles in {1,2,4}; plain: every k_attr != 0 and unit mass
+// (the step without those two cases, pmaf_k_w64.hip); dppsum: the ordered force sum by the DPP
 // row-broadcast chain (always for tiles >= 2) or by LDS batches. Returns false if this build holds no such variant.
 // e0 / e1 (may be NULL): HIP events attached to the kernel's own dispatch packet (hipExtLaunchKernel start / stop
 // events) -- no marker packets in the stream, so timing a launch does not put anything between two kernels
-bool pmaf_k_launch_w64(const DevView &D, const CostParams &cp, int tiles, int math, bool dppsum, size_t lds,
+bool pmaf_k_launch_w64(const DevView &D, const CostParams &cp, int tiles, int math, bool dppsum, bool plain, size_t lds,
                        hipStream_t s, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
 // k_rollout_grp<LPA, TILES, MATH> on grid (n_blocks, P); lpa in {8,16,32}, tiles in {1,2,4}, math XACT or IEEE
 bool pmaf_k_launch_grp(const DevView &D, const CostParams &cp, int lpa, int tiles, int math, int n_blocks, size_t lds,

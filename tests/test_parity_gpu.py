@@ -1213,3 +1213,24 @@ def test_blocking_wait_flag_gives_the_same_results(pmaf, oracle, scenes):
     assert cpu < 0.7 * wall   # the spinning default burns a full core: cpu ~ wall
     print("blocking wait: %d ticks in %.1f ms wall, %.1f ms CPU" % (150, wall * 1e3, cpu * 1e3))
     hip.close()
+
+
+@pytest.mark.parametrize("config,ticks", [("C1", 10), ("C2", 8), ("C3", 2)])
+@pytest.mark.parametrize("case", ["mass", "k_attr_zero_some", "forced_general"])
+def test_w64_general_step_mass_and_zero_attractor_gain(pmaf, oracle, scenes, monkeypatch, config, ticks, case):
+    """round 3: the wave-per-agent kernels exist with a PLAIN step (every k_attr != 0, unit mass -- decided by
+    pmaf_create) and with the general one (attractorForce's `k_attr != 0` test B/src/cf_agent.cpp:184, the division by
+    the mass :254). Non-unit mass, a population in which SOME agents have k_attr == 0, and the general step forced onto
+    a plain population must all match the oracle bit for bit on the short-list, one-slot and two-slot kernels."""
+    sc = dict(scenes.config_scene(config))
+    if case == "mass":
+        sc["agent_mass"] = 2.5
+    elif case == "k_attr_zero_some":
+        ka = np.full(int(sc["n_agents"]), float(np.asarray(sc["k_attr"]).reshape(-1)[0]))
+        ka[1::3] = 0.0
+        sc["k_attr"] = ka
+    else:
+        monkeypatch.setenv("PMAF_PLAIN_STEP", "0")
+    hip, _ = run_both(pmaf, oracle, scenes, sc, ticks)
+    assert hip.launch_config()["lanes_per_agent"] == 64
+    hip.close()

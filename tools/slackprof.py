@@ -30,7 +30,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 LLVM = "/opt/rocm/lib/llvm/bin"
-KERNEL = "_Z13k_rollout_w64ILi1ELi2ELb1EEv7DevView10CostParams"
+KERNEL = "_Z13k_rollout_w64ILi1ELi2ELb1ELb1EEv7DevView10CostParams"
 CSRC = os.path.join(ROOT, "predictive-multi-agent-framework_amd", "csrc")
 KFLAGS = ("--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -mllvm "
           "-amdgpu-sched-strategy=max-ilp -mllvm -amdgpu-atomic-optimizer-strategy=None --cuda-device-only -S -DPMAF_W64_MATH=2").split()

@@ -222,6 +222,25 @@ static double repel_boundary(double R, double shell) {
   return z;
 }
 
+// Which step the wave-per-agent kernels run (pmaf_k_w64.hip, PLAIN): the one without attractorForce's `k_attr != 0`
+// test and the division by the mass is only valid when every agent's k_attr is non-zero and the agents have unit mass.
+// Decided where the gains / the mass enter the handle: pmaf_create and pmaf_load_state (k_attr == NULL: read them back
+// from the device).
+static void refresh_plain_step(pmaf_planner *h, const double *k_attr) {
+  const size_t PN = (size_t)h->D.P * h->D.N;
+  std::vector<double> tmp;
+  if (!k_attr) {
+    tmp.resize(PN);
+    h->download(tmp.data(), h->D.k_attr, PN);
+    k_attr = tmp.data();
+  }
+  bool plain = (h->D.C.mass == 1.0);
+  for (size_t i = 0; i < PN && plain; i++) plain = (k_attr[i] != 0.0);
+  const char *ps = getenv("PMAF_PLAIN_STEP");   // "0": always the general step (tests, timing)
+  if (ps && ps[0] == '0') plain = false;
+  h->plain_step = plain;
+}
+
 static int pick_lpa(int N, int P, int M) {
   // Heuristic: fill the 1024 SIMDs of the chip with waves, but never use more
   // lanes per agent than there are field obstacles to share.
@@ -775,9 +794,7 @@ int pmaf_create(const pmaf_params *prm, pmaf_planner **out) {
     h->upload(D.obs_start, soa.data(), soa.size());
     h->upload(D.obs_live, soa.data(), soa.size());
     h->upload(ka, prm->k_attr, PN); h->upload(kc, prm->k_circ, PN);
-    h->plain_step = (prm->agent_mass == 1.0);
-    for (size_t i = 0; i < PN; i++) h->plain_step = h->plain_step && (prm->k_attr[i] != 0.0);
-    { const char *ps = getenv("PMAF_PLAIN_STEP"); if (ps && ps[0] == '0') h->plain_step = false; }   // tests / timing: the general step
+    refresh_plain_step(h, prm->k_attr);
     h->upload(kr, prm->k_repel, PN); h->upload(kd, prm->k_damp, PN);
     std::vector<int32_t> ty(N);
     static const int layout[5] = {PMAF_HAD_HEURISTIC, PMAF_GOAL_HEURISTIC, PMAF_OBSTACLE_HEURISTIC,
@@ -1784,6 +1801,7 @@ int pmaf_load_state(pmaf_planner *h, const void *blob, size_t bytes) {
       r += h->alloc_bytes[i];
     }
     HIP_CHECK(hipStreamSynchronize(h->stream));
+    refresh_plain_step(h, nullptr);                                 // the blob's gains and mass, not the handle's
     h->download(h->goal_h.data(), h->D.goal, (size_t)h->D.P * 3);  // host copy of the goals
     const size_t n3 = sizeof(double) * 3 * (size_t)h->D.P;
     std::memcpy(h->real_pos_h.data(), r, n3); r += n3;

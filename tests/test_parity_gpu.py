@@ -1234,3 +1234,31 @@ def test_w64_general_step_mass_and_zero_attractor_gain(pmaf, oracle, scenes, mon
     hip, _ = run_both(pmaf, oracle, scenes, sc, ticks)
     assert hip.launch_config()["lanes_per_agent"] == 64
     hip.close()
+
+
+@pytest.mark.parametrize("blob_case", ["mass", "k_attr_zero_some"])
+def test_checkpoint_carries_the_step_variant(pmaf, oracle, scenes, blob_case):
+    """round 3: pmaf_create picks the wave-per-agent kernels' PLAIN step from the gains and the mass; a state blob brings
+    its OWN gains and mass, so pmaf_load_state must pick again -- a blob saved from a population with non-unit mass (or
+    some k_attr == 0) restored into a handle created with the defaults continues like the oracle of the blob's scene"""
+    sc = dict(scenes.config_scene("C2", scene_id=1))
+    if blob_case == "mass":
+        sc["agent_mass"] = 2.5
+    else:
+        ka = np.full(int(sc["n_agents"]), float(np.asarray(sc["k_attr"]).reshape(-1)[0]))
+        ka[::4] = 0.0
+        sc["k_attr"] = ka
+    hip, ora = make_pair(pmaf, oracle, sc)
+    for t in range(6):
+        assert hip.tick(None, sc["dt"], sc["cost_gains"], sc["ws_limits"]) == ora.tick(None, sc["dt"], sc["cost_gains"], sc["ws_limits"])
+    blob = hip.save_state()
+    hip.stop(); hip.close()
+    plain = scenes.config_scene("C2", scene_id=1)          # unit mass, k_attr != 0 everywhere: the PLAIN step
+    hip2 = pmaf.PmafPlanner(plain, device=0)
+    hip2.load_state(blob)
+    for t in range(6):
+        assert hip2.tick(None, sc["dt"], sc["cost_gains"], sc["ws_limits"]) == ora.tick(None, sc["dt"], sc["cost_gains"], sc["ws_limits"])
+    hip2.stop()
+    assert_state_equal(hip2, ora)
+    np.testing.assert_allclose(hip2.costs(), ora.costs(), rtol=0, atol=0)
+    hip2.close()

@@ -102,6 +102,9 @@ template <> struct Mth<MATH_IEEE> {
   static __device__ __forceinline__ void norm_rcp(V3 a, double &s, double &rs) { s = __builtin_sqrt(sqn(a)); rs = 0.0; }
   // as norm_rcp for a squared norm z the caller has at hand and tests itself (s is only divided by when z != 0)
   static __device__ __forceinline__ void norm_rcp_z(double z, double &s, double &rs) { s = __builtin_sqrt(z); rs = 0.0; }
+  static __device__ __forceinline__ void norm_rcp_zpos(double z, double &s, double &rs) { s = __builtin_sqrt(z); rs = 0.0; }
+  // the policy's helper value for dividing by s (see norm_rcp), for a divisor the caller has at hand
+  static __device__ __forceinline__ double rcp_for(double) { return 0.0; }
   static __device__ __forceinline__ double div_n(double x, double s, double) { return x / s; }
   static __device__ __forceinline__ V3 div3_n(V3 a, double s, double) { return a / s; }
   // (the *_pos variants of the default policy are plain divisions here)
@@ -189,9 +192,13 @@ template <> struct Mth<MATH_XACT> {
   // 1 + 2^-52 are fixed points of the Newton step, it lands on the other one than v_rcp_f64 does, and the quotient
   // of a numerator on a rounding tie came out 1 ulp off (found by tools/fuzz_parity.py, now in the test suite).
   static __device__ __forceinline__ void norm_rcp(V3 a, double &s, double &rs) { s = sqrt(sqn(a)); rs = rcp_refined(s); }
+  static __device__ __forceinline__ double rcp_for(double s) { return rcp_refined(s); }
   // (with sqrt_pos here too the one-slot kernels came out slower on one box -- C2 281.7 vs 279.1 us, C3 1276 vs 1250 us:
   // instruction scheduling, not arithmetic; measured per site with tools/ab.sh)
   static __device__ __forceinline__ void norm_rcp_z(double z, double &s, double &rs) { s = sqrt(z); rs = rcp_refined(s); }
+  // the same for a caller that discards everything derived from s unless z is positive and finite (the circular term's
+  // |rv|: the term only counts for squaredNorm != 0): no zero / infinity select behind the iteration (3 instructions)
+  static __device__ __forceinline__ void norm_rcp_zpos(double z, double &s, double &rs) { s = sqrt_pos(z); rs = rcp_refined(s); }
   static __device__ __forceinline__ double div_n(double x, double s, double rs) { return div_r(x, s, rs); }
   static __device__ __forceinline__ V3 div3_n(V3 a, double s, double rs) {
     return mk(div_r(a.x, s, rs), div_r(a.y, s, rs), div_r(a.z, s, rs));
@@ -206,12 +213,14 @@ template <> struct Mth<MATH_XACT> {
   static __device__ __forceinline__ void norm_unit(V3 a, double &s, V3 &u) {
     double z = sqn(a);
     s = sqrt(z);
-    const double rs = rcp_refined(s);
+    const double rs = TP ? 0.0 : rcp_refined(s);
     // (fixup-free divisions: the quotient is only used when squaredNorm > 0 -- then s is a positive normal and
     // |a_i| <= s -- or the divisor is the exact 1.0)
     if (TP) {
-      const bool pos = z > 0.0;
-      u = div3_n_pos(a, pos ? s : 1.0, pos ? rs : 1.0);
+      // (round 3: ONE select, on the divisor; its refined reciprocal is computed behind it -- rcp_refined(1.0) is 1.0
+      // exactly: v_rcp_f64 returns 1.0 or a neighbour, and the Newton steps round 1 - delta^2 to 1.0)
+      const double sd = (z > 0.0) ? s : 1.0;
+      u = div3_n_pos(a, sd, rcp_refined(sd));
     } else {
       V3 q = div3_n_pos(a, s, rs);
       u = (z > 0.0) ? q : a;
@@ -259,7 +268,9 @@ template <> struct Mth<MATH_FAST> {
   static __device__ __forceinline__ V3 div3(V3 a, double s) { double r = rcp(s); return a * r; }
   static __device__ __forceinline__ double norm(V3 a) { return sqrt(sqn(a)); }
   static __device__ __forceinline__ void norm_rcp(V3 a, double &s, double &rs) { sqrt_rsqrt(sqn(a), s, rs); }
+  static __device__ __forceinline__ double rcp_for(double s) { return rcp(s); }
   static __device__ __forceinline__ void norm_rcp_z(double z, double &s, double &rs) { sqrt_rsqrt(z, s, rs); }
+  static __device__ __forceinline__ void norm_rcp_zpos(double z, double &s, double &rs) { sqrt_rsqrt(z, s, rs); }
   static __device__ __forceinline__ double div_n(double x, double, double rs) { return x * rs; }
   static __device__ __forceinline__ V3 div3_n(V3 a, double, double rs) { return a * rs; }
   static __device__ __forceinline__ double div_pos(double a, double b) { return a * rcp(b); }
@@ -345,12 +356,15 @@ struct ExpKRegs {  // the constants as values (literals / SGPRs, or VGPRs with e
     }
   }
 };
-template <int MATH, class KT>
+// NONPOS: the caller guarantees x <= 0 and not NaN, or discards the result otherwise (attractorForceScaling's
+// -sqrt(d) / shell with d in [1e-5, shell): the upper clamp and the NaN replacement drop out (3 instructions)
+template <int MATH, class KT, bool NONPOS = false>
 __device__ __forceinline__ double portable_exp_k(double x, KT K) {
   double xs0 = x;
   K.tie(xs0);
   x = xs0;
-  const double xs = __builtin_fmin(__builtin_fmax(x, -708.0), 710.0);   // v_max_f64 / v_min_f64 (a NaN is replaced: see below)
+  const double xlo = __builtin_fmax(x, -708.0);                         // v_max_f64 (a NaN is replaced: see below)
+  const double xs = NONPOS ? xlo : __builtin_fmin(xlo, 710.0);
   const double kf = __builtin_rint(xs * K.get(2));                      // v_rndne_f64: k = round-to-nearest-even(x / ln2)
   double r = __builtin_fma(-kf, K.get(0), xs);                          // k * ln2HI is exact (ln2HI has 21 trailing zero bits)
   r = __builtin_fma(-kf, K.get(1), r);
@@ -364,6 +378,7 @@ __device__ __forceinline__ double portable_exp_k(double x, KT K) {
   p = __builtin_fma(p, r, 0.5);
   p = __builtin_fma(p, r, 1.0); p = __builtin_fma(p, r, 1.0);
   const double res = __builtin_ldexp(p, (int)kf);                       // v_cvt_i32_f64 + v_ldexp_f64
+  if (NONPOS) return res;
   // NaN in, NaN out (the clamp above returns its other operand for a NaN): only the high word needs replacing
   const long long bits = __double_as_longlong(res);
   const long long nan_bits = (bits & 0xffffffffLL) | 0x7ff8000000000000LL;
@@ -373,6 +388,10 @@ template <int MATH = MATH_IEEE>
 __device__ __forceinline__ double portable_exp(double x, const ExpK &K) { return portable_exp_k<MATH, ExpKRegs>(x, ExpKRegs{K}); }
 template <int MATH = MATH_IEEE>
 __device__ __forceinline__ double portable_exp(double x, const ExpKLds &K) { return portable_exp_k<MATH, ExpKLds>(x, K); }
+template <int MATH = MATH_IEEE>
+__device__ __forceinline__ double portable_exp_nonpos(double x, const ExpK &K) { return portable_exp_k<MATH, ExpKRegs, true>(x, ExpKRegs{K}); }
+template <int MATH = MATH_IEEE>
+__device__ __forceinline__ double portable_exp_nonpos(double x, const ExpKLds &K) { return portable_exp_k<MATH, ExpKLds, true>(x, K); }
 template <int MATH = MATH_IEEE>
 __device__ __forceinline__ double portable_exp(double x) { return portable_exp<MATH>(x, exp_consts()); }
 
@@ -532,6 +551,18 @@ __device__ __forceinline__ V3 current_vector(int type, V3 agent_vel, V3 goal_vec
     // `if (cur.norm() < 1e-10) cur = (0,0,1); return cur.normalized()` with ONE
     // square root: (0,0,1).normalized() is (0,0,1) exactly, and otherwise
     // normalized() divides by the same sqrt(squaredNorm(cur)) the test compared
+    if constexpr (TP && MATH == MATH_XACT) {
+      // tuned kernels (round 3): the test on the SQUARED norm -- sqrt is correctly rounded and monotone, so
+      // (sqrt(z) < 1e-10) == (z < Z10) with Z10 the smallest double whose root is >= 1e-10 (0x1.79ca10c924223p-67, the
+      // double 1e-20; host check: tests/test_oracle_properties.py) -- which takes the zero / infinity select out of
+      // the root, and the `squaredNorm > 0` select out of normalized(): z == 0 is below the threshold, and for a NaN z
+      // the quotient is NaN in every component, as is the vector normalized() would return (to_obs * NaN is NaN in
+      // every component, so cur is)
+      const double z = sqn(cur);
+      const double s = M::sqrt_pos(z);
+      const V3 q = M::div3_n_pos(cur, s, M::rcp_refined(s));
+      return (z < 0x1.79ca10c924223p-67) ? mk(0.0, 0.0, 1.0) : q;
+    }
     double s;
     V3 u;
     M::template norm_unit<TP>(cur, s, u);

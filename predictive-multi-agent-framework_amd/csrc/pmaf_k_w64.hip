@@ -135,7 +135,9 @@ __device__ __forceinline__ void rollout_w64_body(const DevView &D, const CostPar
   while ((dg > 0.1) && (n < D.cap)) {  // wave-uniform guard, B/src/cf_agent.cpp:310-311
     // gate, :315-317
     // |v| < 0.5 vmax and |p - init| < 0.2 on exact squared thresholds
-    const bool gate = !(dg < C.approach || (zv < C.zvhalf_lt && z_init < C.zinit_lt));
+    // (as a lane mask built from single compares: pmaf_rollout_w64.hpp, "lane predicates as masks")
+    const lmask gate_m = ~(PMAF_BAL(dg < C.approach) | (PMAF_BAL(zv < C.zvhalf_lt) & PMAF_BAL(z_init < C.zinit_lt)));
+    const bool gate = gate_m != 0ull;
     V3 F = mk(0.0, 0.0, 0.0);
     double scale = 1.0;
     PMAF_SEC(ST, 0);
@@ -147,7 +149,7 @@ __device__ __forceinline__ void rollout_w64_body(const DevView &D, const CostPar
 #endif
       circ_and_scale_w64<TILES, TYPE, MATH, PRE, DPPSUM, decltype(EK)>(lane, p, v, zv, goal, g, dg, gn, C, k_circ, n_obs, rot_g, known_bits,
                                                  O, clist, lane_min, F, scale, ST, EK, D.ablate, 0, s_pre, ron_pre,
-                                                 gate);
+                                                 gate_m);
     PMAF_SEC(ST, 5);
     // attractorForce (:183-193), updatePositionAndVelocity (:253-268)
     // repelForce (:159-181): `repel` was evaluated for this step's start state at the end of the previous step; it is
@@ -207,15 +209,20 @@ __device__ __forceinline__ void rollout_w64_body(const DevView &D, const CostPar
       const V3 vec = l_nv ? nv : (l_des ? vel_des : other);
       V3 num = vec;
       num.x = (l_nv || l_des) ? C.vel_max : vec.x;
-      double s, rs;
-      MT::norm_rcp(vec, s, rs);
-      // (y and z: direction components only, behind the squaredNorm > 0 select; x also carries the riders'
-      // vel_max / |.| quotients, whose IEEE value for a zero norm the fixup supplies)
-      const V3 q = mk(MT::div_n(num.x, s, rs), MT::div_n_pos(num.y, s, rs), MT::div_n_pos(num.z, s, rs));
-      const V3 u = (sqn(vec) > 0.0) ? q : vec;  // normalized(): the vector itself unless squaredNorm > 0
+      // normalized(): the vector itself unless squaredNorm > 0 -- by ONE select on the divisor (x / 1.0 == x for every
+      // x, zeros keep their sign, a NaN stays one) instead of three on the quotients; the riders' lanes divide by their
+      // norm whatever it is (vel_max / 0 = inf: the fixup of the x component supplies it)
+      const double zvec = sqn(vec);
+      const double s = MT::sqrt(zvec);
+      const double sd = PMAF_LANE(PMAF_BAL(zvec > 0.0) | (3ull << 61)) ? s : 1.0;
+      const double rs = MT::rcp_for(sd);
+      // (y and z: direction components only; x also carries the riders' vel_max / |.| quotients)
+      const V3 q = mk(MT::div_n(num.x, sd, rs), MT::div_n_pos(num.y, sd, rs), MT::div_n_pos(num.z, sd, rs));
+      const V3 u = q;
       if (PRE) { s_pre = s; ron_pre = u; }
       const double vn = readlane_d(s, 62), f_nv = readlane_d(q.x, 62), f_des = readlane_d(q.x, 61);
-      v = (vn > C.vel_max) ? nv * f_nv : nv;
+      // (the clamp as a select on the FACTOR: nv * 1.0 is nv exactly -- two selects instead of six)
+      v = nv * ((vn > C.vel_max) ? f_nv : 1.0);
       dg = readlane_d(s, 63);
       gn = readlane_v3(u, 63);
       verr = vel_des * smin(1.0, f_des) - v;

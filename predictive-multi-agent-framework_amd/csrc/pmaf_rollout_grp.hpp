@@ -191,7 +191,7 @@ __device__ __forceinline__ void circ_and_scale_grp(bool act, int sub, int grp, i
     } else if (dot(g, v) <= 0.0 && zv < C.zv09_lt && dg > 0.15) {
       sc = 0.0;
     } else {
-      const double w1 = 1 - portable_exp<MATH>(-MT::div(MT::sqrt(m), C.shell), exp_consts_from_lds(exp_tab));
+      const double w1 = 1 - portable_exp_nonpos<MATH>(-MT::div(MT::sqrt(m), C.shell), exp_consts_from_lds(exp_tab));
       double w2 = 1 - MT::div(gr, dg * sb);
       w2 = w2 * w2;
       sc = w1 * w2;

@@ -189,6 +189,16 @@ struct SecTimers {};
 #define PMAF_RARE(c) (c)
 #endif
 
+// Lane predicates as wave-uniform 64-bit MASKS (round 3). The compiler keeps a per-lane bool in an SGPR pair anyway, but a
+// vote on a COMPOUND predicate -- ballot(a && b), any(a && !b) -- is lowered through a VGPR (v_cndmask 0/1 + v_cmp_ne_u32:
+// two issue slots per vote; only ballot(single compare) folds into the compare). So the step's predicates are built
+// from ballots of single compares combined with scalar AND / OR / NOT, tested with a scalar compare, and turned back
+// into a per-lane condition with inverse_ballot, which is free (the SGPR pair IS the select's condition operand).
+// All of it requires the full wave to be active, which holds wherever these are used (wave-uniform branches only).
+typedef unsigned long long lmask;
+#define PMAF_BAL(c) __builtin_amdgcn_ballot_w64(c)
+#define PMAF_LANE(m) __builtin_amdgcn_inverse_ballot_w64(m)
+
 template <int TILES>
 struct LaneObstacles {
   V3 p[TILES], v[TILES];
@@ -215,10 +225,10 @@ __device__ __forceinline__ V3 readlane_v3(V3 a, int lane) {
 // chain + one DPP argmin per latching lane instead of M dependent sqrt chains).
 // Returns, in the latching lanes, the position of that closest obstacle.
 template <int TILES, int MATH>
-__device__ __forceinline__ V3 closest_other_w64(bool need_latch, int t, int lane, int M,
+__device__ __forceinline__ V3 closest_other_w64(lmask need_latch_m, int t, int lane, int M,
                                                 const LaneObstacles<TILES> &O) {
   V3 cpos = mk(0.0, 0.0, 0.0);
-  unsigned long long pend = wave_ballot(need_latch);
+  unsigned long long pend = need_latch_m;
   while (pend) {
     const int L = __ffsll((long long)pend) - 1;  // wave-uniform
     pend &= pend - 1;
@@ -276,7 +286,7 @@ __device__ __forceinline__ void circ_and_scale_w64(int lane, V3 p, V3 v, double 
                                                    V3 &F, double &scale, SecTimers &ST, const KT &EK,
                                                    const int ablate = 0, const int rtype = 0,
                                                    const double s_pre = 0.0, const V3 ron_pre = V3{0.0, 0.0, 0.0},
-                                                   const bool gate = true) {
+                                                   const lmask gate_m = ~0ull) {
   typedef Mth<MATH> MT;
   // TYPE == T_REAL: the heuristic is a run-time value (the real agent's step in
   // k_manager dispatches to the stored best agent's type, cf_agent.cpp:368-387)
@@ -291,40 +301,47 @@ __device__ __forceinline__ void circ_and_scale_w64(int lane, V3 p, V3 v, double 
   double best_d = C.shell;
   double best_s = 0.0, best_gr = 0.0;  // |ro| and g.ro of the lane's closest obstacle
   int best_i = 0x7fffffff;
+  lmask has_best_m = 0ull;             // lanes with best_i != none
   // ---- sweep geometry (circForce :76-88, attractorForceScaling :201-211) ----
   V3 ron_t[TILES], rv_t[TILES];
   double d_t[TILES];
-  bool in_t[TILES];
-  bool any_in = false;
+  lmask in_m[TILES];
+  lmask any_in_m = 0ull;
 #pragma unroll
   for (int t = 0; t < TILES; t++) {
     const int i = t * 64 + lane;
-    const bool valid = gate && (i < M);  // gate (:315-317) closed: no obstacle counts, the sweep below finds nothing
+    // lanes whose slot holds a field obstacle (i < M), by scalar arithmetic: loop-invariant, and a ballot of the
+    // hoisted compare would cost the VGPR round trip again; gate (:315-317) closed: no obstacle counts
+    const int left = M - t * 64;
+    const lmask valid_m = gate_m & ((left >= 64) ? ~0ull : ((left <= 0) ? 0ull : ((1ull << left) - 1ull)));
     const V3 ro = O.p[t] - p;
     rv_t[t] = v - O.v[t];
     double s;
     if (PRE) { s = s_pre; ron_t[t] = ron_pre; }
     else MT::norm_unit(ro, s, ron_t[t]);
-    const bool skip = (dot(ron_t[t], gn) < -0.01) && (dot(ro, rv_t[t]) < -0.01);
+    const lmask skip_m = PMAF_BAL(dot(ron_t[t], gn) < -0.01) & PMAF_BAL(dot(ro, rv_t[t]) < -0.01);
     double d = s - (C.rad + O.r[t]);
     d = smax(d, 1e-5);
     d_t[t] = d;
+    const lmask closer_m = valid_m & PMAF_BAL(d < best_d);
+    has_best_m |= closer_m;
+    const bool closer = PMAF_LANE(closer_m);
     if (TILES == 1) {  // one slot per lane: its |ro| and g.ro are only read from the winning lane
-      if (valid && d < best_d) { best_d = d; best_i = i; }
+      if (closer) { best_d = d; best_i = i; }
       best_s = s; best_gr = dot(g, ro);
     } else {
-      if (valid && d < best_d) { best_d = d; best_i = i; best_s = s; best_gr = dot(g, ro); }
+      if (closer) { best_d = d; best_i = i; best_s = s; best_gr = dot(g, ro); }
     }
-    const bool live = valid && !skip;
-    if (live && d < lane_min) lane_min = d;
-    in_t[t] = live && (d < C.shell);
-    any_in = any_in || in_t[t];
+    const lmask live_m = valid_m & ~skip_m;
+    if (PMAF_LANE(live_m & PMAF_BAL(d < lane_min))) lane_min = d;
+    in_m[t] = live_m & PMAF_BAL(d < C.shell);
+    any_in_m |= in_m[t];
   }
   PMAF_SEC(ST, 1);
 #ifdef PMAF_ABLATION   // timing experiments only (PMAF_ABLATE=4): no in-shell block
   if (ablate & 4) return;
 #endif
-  if (PMAF_RARE(!wave_any(any_in))) return;  // nothing inside the shell: F stays 0, scale stays 1
+  if (PMAF_RARE(any_in_m == 0ull)) return;  // nothing inside the shell: F stays 0, scale stays 1
   PMAF_CNT(ST, 0, 1);
 #ifndef PMAF_LDS_MIN
 #define PMAF_LDS_MIN 1
@@ -351,11 +368,11 @@ __device__ __forceinline__ void circ_and_scale_w64(int lane, V3 p, V3 v, double 
 #pragma unroll
   for (int t = 0; t < TILES; t++) {
     const int i = t * 64 + lane;
-    const bool need_latch = in_t[t] && !((known_bits >> t) & 1u);
-    if (PMAF_RARE(wave_any(need_latch))) {
+    const lmask need_latch_m = in_m[t] & PMAF_BAL((known_bits & (1u << t)) == 0u);
+    if (PMAF_RARE(need_latch_m != 0ull)) {
       V3 cpos = O.p[t];
-      if (type == T_OBST || type == T_GOALOBST) cpos = closest_other_w64<TILES, MATH>(need_latch, t, lane, M, O);
-      if (need_latch) {
+      if (type == T_OBST || type == T_GOALOBST) cpos = closest_other_w64<TILES, MATH>(need_latch_m, t, lane, M, O);
+      if (PMAF_LANE(need_latch_m)) {
         V3 rot = calc_rot_vec_c<MATH>(type, p, goal, n_obs, O.p[t], cpos, mk(O.qx[t], O.qy[t], O.qz[t]));
         rot_g[i] = rot.x; rot_g[n_obs + i] = rot.y; rot_g[2 * n_obs + i] = rot.z;
         O.rx[t] = rot.x; O.ry[t] = rot.y; O.rz[t] = rot.z;
@@ -371,32 +388,37 @@ __device__ __forceinline__ void circ_and_scale_w64(int lane, V3 p, V3 v, double 
   int count = 0;
 #pragma unroll
   for (int t = 0; t < TILES; t++) {
-    if (TILES > 2 && !wave_any(in_t[t])) continue;  // no term from this slot (wave-uniform; 2 slots: both in one block)
+    if (TILES > 2 && in_m[t] == 0ull) continue;  // no term from this slot (wave-uniform; 2 slots: both in one block)
     const V3 rot = mk(O.rx[t], O.ry[t], O.rz[t]);
     const V3 rv = rv_t[t];
     // |rv| is only divided by, and compared with 0: sqrt(z) != 0 <=> z != 0 (for z == 0 the term is discarded, has_c)
     const double zrv = sqn(rv);
     double vn, rvn;
-    MT::norm_rcp_z(zrv, vn, rvn);
+    MT::norm_rcp_zpos(zrv, vn, rvn);   // (zrv == 0: garbage that goes to the lane's scratch entry, has_c below)
     const V3 nv = MT::div3_n_pos(rv, vn, rvn);
-    const V3 cur = current_vector<MATH>(type, rv, g, ron_t[t], rot);
+    const V3 cur = current_vector<MATH, true>(type, rv, g, ron_t[t], rot);   // (normalized() by a select on the divisor: 4 instructions less)
 #ifdef PMAF_ABL_NOCIRC   // timing experiments only (tools/ablate.sh): no circular-term arithmetic, list traffic kept
     const V3 c = rv; (void)nv; (void)cur; (void)rot;
 #else
     const V3 c = MT::div_pos(k_circ, d_t[t] * d_t[t]) * cross(nv, cross(cur, nv));  // d >= 1e-5
 #endif
-    const bool has_c = in_t[t] && (zrv != 0);   // vel_norm != 0, B/src/cf_agent.cpp:98
     // compact the contributing terms, ascending obstacle index
-    const unsigned long long m = wave_ballot(has_c);
+    const unsigned long long m = in_m[t] & PMAF_BAL(zrv != 0);   // vel_norm != 0, B/src/cf_agent.cpp:98
+    const bool has_c = PMAF_LANE(m);
     if (DPPSUM) {
       // row-transposed list: 16 entries per chunk of 64 doubles, [x0..x15 | y0..y15 | z0..z15 | -], so that ONE
       // conflict-free ds_read hands lane 16 r + k component r of entry k (see the sum below); lanes without a term
       // store to a scratch area behind the list
       const int sl = count + lane_rank(m);
-      const int idx = has_c ? (((sl >> 4) << 6) + (sl & 15)) : (SUM_SCRATCH + lane);
-      const int st = has_c ? 16 : 64;
-      PMAF_BOUND(sl < 64 * TILES && idx + 2 * st < MIN_CELL_BOUND);
-      clist[idx] = c.x; clist[idx + st] = c.y; clist[idx + 2 * st] = c.z;
+      // (the scratch entries use the list's component stride of 16 too -- three blocks of 16 per row of lanes, 192
+      // doubles -- so the three stores share one address register and immediate offsets)
+      // (list index computed by every lane and SELECTED: left to itself the compiler wraps it into an exec-masked
+      // block -- s_and_saveexec / s_or exec and a copy -- for one v_cndmask_b32)
+      int li = ((sl >> 4) << 6) + (sl & 15);
+      asm("" : "+v"(li));
+      const int idx = has_c ? li : (SUM_SCRATCH + (lane >> 4) * 48 + (lane & 15));
+      PMAF_BOUND(sl < 64 * TILES && idx + 32 < MIN_CELL_BOUND);
+      clist[idx] = c.x; clist[idx + 16] = c.y; clist[idx + 32] = c.z;
     } else {
       const int slot = has_c ? (count + lane_rank(m)) : (SCRATCH + lane);
       PMAF_BOUND(slot * 4 + 2 < MIN_CELL_BOUND);
@@ -444,20 +466,20 @@ __device__ __forceinline__ void circ_and_scale_w64(int lane, V3 p, V3 v, double 
     } else {
       m = wave_min64(best_d);
     }
-    const bool cand = (best_i != 0x7fffffff) && (best_d == m);
+    const lmask cand_m = has_best_m & PMAF_BAL(best_d == m);
     int bi;
     if (TILES == 1) {  // obstacle index == lane: lowest candidate lane wins
-      const unsigned long long bm = wave_ballot(cand);
-      bi = bm ? (__ffsll((long long)bm) - 1) : 0x7fffffff;
+      bi = cand_m ? (__ffsll((long long)cand_m) - 1) : 0x7fffffff;
     } else {
-      bi = wave_min64_i(cand ? best_i : 0x7fffffff);
+      bi = wave_min64_i(PMAF_LANE(cand_m) ? best_i : 0x7fffffff);
     }
     // (the chunk fetched above is not touched before the closest-obstacle reduction is through: the scheduler, left
     // alone, starts the sum ten instructions behind the ds_read and waits for it there)
     if (HOIST1 && (PMAF_SUM_HOIST & 4)) asm("" : "+v"(e_first) : "s"(bi));
     const bool stall = (dot(g, v) <= 0.0) && (zv < C.zv09_lt) && (dg > 0.15);  // norm(v) < vmax - 0.1 vmax
     // (shell == 0: nothing is ever inside it, bi stays "none" and w is discarded)
-    const double w1 = 1 - portable_exp<MATH>(-MT::div_pos(MT::sqrt_pos(m), C.shell), EK);  // m >= 1e-5
+    // (m in [1e-5, shell) whenever an obstacle is in reach; otherwise bi is "none" and w is discarded)
+    const double w1 = 1 - portable_exp_nonpos<MATH>(-MT::div_pos(MT::sqrt_pos(m), C.shell), EK);
     // |ro| and g.ro of the closest obstacle were computed by the lane that
     // owns it (same operands, same bits as recomputing them here)
     const int bl = bi & 63;

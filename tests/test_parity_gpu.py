@@ -1249,15 +1249,16 @@ def test_checkpoint_carries_the_step_variant(pmaf, oracle, scenes, blob_case):
         ka[::4] = 0.0
         sc["k_attr"] = ka
     hip, ora = make_pair(pmaf, oracle, sc)
+    obs = sc["obstacles"]
     for t in range(6):
-        assert hip.tick(None, sc["dt"], sc["cost_gains"], sc["ws_limits"]) == ora.tick(None, sc["dt"], sc["cost_gains"], sc["ws_limits"])
+        assert hip.tick(obs, sc["dt"], sc["cost_gains"], sc["ws_limits"]) == ora.tick(obs, sc["dt"], sc["cost_gains"], sc["ws_limits"])
     blob = hip.save_state()
     hip.stop(); hip.close()
     plain = scenes.config_scene("C2", scene_id=1)          # unit mass, k_attr != 0 everywhere: the PLAIN step
     hip2 = pmaf.PmafPlanner(plain, device=0)
     hip2.load_state(blob)
     for t in range(6):
-        assert hip2.tick(None, sc["dt"], sc["cost_gains"], sc["ws_limits"]) == ora.tick(None, sc["dt"], sc["cost_gains"], sc["ws_limits"])
+        assert hip2.tick(obs, sc["dt"], sc["cost_gains"], sc["ws_limits"]) == ora.tick(obs, sc["dt"], sc["cost_gains"], sc["ws_limits"])
     hip2.stop()
     assert_state_equal(hip2, ora)
     np.testing.assert_allclose(hip2.costs(), ora.costs(), rtol=0, atol=0)

@@ -114,8 +114,13 @@ __device__ __forceinline__ void rollout_w64_body(const DevView &D, const CostPar
   constexpr bool PRE = (TILES == 1);
   double s_pre = 0.0;
   V3 ron_pre = mk(0.0, 0.0, 0.0);
+  // attractorForce's desired velocity (k_attr / k_damp) * g rides in lane 61 as `other * lane_scale`: the lane holds the
+  // goal like lane 63 (one-slot kernel; the others use g directly) and lane_scale is the gain ratio there, 1.0 in every
+  // other lane (x * 1.0 == x): three multiplies instead of three 64-bit selects per step
+  double lane_scale = (lane == 61) ? (k_attr / k_damp) : 1.0;
+  asm volatile("" : "+v"(lane_scale));
   if (PRE) {
-    if (lane == 63) { O.p[0] = goal; O.v[0] = mk(0.0, 0.0, 0.0); }
+    if (lane == 63 || lane == 61) { O.p[0] = goal; O.v[0] = mk(0.0, 0.0, 0.0); }
     MT::norm_unit(O.p[0] - p, s_pre, ron_pre);
   }
   V3 verr = attractor_velocity_error<MATH>(v, g, C, k_attr, k_damp);
@@ -205,8 +210,8 @@ __device__ __forceinline__ void rollout_w64_body(const DevView &D, const CostPar
       // the same operations on the same operands as separate sequences, read back with v_readlane.
       const V3 vel_des = (k_attr / k_damp) * g;
       const bool l_nv = (lane == 62), l_des = (lane == 61);
-      const V3 other = PRE ? (O.p[0] - p) : g;   // one-slot kernel: lane 63 holds the goal, O.p - p = g there
-      const V3 vec = l_nv ? nv : (l_des ? vel_des : other);
+      const V3 other = PRE ? (O.p[0] - p) : g;   // one-slot kernel: lanes 63 and 61 hold the goal, O.p - p = g there
+      const V3 vec = l_nv ? nv : (other * lane_scale);   // lane 61: (k_attr / k_damp) * g = vel_des, the same product
       V3 num = vec;
       num.x = (l_nv || l_des) ? C.vel_max : vec.x;
       // normalized(): the vector itself unless squaredNorm > 0 -- by ONE select on the divisor (x / 1.0 == x for every
@@ -240,7 +245,9 @@ __device__ __forceinline__ void rollout_w64_body(const DevView &D, const CostPar
       for (int t = 0; t < TILES; t++) O.p[t] = O.p[t] + O.v[t] * C.dt;
       advance = moving;
     }
-    if (sent_reachable) {  // the only masked block of the step for the repulsive obstacle: advance it, next step's repelForce
+    // (decided at run time in the multi-slot kernels: out of line there -- in the shipped scenes the obstacle sits 170 m
+    // away, and a block that is skipped costs a taken branch per step)
+    if ((SENT == 2) ? PMAF_RARE(sent_reachable) : sent_reachable) {  // the only masked block of the step for the repulsive obstacle: advance it, next step's repelForce
       sent_p = sent_p + sent_v * C.dt;
       repel = sentinel_repel(p, C, k_repel, sent_p, sent_r, zsent_lt);
     }

@@ -318,7 +318,7 @@ __device__ __forceinline__ void circ_and_scale_w64(int lane, V3 p, V3 v, double 
     rv_t[t] = v - O.v[t];
     double s;
     if (PRE) { s = s_pre; ron_t[t] = ron_pre; }
-    else MT::norm_unit(ro, s, ron_t[t]);
+    else MT::template norm_unit<true>(ro, s, ron_t[t]);   // (normalized() by one select on the divisor)
     const lmask skip_m = PMAF_BAL(dot(ron_t[t], gn) < -0.01) & PMAF_BAL(dot(ro, rv_t[t]) < -0.01);
     double d = s - (C.rad + O.r[t]);
     d = smax(d, 1e-5);
@@ -471,7 +471,15 @@ __device__ __forceinline__ void circ_and_scale_w64(int lane, V3 p, V3 v, double 
     if (TILES == 1) {  // obstacle index == lane: lowest candidate lane wins
       bi = cand_m ? (__ffsll((long long)cand_m) - 1) : 0x7fffffff;
     } else {
-      bi = wave_min64_i(PMAF_LANE(cand_m) ? best_i : 0x7fffffff);
+      // several slots per lane: the lowest obstacle index among the candidates = the lowest candidate lane of the
+      // lowest slot that has one (index = slot * 64 + lane) -- scalar bit operations on the candidates' masks per
+      // slot instead of a six-stage DPP minimum over the indices
+      bi = 0x7fffffff;
+#pragma unroll
+      for (int t = TILES - 1; t >= 0; t--) {
+        const lmask ct = cand_m & PMAF_BAL((best_i >> 6) == t);
+        bi = ct ? (t * 64 + __ffsll((long long)ct) - 1) : bi;
+      }
     }
     // (the chunk fetched above is not touched before the closest-obstacle reduction is through: the scheduler, left
     // alone, starts the sum ten instructions behind the ds_read and waits for it there)

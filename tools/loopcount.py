@@ -36,7 +36,7 @@ for name, k in KERNELS.items():
             loops.append((h, e, sum(1 for l in body if sp.is_instr(l))))
     loops.sort()
     print(name, "step loops (instructions in extent):", [n for _, _, n in loops])
-    if loops and "C2" in name:
+    if loops and os.environ.get("LOOPCOUNT_KERNEL", "C2") in name:
         h, e, _ = min(loops, key=lambda t: t[2])
         hist = collections.Counter(re.sub(r"_e(32|64)$", "", l.split()[0]) for l in lines[h:e + 1] if sp.is_instr(l))
         print("   smallest loop:", ", ".join("%s %d" % kv for kv in hist.most_common(14)))

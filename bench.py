@@ -124,7 +124,7 @@ def kernel_name_of(cfg, n_obs):
     generic = os.environ.get("PMAF_FORCE_GENERIC") == "1"
     if cfg["lanes_per_agent"] == 64 and tiles <= 4 and not generic:
         t = 1 if tiles <= 1 else 2 if tiles == 2 else 4
-        dpp = t > 1 or (n_obs - 1) > 20
+        dpp = True    # (rounds 1-2: LDS batches for <= 20 obstacles; round 3: the DPP chain for every count)
         if os.environ.get("PMAF_SUM"):
             dpp = t > 1 or os.environ["PMAF_SUM"].startswith("d")
         # <TILES, MATH_XACT, DPPSUM, PLAIN>; the bench scenes have k_attr != 0 and unit mass = the PLAIN step

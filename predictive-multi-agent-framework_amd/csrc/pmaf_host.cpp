@@ -312,8 +312,7 @@ static void launch_rollout(pmaf_planner *h) {
     if (e1) HIP_CHECK(hipEventRecord(e1, h->stream));
     ok = true;
   } else if (h->lpa == 64 && tiles64 <= 4 && !h->force_generic)
-    // ordered force sum: DPP chain from ~20 field obstacles up (lists long enough to need several LDS round trips),
-    // LDS batches below (pmaf_rollout_w64.hpp, tools/msweep.py)
+    // ordered force sum: the DPP chain (h->dpp_sum, see pmaf_create), LDS batches on request (pmaf_rollout_w64.hpp)
     ok = pmaf_k_launch_w64(h->D, h->cp, tiles64, h->math, h->dpp_sum, h->plain_step, h->lds_rollout, h->stream, e0, e1);
   else if (!h->force_generic && (h->lpa == 32 || h->lpa == 16 || h->lpa == 8) && (M + h->lpa - 1) / h->lpa <= 4)
     // (the opt-in fast arithmetic exists for the w64 kernels only)
@@ -692,7 +691,10 @@ int pmaf_create(const pmaf_params *prm, pmaf_planner **out) {
     { const char *fg = getenv("PMAF_FORCE_GENERIC"); h->force_generic = fg && fg[0] == '1'; }
     { const char *ab = getenv("PMAF_ABLATE"); D.ablate = ab ? atoi(ab) : 0; }
     { const char *to = getenv("PMAF_EXCHANGE_TIMEOUT_S"); if (to && atof(to) > 0.0) h->exchange_timeout_s = atof(to); }
-    h->dpp_sum = M > 20;
+    // ordered force sum: the DPP chain for every obstacle count (round 3: with the first chunk's accumulates fused and
+    // interleaved with the scaling chain it also wins for short lists -- C1, nine obstacles: 121.3 -> 111.8 us; rounds 1-2
+    // switched to LDS batches below 21 obstacles). PMAF_SUM=lds selects the LDS-batch kernels (tests, timing).
+    h->dpp_sum = true;
     { const char *ds = getenv("PMAF_SUM"); if (ds && ds[0]) h->dpp_sum = (ds[0] == 'd'); }  // "dpp" / "lds": tests, timing
     {
       int cus = 0;

@@ -439,7 +439,7 @@ __device__ __forceinline__ void circ_and_scale_w64(int lane, V3 p, V3 v, double 
 #define PMAF_SUM_HOIST 3
 #endif
 #ifndef PMAF_SUM_FMAC1
-#define PMAF_SUM_FMAC1 0
+#define PMAF_SUM_FMAC1 1
 #endif
   // The first chunk of the list is fetched HERE, in front of the attractor-scaling chain (round 3): issued behind the
   // compaction stores (a wave's DS instructions execute in order), its LDS round trip runs under that chain instead
@@ -530,7 +530,29 @@ __device__ __forceinline__ void circ_and_scale_w64(int lane, V3 p, V3 v, double 
     double one = 1.0;
     asm volatile("" : "+v"(one));
     double e = HOISTN ? e_first : 0.0;
-    for (int c16 = 0; c16 < count; c16 += 16) {
+    int c16 = 0;
+#ifndef PMAF_SUM_PEELN
+#define PMAF_SUM_PEELN 1
+#endif
+    if (HOISTN && PMAF_SUM_PEELN) {
+      // Round 3: the FIRST chunk as sixteen separate statements in the block of the attractor-scaling chain. A fused
+      // accumulate needs two issue slots of distance to the next one, so a chunk in one asm block is 16 instructions in
+      // 32 slots; the scaling chain (sqrt -> divide -> exp -> divide) is a second dependent chain with the same
+      // property and nothing in common with this one -- as separate statements the scheduler can put the one into the
+      // other's empty slots. Hazards as in the block below: the DPP source comes out of a ds_read (the s_nop covers a
+      // copy the register allocator might place in front), EXEC is only written by SALU instructions on this path.
+      double en = clist[(16 << 2) + lane];
+      asm volatile("s_nop 1" : "+v"(e));
+#define PMAF_FM1(K) asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:" #K " row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(e), "v"(one));
+      PMAF_FM1(0) PMAF_FM1(1) PMAF_FM1(2) PMAF_FM1(3) PMAF_FM1(4) PMAF_FM1(5) PMAF_FM1(6) PMAF_FM1(7)
+      PMAF_FM1(8) PMAF_FM1(9) PMAF_FM1(10) PMAF_FM1(11) PMAF_FM1(12) PMAF_FM1(13) PMAF_FM1(14) PMAF_FM1(15)
+#undef PMAF_FM1
+      asm volatile("s_nop 0" : "+v"(acc));   // (a v_readlane / the next block's DPP reads acc next)
+      e = en;
+      c16 = 16;
+      asm volatile("" : : "v"(sc));          // the scaling value is complete in THIS block (not sunk behind the loop)
+    }
+    for (; c16 < count; c16 += 16) {
       double en = 0.0;
       if (HOISTN) en = clist[((c16 + 16) << 2) + lane];   // (behind the last chunk: padding / scratch, never used)
       else e = clist[(c16 << 2) + lane];

@@ -1178,8 +1178,8 @@ def test_many_agents_with_200_obstacles_stay_on_the_four_slot_kernel(pmaf, oracl
 @pytest.mark.parametrize("cfg,ticks,dynamic", [("C1", 12, False), ("C2", 10, True)])
 def test_both_ordered_sum_variants_of_the_one_slot_kernel(pmaf, oracle, scenes, monkeypatch, mode, cfg, ticks, dynamic):
     """the ordered force sum of the wave-per-agent kernel exists in two variants
-    (LDS batches for short lists, DPP row_newbcast chain for long ones; the host
-    picks by obstacle count): both on both configs, bit-exact, plus a dense scene
+    (LDS batches, the rounds-1/2 choice for short lists, and the DPP row_newbcast chain the
+    host picks for every obstacle count since round 3): both on both configs, bit-exact, plus a dense scene
     with up to 61 in-shell terms (4 chunks of 16, chunk-boundary padding)"""
     monkeypatch.setenv("PMAF_SUM", mode)
     sc = scenes.config_scene(cfg, dynamic=dynamic) if cfg != "C1" else scenes.config_scene(cfg)

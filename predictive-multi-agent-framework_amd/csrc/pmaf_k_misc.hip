@@ -234,6 +234,14 @@ __global__ __launch_bounds__(64) void k_manager(DevView D, CostParams CP, Manage
 #ifdef PMAF_TICK_STAMPS
   const unsigned long long t_mgr0 = wall_clock64();
 #endif
+#ifdef PMAF_MGR_SECTIONS   // timing experiments only: where the manager step's time goes (10 ns ticks, printed by population 0)
+  unsigned long long t_sec[8];
+  int n_sec = 0;
+#define PMAF_MSEC() do { __builtin_amdgcn_s_waitcnt(0); t_sec[n_sec++] = wall_clock64(); } while (0)
+#else
+#define PMAF_MSEC() do { } while (0)
+#endif
+  PMAF_MSEC();
   const int lane = threadIdx.x;
   const int pop = blockIdx.x;
   const int n_obs = D.n_obs;
@@ -303,6 +311,7 @@ __global__ __launch_bounds__(64) void k_manager(DevView D, CostParams CP, Manage
   }
   // random vectors the real agent's heuristic uses (best_agent_'s copy)
   const double *rand_g = D.best_rnd + (size_t)pop * 3 * n_obs;
+  PMAF_MSEC();   // 1: up-front loads, live obstacles in LDS
 
   if (A.do_select) {
     // cost assembly + argmin, B/src/cf_manager.cpp:325-343
@@ -350,7 +359,7 @@ __global__ __launch_bounds__(64) void k_manager(DevView D, CostParams CP, Manage
     best = min_idx;
     if (lane == 0) D.best_idx[pop] = best;
   }
-
+  PMAF_MSEC();   // 2: selection
   if (A.do_move) {
     // RealCfAgent::cfPlanner one step, B/src/cf_agent.cpp:343-366
     int gid = A.agent_id ? A.agent_id[pop] : best;
@@ -405,6 +414,7 @@ __global__ __launch_bounds__(64) void k_manager(DevView D, CostParams CP, Manage
     }
   }
 
+  PMAF_MSEC();   // 3: the real agent's step
   // header of this population's winner record (sharded runs): the selection just made, with the path length the
   // selected agent's rollout had when it was scored and the set-point the real agent moves to. Written BEFORE the
   // mailbox's sequence number (system-scope fence below): once the host has seen that number the header is visible
@@ -461,6 +471,7 @@ __global__ __launch_bounds__(64) void k_manager(DevView D, CostParams CP, Manage
     }
   }
 
+  PMAF_MSEC();   // 4: published (mailbox, fence)
   if (A.do_reset) {
     // resetEEAgents, B/src/cf_manager.cpp:246-255
     V3 sp, sv;
@@ -505,6 +516,13 @@ __global__ __launch_bounds__(64) void k_manager(DevView D, CostParams CP, Manage
 #ifdef PMAF_TICK_STAMPS
   if (lane == 0 && pop == 0) printf("M %llu %llu\n", t_mgr0, wall_clock64());
 #endif
+#ifdef PMAF_MGR_SECTIONS
+  PMAF_MSEC();   // 5: reset
+  if (lane == 0 && pop == 0)
+    printf("MGR loads %llu select %llu real-step %llu publish %llu reset %llu | total %llu (x10 ns)\n", t_sec[1] - t_sec[0],
+           t_sec[2] - t_sec[1], t_sec[3] - t_sec[2], t_sec[4] - t_sec[3], t_sec[5] - t_sec[4], t_sec[5] - t_sec[0]);
+#endif
+#undef PMAF_MSEC
 }
 
 // CfAgent::setPosition for every predicted agent (clear + push_back,

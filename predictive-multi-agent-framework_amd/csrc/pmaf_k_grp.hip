@@ -101,17 +101,21 @@ __global__ __launch_bounds__(64) void k_rollout_grp(DevView D, CostParams CP) {
   const unsigned lin_block = blockIdx.y * gridDim.x + blockIdx.x;
   const bool shared_simd = gridDim.x * gridDim.y > (unsigned)D.n_simds;
   const bool younger = ((lin_block / (unsigned)D.n_simds) & 1u) != 0u;
+  const lmask active_m = PMAF_BAL(a < D.N);   // (outside the loop: a ballot of a hoisted compare would go through a VGPR)
   while (true) {
-    const bool run = active && (dg > 0.1) && (n < D.cap);  // B/src/cf_agent.cpp:310-311, per agent
-    if (!wave_any(run)) break;
+    // B/src/cf_agent.cpp:310-311, per agent -- as a lane mask built from single compares (pmaf_rollout_w64.hpp)
+    const lmask run_m = active_m & PMAF_BAL(dg > 0.1) & PMAF_BAL(n < D.cap);
+    if (run_m == 0ull) break;
+    const bool run = PMAF_LANE(run_m);
     unsigned long long clk = 0ull;
     if (shared_simd) clk = wall_clock64();
-    const bool gate = !(dg < C.approach || (zv < C.zvhalf_lt && z_init < C.zinit_lt));  // :315-317
+    // gate, :315-317
+    const lmask gate_m = ~(PMAF_BAL(dg < C.approach) | (PMAF_BAL(zv < C.zvhalf_lt) & PMAF_BAL(z_init < C.zinit_lt)));
     const V3 verr = attractor_velocity_error<MATH>(v, g, C, k_attr, k_damp);
     V3 F = mk(0.0, 0.0, 0.0);
     double scale = 1.0;
-    if (wave_any(run && gate))
-      circ_and_scale_grp<LPA, TILES, MATH>(run && gate, sub, grp, type, p, v, zv, goal, g, dg, C, k_circ, n_obs, rot_g,
+    if ((run_m & gate_m) != 0ull)
+      circ_and_scale_grp<LPA, TILES, MATH>(run_m & gate_m, sub, grp, type, p, v, zv, goal, g, dg, C, k_circ, n_obs, rot_g,
                                      known_bits, O, clist, lane_min, F, scale, s_expk);
     V3 new_pos;
     V3 nv = v;

@@ -99,41 +99,47 @@ __device__ __forceinline__ V3 closest_other_grp(bool srch, int t, int sub, int g
 // clist: this GROUP's list in LDS (LPA*TILES entries of 4 doubles + one
 // all-zero entry at index LPA*TILES).
 template <int LPA, int TILES, int MATH>
-__device__ __forceinline__ void circ_and_scale_grp(bool act, int sub, int grp, int type, V3 p, V3 v, double zv,
+__device__ __forceinline__ void circ_and_scale_grp(lmask act_m, int sub, int grp, int type, V3 p, V3 v, double zv,
                                                    V3 goal, V3 g, double dg, const PopConst &C, double k_circ,
                                                    int n_obs, double *rot_g, unsigned &known_bits,
                                                    LaneObstacles<TILES> &O, double *clist, double &lane_min, V3 &F,
                                                    double &scale, const double *exp_tab) {
+  // Lane predicates as scalar masks built from single-compare ballots (pmaf_rollout_w64.hpp, "lane predicates as
+  // masks": a vote on a compound predicate costs two VALU instructions, and this kernel is VALU-issue bound).
   typedef Mth<MATH> MT;
   const int M = n_obs - 1;
   const V3 gn = MT::div3(g, (dg > 0.0) ? dg : 1.0);  // goal_vec.normalized(): x / 1.0 == x
   double best_d = C.shell;
   double best_s = 0.0, best_gr = 0.0;
   int best_i = 0x7fffffff;
+  lmask has_best_m = 0ull;
   int count = 0;
   const unsigned long long gmask = ((1ull << LPA) - 1ull) << (grp * LPA);
   const unsigned long long below = gmask & ((1ull << (grp * LPA + sub)) - 1ull);
 #pragma unroll
   for (int t = 0; t < TILES; t++) {
     const int i = t * LPA + sub;
-    const bool valid = act && (i < M);
+    const lmask valid_m = act_m & PMAF_BAL(i < M);
     const V3 op = O.p[t];
     const V3 ro = op - p;
     const V3 rv = v - O.v[t];
     double s;
     V3 ron;
     MT::template norm_unit<true>(ro, s, ron);
-    const bool skip = (dot(ron, gn) < -0.01) && (dot(ro, rv) < -0.01);
+    const lmask skip_m = PMAF_BAL(dot(ron, gn) < -0.01) & PMAF_BAL(dot(ro, rv) < -0.01);
     double d = s - (C.rad + O.r[t]);
     d = smax(d, 1e-5);
-    if (valid && d < best_d) { best_d = d; best_i = i; best_s = s; best_gr = dot(g, ro); }
-    const bool live = valid && !skip;
-    if (live && d < lane_min) lane_min = d;
-    const bool in_shell = live && (d < C.shell);
-    if (wave_any(in_shell)) {
-      const bool need_latch = in_shell && !((known_bits >> t) & 1u);
-      if (PMAF_RARE(wave_any(need_latch))) {
+    const lmask closer_m = valid_m & PMAF_BAL(d < best_d);
+    has_best_m |= closer_m;
+    if (PMAF_LANE(closer_m)) { best_d = d; best_i = i; best_s = s; best_gr = dot(g, ro); }
+    const lmask live_m = valid_m & ~skip_m;
+    if (PMAF_LANE(live_m & PMAF_BAL(d < lane_min))) lane_min = d;
+    const lmask in_m = live_m & PMAF_BAL(d < C.shell);
+    if (in_m != 0ull) {
+      const lmask need_latch_m = in_m & PMAF_BAL((known_bits & (1u << t)) == 0u);
+      if (PMAF_RARE(need_latch_m != 0ull)) {
         V3 cpos = op;
+        const bool need_latch = PMAF_LANE(need_latch_m);
         const bool srch = need_latch && (type == T_OBST || type == T_GOALOBST);
         if (PMAF_RARE(wave_any(srch))) cpos = closest_other_grp<LPA, TILES, MATH>(srch, t, sub, grp, M, O);
         if (need_latch) {
@@ -144,14 +150,16 @@ __device__ __forceinline__ void circ_and_scale_grp(bool act, int sub, int grp, i
         }
       }
       const V3 rot = mk(O.rx[t], O.ry[t], O.rz[t]);
+      // |rv| is only divided by and compared with 0 (sqrt(z) != 0 <=> z != 0): no zero / infinity select behind the
+      // root, fixup-free divisions -- for z == 0 the term is discarded (has_m)
+      const double zrv = sqn(rv);
       double vn, rvn;
-      MT::norm_rcp(rv, vn, rvn);
-      const V3 nv = MT::div3_n(rv, vn, rvn);
+      MT::norm_rcp_zpos(zrv, vn, rvn);
+      const V3 nv = MT::div3_n_pos(rv, vn, rvn);
       const V3 cur = current_vector<MATH, true>(type, rv, g, ron, rot);
-      const V3 c = MT::div(k_circ, d * d) * cross(nv, cross(cur, nv));
-      const bool has_c = in_shell && (vn != 0);
-      const unsigned long long m = wave_ballot(has_c);
-      if (has_c) {
+      const V3 c = MT::div_pos(k_circ, d * d) * cross(nv, cross(cur, nv));   // d >= 1e-5
+      const lmask m = in_m & PMAF_BAL(zrv != 0);   // vel_norm != 0, B/src/cf_agent.cpp:98
+      if (PMAF_LANE(m)) {
         PMAF_BOUND(count + __popcll(m & below) < LPA * TILES);
         double *e = clist + (size_t)(count + __popcll(m & below)) * 4;
         e[0] = c.x; e[1] = c.y; e[2] = c.z;
@@ -160,11 +168,11 @@ __device__ __forceinline__ void circ_and_scale_grp(bool act, int sub, int grp, i
     }
   }
   const double m = group_min_dpp<LPA>(best_d);
-  if (wave_any(count > 0)) {
+  if (PMAF_BAL(count > 0) != 0ull) {
     wave_lds_fence();
     // F = ((0 + c_0) + c_1) + ... per group; a group that has run out of terms adds +0.0 (exact no-op)
     // (lanes past their group's last term read the group's all-zero slot)
-    for (int k = 0; wave_any(k < count); k += 4) {
+    for (int k = 0; PMAF_BAL(k < count) != 0ull; k += 4) {
 #pragma unroll
       for (int j = 0; j < 4; j++) {
         const int idx = ((k + j) < count) ? (k + j) : (LPA * TILES);
@@ -176,10 +184,10 @@ __device__ __forceinline__ void circ_and_scale_grp(bool act, int sub, int grp, i
     }
     wave_lds_fence();
   }
-  const bool want_scale = act && (sqn(F) >= C.zf_gt);  // norm(F) > 1e-5
-  if (wave_any(want_scale)) {
-    const bool cand = (best_i != 0x7fffffff) && (best_d == m);
-    const int bi = group_min_dpp_i<LPA>(cand ? best_i : 0x7fffffff);
+  const lmask want_m = act_m & PMAF_BAL(sqn(F) >= C.zf_gt);  // norm(F) > 1e-5
+  if (want_m != 0ull) {
+    const lmask cand_m = has_best_m & PMAF_BAL(best_d == m);
+    const int bi = group_min_dpp_i<LPA>(PMAF_LANE(cand_m) ? best_i : 0x7fffffff);
     const int src = grp * LPA + ((bi == 0x7fffffff) ? 0 : (bi & (LPA - 1)));
     // closest obstacle's |ro| and g.ro live in the owning lane's slot registers
     // of tile bi / LPA; its best_* registers hold them iff that lane's own
@@ -196,7 +204,7 @@ __device__ __forceinline__ void circ_and_scale_grp(bool act, int sub, int grp, i
       w2 = w2 * w2;
       sc = w1 * w2;
     }
-    if (want_scale) scale = sc;
+    if (PMAF_LANE(want_m)) scale = sc;
   }
 }
 

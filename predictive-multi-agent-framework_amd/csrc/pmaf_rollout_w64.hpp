@@ -90,8 +90,7 @@ __device__ __forceinline__ void finish_step_w64(V3 p, V3 &v, V3 verr, V3 F, doub
   double vn, rvn;
   Mth<MATH>::norm_rcp(nv, vn, rvn);
   const double f = Mth<MATH>::div_n_pos(C.vel_max, vn, rvn);  // only used when vn > vel_max
-  const V3 cl = nv * f;
-  v = (vn > C.vel_max) ? cl : nv;
+  v = nv * ((vn > C.vel_max) ? f : 1.0);   // (select on the factor: nv * 1.0 is nv exactly)
 }
 
 // Can the repulsive obstacle come into range at all during this rollout? Per

@@ -116,6 +116,16 @@ __device__ __forceinline__ void circ_and_scale_grp(lmask act_m, int sub, int grp
   int count = 0;
   const unsigned long long gmask = ((1ull << LPA) - 1ull) << (grp * LPA);
   const unsigned long long below = gmask & ((1ull << (grp * LPA + sub)) - 1ull);
+  // The group's list is cleared first (round 3): the sum below then reads entry k for every k the longest list of the
+  // wave reaches -- a shorter list is followed by +0.0 entries (exact no-ops) -- without the per-entry clamp of the
+  // index to an all-zero slot (a compare, a select and an address computation per entry: VALU instructions, which bound
+  // this kernel; the clearing is TILES LDS stores per lane with loop-invariant addresses).
+  {
+    double2 *z = reinterpret_cast<double2 *>(clist) + sub * 2 * TILES;
+#pragma unroll
+    for (int q = 0; q < 2 * TILES; q++) z[q] = make_double2(0.0, 0.0);
+    wave_lds_fence();   // (compiler ordering only: the terms' stores below go to the same entries)
+  }
 #pragma unroll
   for (int t = 0; t < TILES; t++) {
     const int i = t * LPA + sub;
@@ -172,14 +182,13 @@ __device__ __forceinline__ void circ_and_scale_grp(lmask act_m, int sub, int grp
     wave_lds_fence();
     // F = ((0 + c_0) + c_1) + ... per group; a group that has run out of terms adds +0.0 (exact no-op)
     // (lanes past their group's last term read the group's all-zero slot)
-    for (int k = 0; PMAF_BAL(k < count) != 0ull; k += 4) {
+    for (int k = 0; PMAF_BAL(k < count) != 0ull; k += 4) {   // k + 3 <= LPA * TILES - 1: count <= LPA * TILES
+      const double *e = clist + (size_t)k * 4;
 #pragma unroll
       for (int j = 0; j < 4; j++) {
-        const int idx = ((k + j) < count) ? (k + j) : (LPA * TILES);
-        const double *e = clist + (size_t)idx * 4;
-        F.x = F.x + e[0];
-        F.y = F.y + e[1];
-        F.z = F.z + e[2];
+        F.x = F.x + e[j * 4];
+        F.y = F.y + e[j * 4 + 1];
+        F.z = F.z + e[j * 4 + 2];
       }
     }
     wave_lds_fence();

@@ -345,23 +345,36 @@ __global__ __launch_bounds__(64) void k_rollout_w64(DevView D, CostParams CP) {
 #endif
 #define PMAF_CAT2(a, b) a##b
 #define PMAF_CAT(a, b) PMAF_CAT2(a, b)
-bool PMAF_CAT(pmaf_k_launch_w64_m, PMAF_W64_MATH)(const DevView &D, const CostParams &cp, int tiles, bool dppsum,
-                                                  bool plain, size_t lds, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
+// PMAF_W64_PART (csrc/build.sh, default policy only): the translation unit holds the one-slot kernels (1) or the
+// multi-slot kernels (2) alone -- the two are compiled with different pre-RA scheduling directions (measured per
+// kernel family: build.sh); undefined = all of them in one unit.
+#if defined(PMAF_W64_PART) && PMAF_W64_PART == 1
+#define PMAF_W64_LAUNCH PMAF_CAT(PMAF_CAT(pmaf_k_launch_w64_m, PMAF_W64_MATH), _t1)
+#elif defined(PMAF_W64_PART) && PMAF_W64_PART == 2
+#define PMAF_W64_LAUNCH PMAF_CAT(PMAF_CAT(pmaf_k_launch_w64_m, PMAF_W64_MATH), _tn)
+#else
+#define PMAF_W64_LAUNCH PMAF_CAT(pmaf_k_launch_w64_m, PMAF_W64_MATH)
+#endif
+bool PMAF_W64_LAUNCH(const DevView &D, const CostParams &cp, int tiles, bool dppsum,
+                     bool plain, size_t lds, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
   const dim3 g64((unsigned)D.N, (unsigned)D.P), block(64);
 #define PMAF_L(K) hipExtLaunchKernelGGL(K, g64, block, (unsigned)lds, s, e0, e1, 0, D, cp)
-  // one slot per lane: both ordered-sum variants (the host picks by obstacle count); two / four slots: DPP only
+  // one slot per lane: both ordered-sum variants (the host picks); two / four slots: DPP only
 #ifdef PMAF_ONLY_W64_1_DPP   // tools/slackprof: a translation unit that holds the C2 kernel alone (same ISA as the product's)
   if (tiles <= 1 && dppsum && plain) { PMAF_L((k_rollout_w64<1, PMAF_W64_MATH, true, true>)); return true; }
   return false;
 #endif
 #define PMAF_LP(T, S) do { if (plain) PMAF_L((k_rollout_w64<T, PMAF_W64_MATH, S, true>)); \
                            else PMAF_L((k_rollout_w64<T, PMAF_W64_MATH, S, false>)); } while (0)
-  if (tiles <= 1 && !dppsum) PMAF_LP(1, false);
-  else if (tiles <= 1) PMAF_LP(1, true);
-  else if (tiles == 2) PMAF_LP(2, true);
-  else if (tiles <= 4) PMAF_LP(4, true);
-  else return false;
+#if !defined(PMAF_W64_PART) || PMAF_W64_PART == 1
+  if (tiles <= 1 && !dppsum) { PMAF_LP(1, false); return true; }
+  if (tiles <= 1) { PMAF_LP(1, true); return true; }
+#endif
+#if !defined(PMAF_W64_PART) || PMAF_W64_PART == 2
+  if (tiles == 2) { PMAF_LP(2, true); return true; }
+  if (tiles > 2 && tiles <= 4) { PMAF_LP(4, true); return true; }
+#endif
 #undef PMAF_LP
 #undef PMAF_L
-  return true;
+  return false;
 }

@@ -636,6 +636,44 @@ __device__ __forceinline__ V3 calc_rot_vec_c(int type, V3 agent_pos, V3 goal_pos
   return mk(0.0, 0.0, 0.0);
 }
 
+// calc_rot_vec_c for callers that already hold the step's geometry (the tuned kernels' first-contact latch): to_obs =
+// normalized(own_pos - agent_pos) (the sweep's ro.normalized() of this slot), goal_vec = goal_pos - agent_pos, goal_dist
+// = norm(goal_vec), goal_dir = goal_vec.normalized() -- the same operations on the same operands as the ones
+// calc_rot_vec_c performs (every sequence is correctly rounded, so the bits are the same), which takes one
+// sqrt / reciprocal / divide chain out of every latch: the Random heuristic's latch (59 of C2's 64 agents, every first
+// contact of every rollout) is then one cross product.
+template <int MATH = MATH_IEEE>
+__device__ __forceinline__ V3 calc_rot_vec_pre(int type, V3 agent_pos, int n_obs, V3 own_pos, V3 closest_pos,
+                                               V3 rand_vec, V3 to_obs, V3 goal_vec, double goal_dist, V3 goal_dir) {
+  typedef Mth<MATH> M;
+  if (type == T_GOAL || type == T_VEL) return mk(0.0, 0.0, 1.0);
+  if (type == T_OBST) {
+    if (n_obs < 2) return mk(0.0, 0.0, 1.0);
+    V3 obstacle_vec = closest_pos - own_pos;
+    V3 cur = to_obs * dot(obstacle_vec, to_obs) - obstacle_vec;
+    return M::normalized(cross(cur, to_obs));
+  }
+  if (type == T_GOALOBST) {
+    V3 obstacle_vec = closest_pos - own_pos;
+    V3 obst_cur = to_obs * dot(obstacle_vec, to_obs) - obstacle_vec;
+    V3 goal_cur = goal_vec - to_obs * dot(to_obs, goal_vec);
+    V3 cur = M::normalized(goal_cur) + M::normalized(obst_cur);
+    double s;
+    V3 u;
+    M::norm_unit(cur, s, u);
+    cur = (s < 1e-10) ? mk(0.0, 0.0, 1.0) : u;
+    return M::normalized(cross(cur, to_obs));
+  }
+  if (type == T_RANDOM) return cross(goal_dir, rand_vec);
+  if (type == T_HAD) {
+    V3 rob_obs = own_pos - agent_pos;
+    V3 d = (agent_pos + goal_vec * M::div(dot(rob_obs, goal_vec), goal_dist * goal_dist)) - own_pos;
+    V3 c = cross(d, goal_vec);
+    return M::div3(c, M::norm(c));
+  }
+  return mk(0.0, 0.0, 0.0);
+}
+
 __device__ __forceinline__ V3 calc_rot_vec(int type, V3 agent_pos, V3 goal_pos, const ObsTab &T,
                                            int n_obs, int id, V3 own_pos, V3 rand_vec) {
   V3 closest_pos = own_pos;

@@ -120,7 +120,10 @@ __device__ __forceinline__ void rollout_w64_body(const DevView &D, const CostPar
   double lane_scale = (lane == 61) ? (k_attr / k_damp) : 1.0;
   asm volatile("" : "+v"(lane_scale));
   if (PRE) {
-    if (lane == 63 || lane == 61) { O.p[0] = goal; O.v[0] = mk(0.0, 0.0, 0.0); }
+    // (velocity -0.0 for dt >= 0: p + (-0.0) dt leaves EVERY p as it is, a -0.0 goal coordinate included -- with +0.0
+    // it would turn into +0.0, and the goal direction read back from lane 63 also feeds the latch, calc_rot_vec_pre)
+    const double nz = (C.dt < 0.0) ? 0.0 : -0.0;
+    if (lane == 63 || lane == 61) { O.p[0] = goal; O.v[0] = mk(nz, nz, nz); }
     MT::norm_unit(O.p[0] - p, s_pre, ron_pre);
   }
   V3 verr = attractor_velocity_error<MATH>(v, g, C, k_attr, k_damp);
@@ -197,9 +200,8 @@ __device__ __forceinline__ void rollout_w64_body(const DevView &D, const CostPar
     g = goal - p;
     // predictObstacles, B/src/cf_agent.cpp:270-276, in registers. Obstacles at
     // rest: p + (+-0) dt is idempotent after its first application (which turns
-    // a -0.0 coordinate into +0.0), so later steps skip it. (Lane 63 of the one-slot kernel holds the goal with
-    // velocity 0: a -0.0 goal coordinate turns into +0.0 there, which can only change the sign of a zero component
-    // of gn, and gn only enters dot(ron, gn) < -0.01; g itself is computed from the goal directly.)
+    // a -0.0 coordinate into +0.0), so later steps skip it. (Lanes 63 / 61 of the one-slot kernel hold the goal with
+    // velocity -0.0: the update leaves it bit for bit.)
     // (one slot per lane: unconditionally -- for obstacles at rest every further application is the identity, and
     // three multiply-adds are cheaper than a branch in the middle of the tail)
     if (PRE) O.p[0] = O.p[0] + O.v[0] * C.dt;

@@ -153,7 +153,7 @@ __device__ __forceinline__ void circ_and_scale_grp(lmask act_m, int sub, int grp
         const bool srch = need_latch && (type == T_OBST || type == T_GOALOBST);
         if (PMAF_RARE(wave_any(srch))) cpos = closest_other_grp<LPA, TILES, MATH>(srch, t, sub, grp, M, O);
         if (need_latch) {
-          V3 rot = calc_rot_vec_c<MATH>(type, p, goal, n_obs, op, cpos, mk(O.qx[t], O.qy[t], O.qz[t]));
+          V3 rot = calc_rot_vec_pre<MATH>(type, p, n_obs, op, cpos, mk(O.qx[t], O.qy[t], O.qz[t]), ron, g, dg, gn);
           rot_g[i] = rot.x; rot_g[n_obs + i] = rot.y; rot_g[2 * n_obs + i] = rot.z;
           O.rx[t] = rot.x; O.ry[t] = rot.y; O.rz[t] = rot.z;
           known_bits |= (1u << t);

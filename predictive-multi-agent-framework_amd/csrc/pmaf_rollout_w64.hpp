@@ -372,7 +372,8 @@ __device__ __forceinline__ void circ_and_scale_w64(int lane, V3 p, V3 v, double 
       V3 cpos = O.p[t];
       if (type == T_OBST || type == T_GOALOBST) cpos = closest_other_w64<TILES, MATH>(need_latch_m, t, lane, M, O);
       if (PMAF_LANE(need_latch_m)) {
-        V3 rot = calc_rot_vec_c<MATH>(type, p, goal, n_obs, O.p[t], cpos, mk(O.qx[t], O.qy[t], O.qz[t]));
+        // (to_obs, the goal vector, its norm and direction are the sweep's / the caller's: calc_rot_vec_pre)
+        V3 rot = calc_rot_vec_pre<MATH>(type, p, n_obs, O.p[t], cpos, mk(O.qx[t], O.qy[t], O.qz[t]), ron_t[t], g, dg, gn);
         rot_g[i] = rot.x; rot_g[n_obs + i] = rot.y; rot_g[2 * n_obs + i] = rot.z;
         O.rx[t] = rot.x; O.ry[t] = rot.y; O.rz[t] = rot.z;
         known_bits |= (1u << t);

@@ -98,6 +98,25 @@ __global__ __launch_bounds__(64) void k_rollout_grp(DevView D, CostParams CP) {
   double dg = Mth<MATH>::norm(g);
   double zv = sqn(v);
   double z_init = sqn(p - init_pos);
+  // goal_vec.normalized() (x / 1.0 == x) and attractorForce's velocity error of the coming step: loop-carried, see the
+  // packed tail below
+  typedef Mth<MATH> MT;
+  V3 gn = MT::div3(g, (dg > 0.0) ? dg : 1.0);
+  V3 verr = attractor_velocity_error<MATH>(v, g, C, k_attr, k_damp);
+  // Packed tail (round 3, 16 and 32 lanes per agent: a group is one or two DPP rows). The step needs three norms of
+  // per-agent vectors -- |g| with g.normalized(), |nv| with vel_max / |nv| (speed clamp), vel_max / |vel_des|
+  // (attractorForce's limit) -- which every lane of the group used to evaluate as separate sqrt / reciprocal / divide
+  // sequences (~110 VALU instructions per step of a VALU-issue-bound kernel). Lanes 0 / 1 / 2 of each row now carry the
+  // three vectors through ONE sequence (the w64 kernel's idle-lane riders) and the results come back by DPP
+  // row_newbcast moves: the same operations on the same operands, so the same bits.
+#ifndef PMAF_GRP_PACK
+#define PMAF_GRP_PACK 1
+#endif
+  constexpr bool PACK = PMAF_GRP_PACK && (LPA >= 16);
+  const int rsub = sub & 15;
+  const bool l_nv = (rsub == 1), l_des = (rsub == 2);
+  double lane_scale = l_des ? (k_attr / k_damp) : 1.0;   // vel_des = (k_attr / k_damp) * g rides as g * lane_scale
+  asm volatile("" : "+v"(lane_scale));
   const unsigned lin_block = blockIdx.y * gridDim.x + blockIdx.x;
   const bool shared_simd = gridDim.x * gridDim.y > (unsigned)D.n_simds;
   const bool younger = ((lin_block / (unsigned)D.n_simds) & 1u) != 0u;
@@ -111,21 +130,58 @@ __global__ __launch_bounds__(64) void k_rollout_grp(DevView D, CostParams CP) {
     if (shared_simd) clk = wall_clock64();
     // gate, :315-317
     const lmask gate_m = ~(PMAF_BAL(dg < C.approach) | (PMAF_BAL(zv < C.zvhalf_lt) & PMAF_BAL(z_init < C.zinit_lt)));
-    const V3 verr = attractor_velocity_error<MATH>(v, g, C, k_attr, k_damp);
+    if (!PACK) verr = attractor_velocity_error<MATH>(v, g, C, k_attr, k_damp);
     V3 F = mk(0.0, 0.0, 0.0);
     double scale = 1.0;
     if ((run_m & gate_m) != 0ull)
-      circ_and_scale_grp<LPA, TILES, MATH>(run_m & gate_m, sub, grp, type, p, v, zv, goal, g, dg, C, k_circ, n_obs, rot_g,
-                                     known_bits, O, clist, lane_min, F, scale, s_expk);
+      circ_and_scale_grp<LPA, TILES, MATH>(run_m & gate_m, sub, grp, type, p, v, zv, goal, g, dg, gn, C, k_circ, n_obs,
+                                     rot_g, known_bits, O, clist, lane_min, F, scale, s_expk);
     V3 new_pos;
     V3 nv = v;
-    finish_step_w64<MATH>(p, nv, verr, F, scale, C, k_attr, k_repel, k_damp, sent_p, sent_r, zsent_lt, new_pos,
-                          sent_reachable);
+    if (PACK) {
+      // finish_step_w64 up to the new velocity (repelForce :159-181, attractorForce :183-193, the acceleration clamp and
+      // the integration :253-258) ...
+      if (sent_reachable) F = F + (mk(0.0, 0.0, 0.0) + sentinel_repel(p, C, k_repel, sent_p, sent_r, zsent_lt));
+      if (k_attr != 0.0) F = F + (scale * k_damp) * verr;
+      V3 acc = F;
+      if (C.mass != 1.0) acc = F / C.mass;
+      const double az = sqn(acc);
+      if (az >= C.zacc_gt) acc = acc * (13.0 / __builtin_sqrt(az));  // norm(acc) > 13.0 (rare)
+      const V3 half = ((0.5 * acc) * C.dt) * C.dt;
+      new_pos = (p + half) + (v * C.dt);
+      nv = v + acc * C.dt;
+    } else {
+      finish_step_w64<MATH>(p, nv, verr, F, scale, C, k_attr, k_repel, k_damp, sent_p, sent_r, zsent_lt, new_pos,
+                            sent_reachable);
+    }
     if (run) {
       p = new_pos;
-      v = nv;
       g = goal - p;
-      dg = Mth<MATH>::norm(g);
+      if (PACK) {
+        // ... and the three norms in one sequence: row lane 0 the goal vector, 1 the new velocity, 2 the desired velocity
+        const V3 vel_des = (k_attr / k_damp) * g;
+        const V3 other = g * lane_scale;
+        const V3 vec = mk(l_nv ? nv.x : other.x, l_nv ? nv.y : other.y, l_nv ? nv.z : other.z);
+        const double numx = (l_nv || l_des) ? C.vel_max : vec.x;
+        const double zvec = sqn(vec);
+        const double s = MT::sqrt(zvec);
+        // normalized(): the vector itself unless squaredNorm > 0, by a select on the divisor (x / 1.0 == x); the riders
+        // divide vel_max by their norm whatever it is (vel_max / 0 = inf: the fixup of the x component supplies it)
+        const double sd = ((zvec > 0.0) || l_nv || l_des) ? s : 1.0;
+        const double rs = MT::rcp_for(sd);
+        const V3 q = mk(MT::div_n(numx, sd, rs), MT::div_n_pos(vec.y, sd, rs), MT::div_n_pos(vec.z, sd, rs));
+#define PMAF_RB(x, K) __builtin_amdgcn_update_dpp(x, x, 0x150 + K, 0xf, 0xf, true)
+        dg = PMAF_RB(s, 0);
+        gn = mk(PMAF_RB(q.x, 0), PMAF_RB(q.y, 0), PMAF_RB(q.z, 0));
+        const double vn = PMAF_RB(s, 1), f_nv = PMAF_RB(q.x, 1), f_des = PMAF_RB(q.x, 2);
+#undef PMAF_RB
+        v = nv * ((vn > C.vel_max) ? f_nv : 1.0);   // (select on the factor: nv * 1.0 is nv exactly)
+        verr = vel_des * smin(1.0, f_des) - v;
+      } else {
+        v = nv;
+        dg = MT::norm(g);
+        gn = MT::div3(g, (dg > 0.0) ? dg : 1.0);
+      }
       zv = sqn(v);
       z_init = sqn(p - init_pos);
       PMAF_BOUND(n < D.cap);

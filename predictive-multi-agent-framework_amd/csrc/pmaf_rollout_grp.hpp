@@ -100,7 +100,7 @@ __device__ __forceinline__ V3 closest_other_grp(bool srch, int t, int sub, int g
 // all-zero entry at index LPA*TILES).
 template <int LPA, int TILES, int MATH>
 __device__ __forceinline__ void circ_and_scale_grp(lmask act_m, int sub, int grp, int type, V3 p, V3 v, double zv,
-                                                   V3 goal, V3 g, double dg, const PopConst &C, double k_circ,
+                                                   V3 goal, V3 g, double dg, V3 gn, const PopConst &C, double k_circ,
                                                    int n_obs, double *rot_g, unsigned &known_bits,
                                                    LaneObstacles<TILES> &O, double *clist, double &lane_min, V3 &F,
                                                    double &scale, const double *exp_tab) {
@@ -108,7 +108,7 @@ __device__ __forceinline__ void circ_and_scale_grp(lmask act_m, int sub, int grp
   // masks": a vote on a compound predicate costs two VALU instructions, and this kernel is VALU-issue bound).
   typedef Mth<MATH> MT;
   const int M = n_obs - 1;
-  const V3 gn = MT::div3(g, (dg > 0.0) ? dg : 1.0);  // goal_vec.normalized(): x / 1.0 == x
+  // gn = goal_vec.normalized(): the caller's (k_rollout_grp computes it with the tail's other norms)
   double best_d = C.shell;
   double best_s = 0.0, best_gr = 0.0;
   int best_i = 0x7fffffff;

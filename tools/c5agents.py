@@ -32,3 +32,7 @@ for ty in sorted(set(types.tolist())):
     sel = t[:, types == ty]
     print("  type %d n=%d mean %.0f max %.0f" % (ty, sel.size, sel.mean(), sel.max()))
 h.close()
+# which waves are the slowest (population, wave index): the special heuristic types sit in wave 0 of every population
+order = np.argsort(-w.reshape(-1))[:12]
+print("slowest waves (population, wave, us):", [(int(i // w.shape[1]), int(i % w.shape[1]), round(float(w.reshape(-1)[i]), 1)) for i in order])
+print("wave 0 of each population us:", [round(float(x), 1) for x in w[:, 0]])

@@ -182,6 +182,24 @@ __device__ __forceinline__ void circ_and_scale_grp(lmask act_m, int sub, int grp
     wave_lds_fence();
     // F = ((0 + c_0) + c_1) + ... per group; a group that has run out of terms adds +0.0 (exact no-op)
     // (lanes past their group's last term read the group's all-zero slot)
+#ifndef PMAF_GRP_SUM3
+#define PMAF_GRP_SUM3 1
+#endif
+    if (PMAF_GRP_SUM3 && LPA >= 16) {
+      // Round 3: the three component sums in three LANES of each DPP row (row lane 0 adds the x of every entry, 1 the y,
+      // 2 the z: ONE v_add_f64 per entry instead of three in this VALU-issue-bound kernel; the per-lane ds_read is not a
+      // VALU instruction), read back by row_newbcast moves. Same additions in the same order per component. (F enters
+      // as +0.0; the other lanes of the row add the entries' padding word.)
+      const double *ec = clist + (sub & 3);
+      double acc = 0.0;
+      for (int k = 0; PMAF_BAL(k < count) != 0ull; k += 4) {   // k + 3 <= LPA * TILES - 1: count <= LPA * TILES
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc = acc + ec[(size_t)(k + j) * 4];
+      }
+#define PMAF_RB(x, K) __builtin_amdgcn_update_dpp(x, x, 0x150 + K, 0xf, 0xf, true)
+      F = mk(PMAF_RB(acc, 0), PMAF_RB(acc, 1), PMAF_RB(acc, 2));
+#undef PMAF_RB
+    } else {
     for (int k = 0; PMAF_BAL(k < count) != 0ull; k += 4) {   // k + 3 <= LPA * TILES - 1: count <= LPA * TILES
       const double *e = clist + (size_t)k * 4;
 #pragma unroll
@@ -190,6 +208,7 @@ __device__ __forceinline__ void circ_and_scale_grp(lmask act_m, int sub, int grp
         F.y = F.y + e[j * 4 + 1];
         F.z = F.z + e[j * 4 + 2];
       }
+    }
     }
     wave_lds_fence();
   }

@@ -666,13 +666,32 @@ __device__ __forceinline__ void path_cost_terms_w64(int lane, const double *path
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   cost_ws = 0.0;
   path_len = 0.0;
-  for (int base = 0; base < n; base += 64) {
+#ifndef PMAF_COST_PREFETCH
+#define PMAF_COST_PREFETCH 1
+#endif
+  // (round 3: the next block's six loads are in flight while this block is summed -- the pass was one memory round trip
+  // per 64 points in front of each sum)
+  V3 q_n = mk(0.0, 0.0, 0.0), qp_n = mk(0.0, 0.0, 0.0);
+  auto fetch = [&](int base, V3 &q, V3 &qp) __attribute__((always_inline)) {
     const int k = base + lane;
     const bool valid = k < n;
     const bool has_seg = valid && (k > 0);
     const int kk = valid ? k : 0, kp = has_seg ? (k - 1) : 0;
-    const V3 q = mk(ld_agent(path + kk * 3), ld_agent(path + kk * 3 + 1), ld_agent(path + kk * 3 + 2));
-    const V3 qp = mk(ld_agent(path + kp * 3), ld_agent(path + kp * 3 + 1), ld_agent(path + kp * 3 + 2));
+    q = mk(ld_agent(path + kk * 3), ld_agent(path + kk * 3 + 1), ld_agent(path + kk * 3 + 2));
+    qp = mk(ld_agent(path + kp * 3), ld_agent(path + kp * 3 + 1), ld_agent(path + kp * 3 + 2));
+  };
+  if (PMAF_COST_PREFETCH) fetch(0, q_n, qp_n);
+  for (int base = 0; base < n; base += 64) {
+    const int k = base + lane;
+    const bool valid = k < n;
+    const bool has_seg = valid && (k > 0);
+    V3 q, qp;
+    if (PMAF_COST_PREFETCH) {
+      q = q_n; qp = qp_n;
+      if (base + 64 < n) fetch(base + 64, q_n, qp_n);
+    } else {
+      fetch(base, q, qp);
+    }
     const double seg = Mth<MATH>::norm(q - qp);
     list[lane] = has_seg ? seg : 0.0;
     wave_lds_fence();

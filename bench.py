@@ -432,8 +432,10 @@ def run_workload(ctx, spec, args, full):
         # set-point latency of a tick issued on an idle stream (the previous rollout has finished, as in a 100 Hz
         # control loop): host call -> best index and next set-point on the host. Outside the timed region.
         idle = np.zeros(0)
+        idle_lib = (np.zeros(0), np.zeros(0))
         if full and not (coupled and n_part > 1):
             idle = np.zeros(500)
+            planner.tick_times_us()          # (clears the library's own record of the timed ticks)
             for k in range(idle.size):
                 maybe_restart_episode()
                 planner.stop()
@@ -441,6 +443,9 @@ def run_workload(ctx, spec, args, full):
                 one_tick(obs)
                 idle[k] = time.perf_counter() - ta
             planner.stop()
+            # the same calls on the library's own clock (pmaf_get_tick_times_us): without this script's ctypes / numpy
+            # / interpreter time, which is where the tail of the figure above comes from
+            idle_lib = planner.tick_times_us(idle.size)
         mine_rec = dict(tick_us=float(np.median(lat) * 1e6), tick_p99=float(np.percentile(lat, 99) * 1e6),
                         ag_us=float(np.median(ag_us)) if ag_us.size else None,
                         ag_p99=float(np.percentile(ag_us, 99)) if ag_us.size else None, ag_n=int(ag_us.size),
@@ -507,6 +512,7 @@ def run_workload(ctx, spec, args, full):
     }
     if full:
         rec["_idle"] = idle
+        rec["_idle_lib"] = idle_lib
         rec["_scene"] = sc
         rec["_P"] = P
         rec["_transport"] = transport
@@ -601,6 +607,7 @@ def main():
     line = None
     if rank == 0:
         idle, sc, P = head.pop("_idle"), head.pop("_scene"), head.pop("_P")
+        idle_enq, idle_sp = head.pop("_idle_lib")
         transport, has_comm = head.pop("_transport"), head.pop("_has_comm")
         N, H, n_obs = head["agents"], head["horizon"], head["obstacles"] + 1
         kernel_name, avg_kernel_s = head["kernel"], head["avg_kernel_us"] * 1e-6
@@ -655,8 +662,14 @@ def main():
             "setpoint_latency_us": None if not idle.size else {
                 "median": float(np.median(idle) * 1e6), "p90": float(np.percentile(idle, 90) * 1e6),
                 "p99": float(np.percentile(idle, 99) * 1e6), "max": float(np.max(idle) * 1e6), "n": int(idle.size),
+                "in_library": None if not idle_sp.size else {
+                    "median": float(np.median(idle_sp)), "p90": float(np.percentile(idle_sp, 90)),
+                    "p99": float(np.percentile(idle_sp, 99)), "max": float(np.max(idle_sp)),
+                    "enqueue_median": float(np.median(idle_enq)), "enqueue_p99": float(np.percentile(idle_enq, 99)),
+                    "note": "the same calls on the library's own clock (pmaf_get_tick_times_us): entry of pmaf_tick -> "
+                            "set-point on the host; enqueue = both launches handed to the stream"},
                 "note": "tick issued on an idle stream: host call -> best index + next set-point "
-                        "on the host (the new rollout then runs asynchronously)"},
+                        "on the host (the new rollout then runs asynchronously); measured around the ctypes call"},
             "allgather_us": head["allgather_us"],
             "header_exchange_us": head["header_exchange_us"],
             "roofline": {"bound": "hbm", "achieved": head["hbm_achieved_gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -327,6 +327,12 @@ void *pmaf_winners_device(pmaf_planner *h);
  * the slowest rank; host communicator: wall time of the callback), oldest
  * first, at most max_n; *n = number written. Clears the record. */
 int pmaf_get_exchange_times_us(pmaf_planner *h, double *out, int32_t max_n, int32_t *n);
+/* host-side clock of the newest pmaf_tick calls (at most 8192 are kept), oldest first, in microseconds from the call's
+ * entry: enqueue_us = both launches (k_manager, rollout) handed to the stream, setpoint_us = best index + next
+ * set-point on the host (what the reference's planCallback publishes, B/src/panda_bimanual_control.cpp:329-369;
+ * the rollout keeps running behind it). Either array may be NULL; *n = number written; clears the record.
+ * Measured inside the library, so a caller in an interpreted language sees the path's latency, not its own. */
+int pmaf_get_tick_times_us(pmaf_planner *h, double *enqueue_us, double *setpoint_us, int32_t max_n, int32_t *n);
 
 /* ---- peer mailboxes: header-only exchange WITHOUT a collective (ABI 3) ----
  * Where a population needs only another population's set-point of the previous

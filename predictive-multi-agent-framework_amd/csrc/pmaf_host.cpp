@@ -68,6 +68,11 @@ struct pmaf_planner {
   hipStream_t stream = nullptr;
   hipEvent_t ev_mgr = nullptr;
   uint64_t mailbox_seq = 0;     // sequence number of the last pmaf_tick (mailbox entry 11)
+  // host-side clock of the last pmaf_tick calls (pmaf_get_tick_times_us): entry -> both launches enqueued, entry ->
+  // set-point on the host; a ring of the newest TICK_RING calls
+  static constexpr size_t TICK_RING = 8192;
+  std::vector<float> tick_enq_us, tick_sp_us;
+  size_t tick_head = 0, tick_count = 0;
   std::vector<void *> allocs;
   std::vector<size_t> alloc_bytes;  // size of every device buffer (state save / load)
   double *h_out = nullptr;      // pinned [P][PMAF_MBOX] mailbox written by k_manager
@@ -1027,6 +1032,7 @@ int pmaf_tick(pmaf_planner *h, const double *obstacles, double dt, const double 
               int32_t *best_idx, double *next_pos, double *next_vel) {
   return guarded([&] {
     REQUIRE(h && cost_gains && ws, "pmaf_tick: NULL argument");
+    const auto t_entry = std::chrono::steady_clock::now();
     h->use_device();
     set_cost_params(h, cost_gains, ws);
     ensure_scores(h);
@@ -1051,10 +1057,19 @@ int pmaf_tick(pmaf_planner *h, const double *obstacles, double dt, const double 
     h->rollout_pending = true;
     h->stepped = false;
     launch_rollout(h);
+    const auto t_enq = std::chrono::steady_clock::now();
     // outputs of k_manager land in mapped pinned memory; wait for them only
     // (no event between the two launches: the host polls the sequence number -- spinning, or with
     // PMAF_FLAG_BLOCKING_WAIT sleeping between polls)
     wait_mailbox(h, A.seq);
+    {
+      const auto t_sp = std::chrono::steady_clock::now();
+      if (h->tick_enq_us.empty()) { h->tick_enq_us.resize(pmaf_planner::TICK_RING); h->tick_sp_us.resize(pmaf_planner::TICK_RING); }
+      h->tick_enq_us[h->tick_head] = std::chrono::duration<float, std::micro>(t_enq - t_entry).count();
+      h->tick_sp_us[h->tick_head] = std::chrono::duration<float, std::micro>(t_sp - t_entry).count();
+      h->tick_head = (h->tick_head + 1) % pmaf_planner::TICK_RING;
+      if (h->tick_count < pmaf_planner::TICK_RING) h->tick_count++;
+    }
     const bool peer_late = h->peer.on && peer_book_tick(h);
     if (h->x.c) begin_exchange(h, scored);  // pack + all-gather on the exchange stream, beside the rollout
     refresh_real_cache(h);
@@ -1523,6 +1538,23 @@ int pmaf_get_exchange_times_us(pmaf_planner *h, double *out, int32_t max_n, int3
     for (size_t i = 0; i < k; i++) out[i] = v[i];
     *n = (int32_t)k;
     v.clear();
+  });
+}
+
+int pmaf_get_tick_times_us(pmaf_planner *h, double *enqueue_us, double *setpoint_us, int32_t max_n, int32_t *n) {
+  return guarded([&] {
+    REQUIRE(h && n, "pmaf_get_tick_times_us: NULL argument");
+    const size_t have = h->tick_count;
+    const size_t k = (max_n > 0) ? std::min(have, (size_t)max_n) : 0;
+    // oldest first among the newest k
+    for (size_t i = 0; i < k; i++) {
+      const size_t at = (h->tick_head + pmaf_planner::TICK_RING - k + i) % pmaf_planner::TICK_RING;
+      if (enqueue_us) enqueue_us[i] = h->tick_enq_us[at];
+      if (setpoint_us) setpoint_us[i] = h->tick_sp_us[at];
+    }
+    *n = (int32_t)k;
+    h->tick_count = 0;
+    h->tick_head = 0;
   });
 }
 

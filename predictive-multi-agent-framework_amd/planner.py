@@ -91,6 +91,7 @@ SYMBOLS = {
     "pmaf_winners_wait": (C.c_int, [_V, C.POINTER(_dp), C.POINTER(C.c_size_t)]),
     "pmaf_winners_device": (_V, [_V]),
     "pmaf_get_exchange_times_us": (C.c_int, [_V, _dp, C.c_int32, _ip]),
+    "pmaf_get_tick_times_us": (C.c_int, [_V, _dp, _dp, C.c_int32, _ip]),
     "pmaf_peer_export": (C.c_int, [_V, C.c_int32, _V]),
     "pmaf_peer_connect": (C.c_int, [_V, C.c_int32, C.c_int32, _V]),
     "pmaf_peer_couple": (C.c_int, [_V, C.c_int32, C.c_int32, C.c_int32, C.c_double, _dp]),
@@ -430,6 +431,13 @@ class PmafPlanner:
         n = C.c_int32(0)
         self._chk(self.L.pmaf_get_exchange_times_us(self._h, _p(out), max_n, C.byref(n)))
         return out[:n.value].copy()
+
+    def tick_times_us(self, max_n=8192):
+        """(enqueue_us, setpoint_us) of the newest pmaf_tick calls, measured inside the library; clears the record"""
+        enq, sp = np.zeros(max_n), np.zeros(max_n)
+        n = C.c_int32(0)
+        self._chk(self.L.pmaf_get_tick_times_us(self._h, _p(enq), _p(sp), max_n, C.byref(n)))
+        return enq[:n.value].copy(), sp[:n.value].copy()
 
     # -- peer mailboxes (header-only exchange without a collective) --
     PEER_HANDLE_BYTES = 128

@@ -935,10 +935,14 @@ def test_idle_lane_riders_at_the_obstacle_count_boundary(pmaf, oracle, scenes, m
 
 
 def test_idle_lane_goal_with_signed_zero_coordinates(pmaf, oracle, scenes):
-    """lane 63 of the one-slot kernel carries the goal like an obstacle at rest:
-    a -0.0 goal coordinate turns into +0.0 there after the first step, which may
-    only change the sign of a zero component of the goal direction. Start and
-    goal on the x axis (y = -0.0 / +0.0, z equal): zeros in g.y all the way."""
+    """lane 63 of the one-slot kernel carries the goal like an obstacle at rest,
+    with velocity -0.0 so that the update `p + v dt` leaves a -0.0 coordinate as
+    it is (with +0.0 it would turn into +0.0 after the first step). The goal
+    direction read back from that lane also feeds the first-contact latch
+    (calc_rot_vec_pre: the Random heuristic's rotation vector is
+    cross(goal direction, random vector)), so the rotation vectors are compared
+    BIT for bit here, signs of zeros included. Start and goal on the x axis
+    (y = -0.0 / +0.0, z equal): zeros in g.y all the way."""
     for goal_y, start_y in ((-0.0, 0.0), (0.0, -0.0), (-0.0, -0.0)):
         sc = scenes.synthetic_scene(12, 120, 9, 6, 31)
         sc["goal"] = np.array([0.6, goal_y, 0.7])
@@ -947,7 +951,10 @@ def test_idle_lane_goal_with_signed_zero_coordinates(pmaf, oracle, scenes):
         sc["obstacles"][:3, 2] = 0.7
         sc["obstacles"][3:9, 0] += 10.0                # the others far away
         for dyn in (False, True):
-            hip, _ = run_both(pmaf, oracle, scenes, sc, 3, dynamic=dyn, lanes_per_agent=64)
+            hip, ora = run_both(pmaf, oracle, scenes, sc, 3, dynamic=dyn, lanes_per_agent=64)
+            rh, ro = np.ascontiguousarray(hip.rot_vecs()), np.ascontiguousarray(ora.rot_vecs())
+            assert hip.known().sum() > 0          # some obstacle was latched
+            np.testing.assert_array_equal(rh.view(np.uint64), ro.view(np.uint64))
             hip.close()
 
 
@@ -1213,6 +1220,28 @@ def test_blocking_wait_flag_gives_the_same_results(pmaf, oracle, scenes):
     assert cpu < 0.7 * wall   # the spinning default burns a full core: cpu ~ wall
     print("blocking wait: %d ticks in %.1f ms wall, %.1f ms CPU" % (150, wall * 1e3, cpu * 1e3))
     hip.close()
+
+
+def test_tick_times_on_the_library_clock(pmaf, scenes):
+    """pmaf_get_tick_times_us: one (enqueue, set-point) pair per pmaf_tick, oldest first, enqueue <= set-point, a
+    set-point within a millisecond of the call on an idle stream, and the record is cleared by the read"""
+    sc = scenes.config_scene("C2", scene_id=2)
+    h = pmaf.PmafPlanner(sc, device=0, mgr_init_pos=sc["start"])
+    h.set_initial_position(sc["start"])
+    for k in range(7):
+        h.tick(sc["obstacles"], sc["dt"], sc["cost_gains"], sc["ws_limits"])
+        h.stop()
+    enq, sp = h.tick_times_us()
+    assert enq.shape == (7,) and sp.shape == (7,)
+    assert np.all(enq > 0) and np.all(enq <= sp) and np.all(sp[1:] < 1000.0)
+    e2, s2 = h.tick_times_us()
+    assert e2.size == 0 and s2.size == 0
+    h.tick(sc["obstacles"], sc["dt"], sc["cost_gains"], sc["ws_limits"])
+    h.stop()
+    assert h.tick_times_us(max_n=4)[1].shape == (1,)
+    print("set-point on the host %.1f us after the call (median of 6), both launches enqueued after %.1f us"
+          % (float(np.median(sp[1:])), float(np.median(enq[1:]))))
+    h.close()
 
 
 @pytest.mark.parametrize("config,ticks", [("C1", 10), ("C2", 8), ("C3", 2)])

@@ -46,8 +46,13 @@ out.append("| config | rollouts/s | ms/tick | rollout kernel µs per launch (HIP
 for name, v, ms, k in rows:
     out.append("| %s | %s | %.4f | %s |" % (name, format(int(round(v)), ",").replace(",", " "), ms, k))
 out.append("")
-out.append("Set-point latency on an idle stream (host call → best index + set-point on the host): median %.1f µs, p90 %.1f, p99 %.1f "
-           "(%d samples); back-to-back tick median %.1f µs." % (sp["median"], sp.get("p90", float("nan")), sp["p99"], sp.get("n", 100), d["tick_latency_us"]["median"]))
+lib = sp.get("in_library")
+out.append("Set-point latency on an idle stream (host call → best index + set-point on the host), %d samples: " % sp.get("n", 100)
+           + ("**on the library's own clock (`pmaf_get_tick_times_us`: entry of `pmaf_tick` → set-point on the host) median %.1f µs, "
+              "p90 %.1f, p99 %.1f, max %.1f** (of which %.1f µs are the two launches being handed to the stream); " % (
+                  lib["median"], lib["p90"], lib["p99"], lib["max"], lib["enqueue_median"]) if lib else "")
+           + "around the bench's ctypes call median %.1f µs, p90 %.1f, p99 %.1f (the tail is the interpreter's, not the path's); "
+             "back-to-back tick median %.1f µs." % (sp["median"], sp.get("p90", float("nan")), sp["p99"], d["tick_latency_us"]["median"]))
 out.append("")
 out.append("**Roofline of the dominant kernel (C2 launch).** Algorithmic bytes (SURVEY §8d) %d B ÷ %.1f µs = %.3f GB/s = **%.3g of 8 TB/s** "
            "(`roofline.frac`; rocprofv3 average of the same kernel: %.1f µs). FP64-VALU: %d measured FP64 operations per agent-step "
@@ -86,6 +91,6 @@ fast = max(cb["spread_O2"][1], cb["spread_O3_native"][1])
 r = re.sub(r"(<!-- ratio:begin -->).*?(<!-- ratio:end -->)", lambda m: m.group(1) + "%.1f × the MEDIAN repetition of the multi-threaded CPU port of the same algorithm on the box's %s (%d threads; the repetitions are bimodal on this host, %.0f k … %.0f k rollouts/s — the fast ones are within %.1f × of the GPU), %.0f × one core" % (d["value"] / cb["value"], cb["cpu_model"], cb["cores"], min(cb["spread_O2"][0], cb["spread_O3_native"][0]) / 1e3, fast / 1e3, d["value"] / fast, d["value"] / cb["value_1core"]) + m.group(2), r, flags=re.S)
 r = re.sub(r"(<!-- frac:begin -->).*?(<!-- frac:end -->)", lambda m: m.group(1) + "%.2g of 8 TB/s" % rf["frac"] + m.group(2), r, flags=re.S)
 r = re.sub(r"(<!-- target:begin -->).*?(<!-- target:end -->)", lambda m: m.group(1) + "%.1f ×" % (d["value"] / 1e5) + m.group(2), r, flags=re.S)
-r = re.sub(r"(<!-- lat:begin -->).*?(<!-- lat:end -->)", lambda m: m.group(1) + "%.0f µs median, %.0f µs p99" % (sp["median"], sp["p99"]) + m.group(2), r, flags=re.S)
+r = re.sub(r"(<!-- lat:begin -->).*?(<!-- lat:end -->)", lambda m: m.group(1) + (("%.1f µs median, %.1f µs p99 on the library's own clock (`pmaf_get_tick_times_us`); " % (lib["median"], lib["p99"])) if lib else "") + "%.0f µs median, %.0f µs p99 around the Python bench's ctypes call" % (sp["median"], sp["p99"]) + m.group(2), r, flags=re.S)
 open(rp, "w").write(r)
 print(block)

@@ -68,6 +68,17 @@ struct pmaf_planner {
   hipStream_t stream = nullptr;
   hipEvent_t ev_mgr = nullptr;
   uint64_t mailbox_seq = 0;     // sequence number of the last pmaf_tick (mailbox entry 11)
+  // DevView::closest_idx: k_manager recomputes the table at the next reset when the caller has handed over a live
+  // obstacle list that DIFFERS (bit for bit) from the previous one -- a node that passes the same static list every tick
+  // pays for the table once
+  bool closest_dirty = true;
+  std::vector<double> last_live;   // the caller's last list, as given ([P][n_obs][7])
+  void note_live_obstacles(const double *obstacles) {
+    const size_t n = (size_t)D.P * D.n_obs * 7;
+    if (last_live.size() == n && std::memcmp(last_live.data(), obstacles, sizeof(double) * n) == 0) return;
+    last_live.assign(obstacles, obstacles + n);
+    closest_dirty = true;
+  }
   // host-side clock of the last pmaf_tick calls (pmaf_get_tick_times_us): entry -> both launches enqueued, entry ->
   // set-point on the host; a ring of the newest TICK_RING calls
   static constexpr size_t TICK_RING = 8192;
@@ -365,6 +376,7 @@ static void ensure_scores(pmaf_planner *h) {
 static void upload_live_obstacles(pmaf_planner *h, const double *obstacles) {
   if (!obstacles) return;
   check_range(obstacles, (size_t)h->D.P * h->D.n_obs * 7, "obstacles");
+  h->note_live_obstacles(obstacles);
   // ring of pinned staging buffers: wait only for the copy that last used this slot
   int s = h->stage_next;
   h->stage_next = (s + 1) % pmaf_planner::kStage;
@@ -380,6 +392,7 @@ static void upload_live_obstacles(pmaf_planner *h, const double *obstacles) {
 static const double *stage_live_obstacles_zero_copy(pmaf_planner *h, const double *obstacles) {
   if (!obstacles) return nullptr;
   check_range(obstacles, (size_t)h->D.P * h->D.n_obs * 7, "obstacles");
+  h->note_live_obstacles(obstacles);
   aos_to_soa(obstacles, h->h_zc, h->D.P, h->D.n_obs);
   return h->d_zc;
 }
@@ -387,6 +400,7 @@ static const double *stage_live_obstacles_zero_copy(pmaf_planner *h, const doubl
 static void launch_manager(pmaf_planner *h, const ManagerArgs &A0, hipEvent_t done = nullptr) {
   ManagerArgs A = A0;
   if (A.do_reset) h->paths_gen++;
+  if (A.do_reset) { A.compute_closest = h->closest_dirty ? 1 : 0; h->closest_dirty = false; }
   A.tuned_real_step = (h->math == MATH_XACT && !h->force_generic) ? 1 : 0;
   pmaf_k_launch_manager(h->D, h->cp, A, h->lds_manager, h->stream, done);
   HIP_CHECK(hipGetLastError());
@@ -734,6 +748,8 @@ int pmaf_create(const pmaf_params *prm, pmaf_planner **out) {
     D.obs_start = h->dalloc<double>((size_t)P * 7 * n_obs);
     D.known_start = h->dalloc<int32_t>((size_t)P * n_obs);
     D.obs_live = h->dalloc<double>((size_t)P * 7 * n_obs);
+    D.closest_idx = h->dalloc<int32_t>((size_t)P * n_obs);   // (zero-filled; closest_ok = 0: no table yet)
+    D.closest_ok = h->dalloc<int32_t>((size_t)P);
     double *ka = h->dalloc<double>(PN), *kc = h->dalloc<double>(PN), *kr = h->dalloc<double>(PN), *kd = h->dalloc<double>(PN);
     D.k_attr = ka; D.k_circ = kc; D.k_repel = kr; D.k_damp = kd;
     int32_t *types = h->dalloc<int32_t>(N);
@@ -1855,6 +1871,8 @@ int pmaf_load_state(pmaf_planner *h, const void *blob, size_t bytes) {
     h->scores_valid = hd.scores_valid != 0;
     h->rollout_pending = hd.rollout_pending != 0;
     h->stepped = hd.stepped != 0;
+    h->closest_dirty = true;   // (the blob's table matches its obs_start; recompute at the next reset all the same)
+    h->last_live.clear();
   });
 }
 

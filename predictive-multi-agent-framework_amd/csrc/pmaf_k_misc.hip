@@ -512,6 +512,23 @@ __global__ __launch_bounds__(64) void k_manager(DevView D, CostParams CP, Manage
       D.start_pos[pop * 3] = sp.x; D.start_pos[pop * 3 + 1] = sp.y; D.start_pos[pop * 3 + 2] = sp.z;
       D.start_vel[pop * 3] = sv.x; D.start_vel[pop * 3 + 1] = sv.y; D.start_vel[pop * 3 + 2] = sv.z;
     }
+    // Closest-other table of the obstacle list just copied into obs_start (DevView::closest_idx): only when the caller
+    // handed over new obstacles since the last one, behind everything the host and the next rollout wait for, and only
+    // for field obstacles at rest -- then every rollout's Obstacle / GoalObstacle latches read the answer of the
+    // reference's scan (closest_other, B/src/cf_agent.cpp:434-446) instead of searching (M distances per latch).
+    if (A.compute_closest) {
+      bool mv = false;
+      for (int i = lane; i < M; i += 64) {
+        const V3 ov = T.vel(i);
+        mv = mv || !(ov.x == 0.0 && ov.y == 0.0 && ov.z == 0.0);   // (a NaN component counts as moving)
+      }
+      mv = wave_any(mv);
+      if (!mv) {
+        int32_t *ci = D.closest_idx + (size_t)pop * n_obs;
+        for (int i = lane; i < M; i += 64) ci[i] = closest_other(T, n_obs, i, T.pos(i));
+      }
+      if (lane == 0) D.closest_ok[pop] = mv ? 0 : 1;
+    }
   }
 #ifdef PMAF_TICK_STAMPS
   if (lane == 0 && pop == 0) printf("M %llu %llu\n", t_mgr0, wall_clock64());

@@ -58,6 +58,13 @@ __device__ __forceinline__ void rollout_w64_body(const DevView &D, const CostPar
 
   LaneObstacles<TILES> O;
   unsigned known_bits = 0u;
+#ifndef PMAF_CLOSEST_TABLE
+#define PMAF_CLOSEST_TABLE 1
+#endif
+  // closest-other table (below): the multi-slot kernels' Obstacle / GoalObstacle bodies only -- with one slot per lane
+  // the search is one sqrt chain + two reductions, the GoalObstacle agent does not bound the C2 launch without it, and
+  // the short C1 rollout would pay for the table's loads in its prologue (measured: profiles/r3_ab_session3.txt)
+  constexpr bool USES_CLOSEST = PMAF_CLOSEST_TABLE && TILES >= 2 && (TYPE == T_OBST || TYPE == T_GOALOBST);
 #pragma unroll
   for (int t = 0; t < TILES; t++) {
     int i = t * 64 + lane;
@@ -134,6 +141,23 @@ __device__ __forceinline__ void rollout_w64_body(const DevView &D, const CostPar
   for (int t = 0; t < TILES; t++) moving = moving || !(O.v[t].x == 0.0 && O.v[t].y == 0.0 && O.v[t].z == 0.0);
   moving = wave_any(moving);
   bool advance = true;
+  // Closest-other table (Obstacle / GoalObstacle heuristics only; DevView::closest_idx): valid when k_manager computed
+  // it for this rollout's start obstacles and they are at rest. The wave keeps its copy in the obstacle-table area of
+  // the LDS layout, which this kernel does not use otherwise (its obstacles live in registers).
+  const int32_t *cidx = nullptr;
+  if (USES_CLOSEST) {
+    if (!moving && D.closest_ok[pop] == 1) {   // wave-uniform
+      int32_t *s_cidx = reinterpret_cast<int32_t *>(smem);
+      const int32_t *ci = D.closest_idx + (size_t)pop * n_obs;
+#pragma unroll
+      for (int t = 0; t < TILES; t++) {
+        const int i = t * 64 + lane;
+        if (i < M) s_cidx[i] = ci[i];
+      }
+      wave_lds_fence();
+      cidx = s_cidx;
+    }
+  }
   V3 repel = mk(0.0, 0.0, 0.0);  // repelForce of the coming step (depends on the step's start state only)
   if (sent_reachable) repel = sentinel_repel(p, C, k_repel, sent_p, sent_r, zsent_lt);
   SecTimers ST;
@@ -157,7 +181,7 @@ __device__ __forceinline__ void rollout_w64_body(const DevView &D, const CostPar
 #endif
       circ_and_scale_w64<TILES, TYPE, MATH, PRE, DPPSUM, decltype(EK)>(lane, p, v, zv, goal, g, dg, gn, C, k_circ, n_obs, rot_g, known_bits,
                                                  O, clist, lane_min, F, scale, ST, EK, D.ablate, 0, s_pre, ron_pre,
-                                                 gate_m);
+                                                 gate_m, cidx);
     PMAF_SEC(ST, 5);
     // attractorForce (:183-193), updatePositionAndVelocity (:253-268)
     // repelForce (:159-181): `repel` was evaluated for this step's start state at the end of the previous step; it is

@@ -256,6 +256,22 @@ __device__ __forceinline__ V3 closest_other_w64(lmask need_latch_m, int t, int l
   return cpos;
 }
 
+// closest_other_w64's answer from the closest-other table (DevView::closest_idx, computed by k_manager for rollout-start
+// obstacles at rest; `cidx` = the wave's LDS copy): the lane's slot-`t` obstacle looks up the index the reference's scan
+// returns and fetches that obstacle's position from the lane that holds it (ds_bpermute; every lane must be active).
+// The positions come from the live registers, so the bits are the ones the scan would have read.
+template <int TILES>
+__device__ __forceinline__ V3 closest_from_table_w64(const int32_t *cidx, int t, int lane, const LaneObstacles<TILES> &O) {
+  const int c = cidx[t * 64 + lane];
+  V3 cp = mk(0.0, 0.0, 0.0);
+#pragma unroll
+  for (int u = 0; u < TILES; u++) {
+    const V3 q = mk(__shfl(O.p[u].x, c & 63), __shfl(O.p[u].y, c & 63), __shfl(O.p[u].z, c & 63));
+    if ((c >> 6) == u) cp = q;
+  }
+  return cp;
+}
+
 // circForce (B/src/cf_agent.cpp:72-108) + attractorForceScaling (:195-227)
 // for one agent per wave. clist: LDS, (64*TILES + 8 + 64) entries of 4 doubles
 // (the list, 8 entries of zero padding, one scratch entry per lane).
@@ -285,7 +301,7 @@ __device__ __forceinline__ void circ_and_scale_w64(int lane, V3 p, V3 v, double 
                                                    V3 &F, double &scale, SecTimers &ST, const KT &EK,
                                                    const int ablate = 0, const int rtype = 0,
                                                    const double s_pre = 0.0, const V3 ron_pre = V3{0.0, 0.0, 0.0},
-                                                   const lmask gate_m = ~0ull) {
+                                                   const lmask gate_m = ~0ull, const int32_t *cidx = nullptr) {
   typedef Mth<MATH> MT;
   // TYPE == T_REAL: the heuristic is a run-time value (the real agent's step in
   // k_manager dispatches to the stored best agent's type, cf_agent.cpp:368-387)
@@ -370,7 +386,11 @@ __device__ __forceinline__ void circ_and_scale_w64(int lane, V3 p, V3 v, double 
     const lmask need_latch_m = in_m[t] & PMAF_BAL((known_bits & (1u << t)) == 0u);
     if (PMAF_RARE(need_latch_m != 0ull)) {
       V3 cpos = O.p[t];
-      if (type == T_OBST || type == T_GOALOBST) cpos = closest_other_w64<TILES, MATH>(need_latch_m, t, lane, M, O);
+      if (type == T_OBST || type == T_GOALOBST) {
+        // (cidx: the closest-other table holds for this rollout -- wave-uniform)
+        if (cidx) cpos = closest_from_table_w64<TILES>(cidx, t, lane, O);
+        else cpos = closest_other_w64<TILES, MATH>(need_latch_m, t, lane, M, O);
+      }
       if (PMAF_LANE(need_latch_m)) {
         // (to_obs, the goal vector, its norm and direction are the sweep's / the caller's: calc_rot_vec_pre)
         V3 rot = calc_rot_vec_pre<MATH>(type, p, n_obs, O.p[t], cpos, mk(O.qx[t], O.qy[t], O.qz[t]), ron_t[t], g, dg, gn);

@@ -77,6 +77,14 @@ struct DevView {
   const double *zsent_lt;            // [P] exact squared-distance boundary of the repel range test
   int ablate;                        // timing experiments only (PMAF_ABLATE), 0 in production
   int n_simds;                       // SIMDs of the device (4 per CU): a launch of more waves doubles them up
+  // closest-other table of the rollout-start obstacles (round 3): closest_idx[p][i] = the index the Obstacle /
+  // GoalObstacle heuristics' scan for the field obstacle nearest to obstacle i returns (B/src/cf_agent.cpp:434-446 /
+  // :480-492), valid while closest_ok[p] != 0: k_manager computes it when it writes obs_start from a NEW live list whose
+  // field obstacles are all at rest (then their positions -- and the table -- hold for the whole rollout and for every
+  // later rollout until the caller hands over new obstacles); the wave-per-agent kernels' first-contact latch reads
+  // it instead of searching.
+  int32_t *closest_idx;              // [P][n_obs]
+  int32_t *closest_ok;               // [P]
 };
 
 struct CostParams {
@@ -118,6 +126,8 @@ struct ManagerArgs {
   double peer_tick;        // t: sequence number this launch publishes (it consumes t - 1)
   double *winner_hdr;      // [P][winner_stride] winner-record headers (send buffer of the sharded runs' all-gather),
   int winner_stride;       // written after a selection: {cost, idx, n_points, type, next_pos[3], goal_dist}; NULL: none
+  int compute_closest;     // with do_reset: the live obstacles changed since the closest-other table was last computed
+                           // (set by launch_manager from the handle's dirty flag)
 };
 
 // synchronous stepping (CfAgent::cfPlanner, B/src/cf_agent.cpp:278-300): k_plan_steps

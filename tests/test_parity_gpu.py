@@ -1222,6 +1222,62 @@ def test_blocking_wait_flag_gives_the_same_results(pmaf, oracle, scenes):
     hip.close()
 
 
+@pytest.mark.parametrize("m_field", [70, 128, 200])
+def test_closest_other_table_life_cycle(pmaf, oracle, scenes, m_field):
+    """DevView::closest_idx (multi-slot wave-per-agent kernels): k_manager computes the Obstacle / GoalObstacle
+    heuristics' closest-other answers once per NEW obstacle list at rest, and the rollouts' first-contact latches read
+    them instead of scanning (B/src/cf_agent.cpp:434-446 / :480-492). Every agent an Obstacle or GoalObstacle one; the
+    list stays, moves to other rest positions, starts moving (no table: the scan), comes to rest again, and a handle
+    restored from a checkpoint carries on -- all bit-exact against the oracle, rotation vectors included."""
+    N, H = 10, 90
+    types = np.array([2, 3] * (N // 2), dtype=np.int32)
+    sc = scenes.synthetic_scene(N, H, m_field, 6, 123 + m_field, agent_types=types)
+    # a ring of obstacles around the start-goal line, two of them at EQUAL distance from a third (index ties)
+    k = min(m_field, 40)
+    ang = np.linspace(0.0, 2 * np.pi, k, endpoint=False)
+    sc["obstacles"][:k, 0] = np.linspace(-0.45, 0.45, k)
+    sc["obstacles"][:k, 1] = 0.12 * np.cos(ang * 3)
+    sc["obstacles"][:k, 2] = 0.7 + 0.12 * np.sin(ang * 3)
+    sc["obstacles"][1, :3] = sc["obstacles"][0, :3] + [0.0, 0.05, 0.0]
+    sc["obstacles"][2, :3] = sc["obstacles"][0, :3] - [0.0, 0.05, 0.0]
+    hip, ora = make_pair(pmaf, oracle, sc, lanes_per_agent=64)
+    args = (sc["dt"], sc["cost_gains"], sc["ws_limits"])
+    rng = np.random.default_rng(m_field)
+
+    cur = [None]
+
+    def both(obs, n):
+        if obs is not None:
+            cur[0] = obs
+        for _ in range(n):
+            assert hip.tick(obs, *args) == ora.tick(cur[0], *args)   # (None: the planner keeps its live list)
+        hip.stop()
+        assert_state_equal(hip, ora)
+        assert hip.known().sum() > 0
+        np.testing.assert_array_equal(np.ascontiguousarray(hip.rot_vecs()).view(np.uint64),
+                                      np.ascontiguousarray(ora.rot_vecs()).view(np.uint64))
+
+    obs = sc["obstacles"].copy()
+    both(obs, 3)                    # table computed at the first reset, reused by the next rollouts (same list)
+    both(None, 2)                   # no list handed over: the live one (and the table) stay
+    obs2 = obs.copy()
+    obs2[:m_field, :3] += rng.uniform(-0.03, 0.03, (m_field, 3))
+    both(obs2, 2)                   # other rest positions: recomputed
+    obs3 = obs2.copy()
+    obs3[5, 3:6] = [0.0, 0.02, 0.0]   # one obstacle moves: no table, the latches scan
+    both(obs3, 2)
+    both(obs2, 2)                   # at rest again
+    blob = hip.save_state()
+    hip2 = pmaf.PmafPlanner(sc, device=0, mgr_init_pos=sc["start"], lanes_per_agent=64)
+    hip2.set_initial_position(sc["start"])
+    hip2.load_state(blob)
+    hip.close()
+    hip = hip2
+    both(None, 2)                   # restored handle: table from the blob, recomputed at its first reset
+    both(obs, 2)
+    hip.close()
+
+
 def test_tick_times_on_the_library_clock(pmaf, scenes):
     """pmaf_get_tick_times_us: one (enqueue, set-point) pair per pmaf_tick, oldest first, enqueue <= set-point, a
     set-point within a millisecond of the call on an idle stream, and the record is cleared by the read"""

@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define PMAF_ABI_VERSION 3
+#define PMAF_ABI_VERSION 4   /* 4: pmaf_get_tick_times_us; the state blob carries the closest-other table */
 
 typedef enum pmaf_status {
   PMAF_OK = 0,

@@ -73,11 +73,23 @@ struct pmaf_planner {
   // pays for the table once
   bool closest_dirty = true;
   std::vector<double> last_live;   // the caller's last list, as given ([P][n_obs][7])
+  // (only the FIELD obstacles count -- the first n_obs - 1 rows of every population: the trailing repulsive obstacle,
+  // which a host-coupled dual-arm run rewrites every tick, is not in the table)
   void note_live_obstacles(const double *obstacles) {
-    const size_t n = (size_t)D.P * D.n_obs * 7;
-    if (last_live.size() == n && std::memcmp(last_live.data(), obstacles, sizeof(double) * n) == 0) return;
-    last_live.assign(obstacles, obstacles + n);
+    const size_t row = (size_t)D.n_obs * 7, field = (size_t)(D.n_obs - 1) * 7;
+    bool same = last_live.size() == (size_t)D.P * field;
+    for (int p = 0; p < D.P && same; p++)
+      same = std::memcmp(last_live.data() + p * field, obstacles + p * row, sizeof(double) * field) == 0;
+    if (same) return;
+    last_live.resize((size_t)D.P * field);
+    for (int p = 0; p < D.P; p++) std::memcpy(last_live.data() + p * field, obstacles + p * row, sizeof(double) * field);
     closest_dirty = true;
+  }
+  // the kernels that read the table: the wave-per-agent kernels with several obstacle slots per lane (launch_rollout)
+  bool uses_closest_table() const {
+    const int M = D.n_obs - 1;
+    const int tiles64 = (M >= 62 && M <= 64) ? 2 : (M + 63) / 64;
+    return lpa == 64 && tiles64 >= 2 && tiles64 <= 4 && !force_generic && !ext_fn;
   }
   // host-side clock of the last pmaf_tick calls (pmaf_get_tick_times_us): entry -> both launches enqueued, entry ->
   // set-point on the host; a ring of the newest TICK_RING calls
@@ -400,7 +412,7 @@ static const double *stage_live_obstacles_zero_copy(pmaf_planner *h, const doubl
 static void launch_manager(pmaf_planner *h, const ManagerArgs &A0, hipEvent_t done = nullptr) {
   ManagerArgs A = A0;
   if (A.do_reset) h->paths_gen++;
-  if (A.do_reset) { A.compute_closest = h->closest_dirty ? 1 : 0; h->closest_dirty = false; }
+  if (A.do_reset && h->uses_closest_table()) { A.compute_closest = h->closest_dirty ? 1 : 0; h->closest_dirty = false; }
   A.tuned_real_step = (h->math == MATH_XACT && !h->force_generic) ? 1 : 0;
   pmaf_k_launch_manager(h->D, h->cp, A, h->lds_manager, h->stream, done);
   HIP_CHECK(hipGetLastError());

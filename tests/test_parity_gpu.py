@@ -1267,6 +1267,9 @@ def test_closest_other_table_life_cycle(pmaf, oracle, scenes, m_field):
     obs3[5, 3:6] = [0.0, 0.02, 0.0]   # one obstacle moves: no table, the latches scan
     both(obs3, 2)
     both(obs2, 2)                   # at rest again
+    obs4 = obs2.copy()
+    obs4[-1, :3] = [0.1, 0.3, 0.7]   # only the trailing (repulsive) obstacle differs: not a field obstacle, the table stays
+    both(obs4, 2)
     blob = hip.save_state()
     hip2 = pmaf.PmafPlanner(sc, device=0, mgr_init_pos=sc["start"], lanes_per_agent=64)
     hip2.set_initial_position(sc["start"])

@@ -22,8 +22,14 @@ using namespace pmaf;
 // * every population's first two waves hold its five heuristic agents (mixed types: the wave runs the union of their
 //   code paths, 1.13x the work of a wave of Random agents), and b + n_simds is the same wave index of another
 //   population: the wave index is rotated by 8 per population so that two such waves do not share a SIMD (-3 %).
-constexpr int PRIO_SLICE_LOG2 = 10;       // 2^10 ticks of the 100 MHz wall clock
-constexpr unsigned PRIO_YOUNGER_OF_8 = 5;
+#ifndef PMAF_PRIO_SLICE_LOG2
+#define PMAF_PRIO_SLICE_LOG2 10
+#endif
+#ifndef PMAF_PRIO_YOUNGER_OF_8
+#define PMAF_PRIO_YOUNGER_OF_8 5
+#endif
+constexpr int PRIO_SLICE_LOG2 = PMAF_PRIO_SLICE_LOG2;       // 2^10 ticks of the 100 MHz wall clock
+constexpr unsigned PRIO_YOUNGER_OF_8 = PMAF_PRIO_YOUNGER_OF_8;
 constexpr unsigned POP_ROTATE = 8;
 template <int LPA, int TILES, int MATH>
 __global__ __launch_bounds__(64) void k_rollout_grp(DevView D, CostParams CP) {

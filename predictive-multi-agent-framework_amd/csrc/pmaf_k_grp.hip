@@ -22,15 +22,20 @@ using namespace pmaf;
 // * every population's first two waves hold its five heuristic agents (mixed types: the wave runs the union of their
 //   code paths, 1.13x the work of a wave of Random agents), and b + n_simds is the same wave index of another
 //   population: the wave index is rotated by 8 per population so that two such waves do not share a SIMD (-3 %).
+//   Re-swept in round 3 on the shorter step (profiles/r3_ab_session3.txt item 11): 6 slices of 8 for the younger wave, slices of
+//   2^9 ticks (5 us): 736 us against 761 us with the round-2 setting (5 of 8, 2^10), 746 (6, 2^10), 752 (6, 2^8), 776 (7, 2^10).
 #ifndef PMAF_PRIO_SLICE_LOG2
-#define PMAF_PRIO_SLICE_LOG2 10
+#define PMAF_PRIO_SLICE_LOG2 9
 #endif
 #ifndef PMAF_PRIO_YOUNGER_OF_8
-#define PMAF_PRIO_YOUNGER_OF_8 5
+#define PMAF_PRIO_YOUNGER_OF_8 6
 #endif
-constexpr int PRIO_SLICE_LOG2 = PMAF_PRIO_SLICE_LOG2;       // 2^10 ticks of the 100 MHz wall clock
+constexpr int PRIO_SLICE_LOG2 = PMAF_PRIO_SLICE_LOG2;       // 2^9 ticks of the 100 MHz wall clock
 constexpr unsigned PRIO_YOUNGER_OF_8 = PMAF_PRIO_YOUNGER_OF_8;
-constexpr unsigned POP_ROTATE = 8;
+#ifndef PMAF_POP_ROTATE
+#define PMAF_POP_ROTATE 8
+#endif
+constexpr unsigned POP_ROTATE = PMAF_POP_ROTATE;
 template <int LPA, int TILES, int MATH>
 __global__ __launch_bounds__(64) void k_rollout_grp(DevView D, CostParams CP) {
   extern __shared__ double smem[];

@@ -276,10 +276,14 @@ static int pick_lpa(int N, int P, int M) {
   //   wave per agent 360 / 549 / 1024 / -,  32 lanes 512 / 492 / 697 / 1348,  16 lanes 672 / 712 / 684 / 1017.
   // The wave-per-agent kernel is the fastest while every wave has a SIMD to itself (<= 1024 waves); a second
   // wave per SIMD costs it more than the group kernels' narrower mapping does, and those run best at 2 per SIMD.
+  // Re-measured at the end of round 3 (C5-shaped populations, kernel us for 1024 / 2048 / 4096 / 8192 agents):
+  //   wave per agent 239 / 395 / 722 / 1336,  32 lanes 416 / 417 / 519 / 1019,  16 lanes 532 / 570 / 561 / 739:
+  // with the shorter step the wave-per-agent kernel also wins at TWO waves per SIMD (2048 agents), so every mapping
+  // now runs up to 2048 waves.
   int lpa = 64;
   while (lpa > 1) {
     long waves = ((long)N * lpa + 63) / 64 * P;
-    if (waves > (lpa == 64 ? 1024 : 2048)) lpa /= 2; else break;
+    if (waves > 2048) lpa /= 2; else break;
   }
   // 129..256 obstacles: the lane-group kernels hold at most 4 slots per lane (M <= 128 at 32 lanes), so a narrower
   // mapping would fall to the generic LDS-table kernel -- the four-slot wave-per-agent kernel is 2.7-3.7x faster

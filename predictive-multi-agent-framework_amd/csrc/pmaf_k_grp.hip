@@ -124,6 +124,7 @@ __global__ __launch_bounds__(64) void k_rollout_grp(DevView D, CostParams CP) {
 #define PMAF_GRP_PACK 1
 #endif
   constexpr bool PACK = PMAF_GRP_PACK && (LPA >= 16);
+  const double inv_shell = 1.0 / C.shell;   // (sentinel_repel_m)
   const int rsub = sub & 15;
   const bool l_nv = (rsub == 1), l_des = (rsub == 2);
   double lane_scale = l_des ? (k_attr / k_damp) : 1.0;   // vel_des = (k_attr / k_damp) * g rides as g * lane_scale
@@ -152,7 +153,7 @@ __global__ __launch_bounds__(64) void k_rollout_grp(DevView D, CostParams CP) {
     if (PACK) {
       // finish_step_w64 up to the new velocity (repelForce :159-181, attractorForce :183-193, the acceleration clamp and
       // the integration :253-258) ...
-      if (sent_reachable) F = F + (mk(0.0, 0.0, 0.0) + sentinel_repel(p, C, k_repel, sent_p, sent_r, zsent_lt));
+      if (sent_reachable) F = F + (mk(0.0, 0.0, 0.0) + sentinel_repel_m<MATH>(p, C, k_repel, sent_p, sent_r, zsent_lt, inv_shell));
       if (k_attr != 0.0) F = F + (scale * k_damp) * verr;
       V3 acc = F;
       if (C.mass != 1.0) acc = F / C.mass;

@@ -159,7 +159,8 @@ __device__ __forceinline__ void rollout_w64_body(const DevView &D, const CostPar
     }
   }
   V3 repel = mk(0.0, 0.0, 0.0);  // repelForce of the coming step (depends on the step's start state only)
-  if (sent_reachable) repel = sentinel_repel(p, C, k_repel, sent_p, sent_r, zsent_lt);
+  const double inv_shell = (SENT == 0) ? 0.0 : 1.0 / C.shell;   // (sentinel_repel_m)
+  if (sent_reachable) repel = sentinel_repel_m<MATH>(p, C, k_repel, sent_p, sent_r, zsent_lt, inv_shell);
   SecTimers ST;
 #ifdef PMAF_SECTION_TIMERS
   ST.start();
@@ -275,7 +276,7 @@ __device__ __forceinline__ void rollout_w64_body(const DevView &D, const CostPar
     // away, and a block that is skipped costs a taken branch per step)
     if ((SENT == 2) ? PMAF_RARE(sent_reachable) : sent_reachable) {  // the only masked block of the step for the repulsive obstacle: advance it, next step's repelForce
       sent_p = sent_p + sent_v * C.dt;
-      repel = sentinel_repel(p, C, k_repel, sent_p, sent_r, zsent_lt);
+      repel = sentinel_repel_m<MATH>(p, C, k_repel, sent_p, sent_r, zsent_lt, inv_shell);
     }
     PMAF_SEC(ST, 7);
   }
@@ -340,8 +341,8 @@ __global__ __launch_bounds__(64) void k_rollout_w64(DevView D, CostParams CP) {
     const PopConst C0 = D.C;
     const bool reach = sentinel_reachable(p0, sp, sv, D.zsent_lt[pop], C0, D.cap);
 #define PMAF_BODY(T) \
-    if (reach) rollout_w64_body<TILES, T, MATH, 1, DPPSUM, PLAIN>(D, CP, lane, pop, a); \
-    else rollout_w64_body<TILES, T, MATH, 0, DPPSUM, PLAIN>(D, CP, lane, pop, a)
+    if (!reach) rollout_w64_body<TILES, T, MATH, 0, DPPSUM, PLAIN>(D, CP, lane, pop, a); \
+    else rollout_w64_body<TILES, T, MATH, 1, DPPSUM, PLAIN>(D, CP, lane, pop, a)
     switch (D.types[a]) {
       case T_GOAL: PMAF_BODY(T_GOAL); break;
       case T_OBST: PMAF_BODY(T_OBST); break;

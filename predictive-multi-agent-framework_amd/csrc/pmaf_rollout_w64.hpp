@@ -130,6 +130,37 @@ __device__ __forceinline__ V3 sentinel_repel(V3 p, const PopConst &C, double k_r
   return repel;
 }
 
+// sentinel_repel in the kernel's arithmetic policy (round 3): in BASELINE C4 the repulsive obstacle is the other arm's
+// end effector and sits inside the range for a good part of every rollout, so the block is not rare there -- with the
+// compiler's IEEE expansions (two square roots, seven divisions: ~240 instructions) the step of the C4 kernel was 45 %
+// longer than C2's. Same operations on the same operands through the policy's sequences (bit-equal to the IEEE ones in
+// the validated range, test_xact_sequences_match_ieee): ONE square root -- |dist_vec| and |p - sent_pos| are the norm of
+// the same vector up to sign, so their squared norms are the same double --, normalized() by a select on the divisor,
+// 1 / d and the three divisions by d d through refined reciprocals without fixup (d in [1e-5, shell), d d >= 1e-10:
+// positive normals; numerators finite); 1 / shell comes in as a loop invariant.
+template <int MATH>
+__device__ __forceinline__ V3 sentinel_repel_m(V3 p, const PopConst &C, double k_repel, V3 sent_pos, double sent_rad,
+                                               double zsent_lt, double inv_shell) {
+  typedef Mth<MATH> MT;
+  const V3 ro = sent_pos - p;
+  const V3 dist_vec = -ro;
+  V3 repel = mk(0.0, 0.0, 0.0);
+  const double z = sqn(dist_vec);
+  if (z < zsent_lt) {
+    const double s = MT::sqrt(z);                       // norm(dist_vec) == norm(p - sent_pos)
+    double d = s - (C.rad + sent_rad);
+    d = smax(d, 1e-5);
+    const V3 pms = p - sent_pos;
+    const double sd = (z > 0.0) ? s : 1.0;              // normalized(): the vector itself unless squaredNorm > 0
+    const V3 otr = MT::div3_n_pos(pms, sd, MT::rcp_for(sd));
+    const double t = MT::div_pos(1.0, d) - inv_shell;
+    const double dd = d * d;
+    const V3 num = (k_repel * otr) * t;
+    repel = MT::div3_n_pos(num, dd, MT::rcp_for(dd));
+  }
+  return repel;
+}
+
 // repelForce for the REAL agent's step (RealCfAgent::cfPlanner -> CfAgent::repelForce, B/src/cf_agent.cpp:159-181):
 // the live obstacle list is the caller's, so its last radius may differ from the create-time one the host-computed
 // squared boundary (zsent_lt) was derived from -- the range test is the reference's own `d < shell` on the live radius.

@@ -10,6 +10,7 @@ for c in c2 c3 c5; do
   for i in 1 2 3 4 5; do [ -s gpurun_out/prof_r3_$c/pmc${i}_summary.txt ] && cp gpurun_out/prof_r3_$c/pmc${i}_summary.txt profiles/r3_${c}_pmc$i.txt; done
 done
 [ -s gpurun_out/r3_asan.txt ] && cp gpurun_out/r3_asan.txt profiles/r3_asan.txt
+[ -s gpurun_out/r3_agent_times.txt ] && cp gpurun_out/r3_agent_times.txt profiles/r3_agent_times.txt
 [ -s gpurun_out/r3_gpu_tests.log ] && cp gpurun_out/r3_gpu_tests.log profiles/r3_gpu_tests.log
 python tools/traffic_from_pmc.py C2=r3_c2 C3=r3_c3 C5x8=r3_c5
 python tools/fill_numbers.py > /dev/null && echo "DESIGN / README blocks regenerated"

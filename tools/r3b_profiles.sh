@@ -13,6 +13,8 @@ PMAF_BENCH_FORCE_DIST=1 MASTER_PORT=29531 python bench.py --only-headline --cpu-
 bash tools/gpu_prof.sh r3_c2 > /dev/null 2>&1
 bash tools/gpu_prof.sh r3_c3 --config C3 --steps 400 > /dev/null 2>&1
 bash tools/gpu_prof.sh r3_c5 --config C5 --populations 8 --steps 400 > /dev/null 2>&1
+{ echo "# per-agent / per-wave rollout durations from the device clock, and launch duration against the slowest wave (final kernels of round 3)";
+  python tools/agenttime.py C1 C2 C3; python tools/c4agents.py; python tools/c5agents.py; python tools/launchgap.py; } 2>&1 | grep -v "^$\|amdgpu.ids" > gpurun_out/r3_agent_times.txt
 bash tools/asan.sh run > /dev/null 2>&1
 python -m pytest tests -m gpu -q 2>&1 | grep -v "^RCCL\|^HIP\|^ROCm\|^Hostname\|^Librccl" | tail -6 > gpurun_out/r3_gpu_tests.log
 for f in gpurun_out/r3_bench_*.json; do echo "== $f"; python - "$f" <<'PY'

@@ -165,16 +165,7 @@ __device__ __forceinline__ void rollout_w64_body(const DevView &D, const CostPar
 #ifdef PMAF_SECTION_TIMERS
   ST.start();
 #endif
-#ifdef PMAF_W64_SHARED   // experiment: issue-priority time slicing when two waves share a SIMD (as in the group kernel)
-  const unsigned lin_block = blockIdx.y * gridDim.x + blockIdx.x;
-  const bool shared_simd = gridDim.x * gridDim.y > (unsigned)D.n_simds;
-  const bool younger = ((lin_block / (unsigned)D.n_simds) & 1u) != 0u;
-#endif
   while ((dg > 0.1) && (n < D.cap)) {  // wave-uniform guard, B/src/cf_agent.cpp:310-311
-#ifdef PMAF_W64_SHARED
-    unsigned long long clk = 0ull;
-    if (shared_simd) clk = wall_clock64();
-#endif
     // gate, :315-317
     // |v| < 0.5 vmax and |p - init| < 0.2 on exact squared thresholds
     // (as a lane mask built from single compares: pmaf_rollout_w64.hpp, "lane predicates as masks")
@@ -288,16 +279,7 @@ __device__ __forceinline__ void rollout_w64_body(const DevView &D, const CostPar
       repel = sentinel_repel_m<MATH>(p, C, k_repel, sent_p, sent_r, zsent_lt, inv_shell);
     }
     PMAF_SEC(ST, 7);
-#ifdef PMAF_W64_SHARED
-    if (shared_simd) {
-      if (((((unsigned)(clk >> 9)) & 7u) < (unsigned)PMAF_W64_SHARED) == younger) __builtin_amdgcn_s_setprio(1);
-      else __builtin_amdgcn_s_setprio(0);
-    }
-#endif
   }
-#ifdef PMAF_W64_SHARED
-  __builtin_amdgcn_s_setprio(0);
-#endif
 #ifdef PMAF_SECTION_TIMERS
   if (lane == 0 && pop == 0 && a < 7)
     printf("agent %d type %d steps %d | verr+gate %llu sweep %llu scale %llu circ %llu sum %llu (skip) %llu finish %llu tail %llu | "

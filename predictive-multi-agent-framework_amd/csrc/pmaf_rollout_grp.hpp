@@ -94,6 +94,40 @@ __device__ __forceinline__ V3 closest_other_grp(bool srch, int t, int sub, int g
   return cpos;
 }
 
+// currentVector (pmaf_device.hpp: current_vector) for a wave whose agents may use DIFFERENT heuristics (the group kernel:
+// the type is a per-lane run-time value). Evaluated branch by branch a mixed wave -- every population's first two waves
+// hold its five heuristic agents, and they bound the C5 launch -- runs one normalisation per branch; here the branches
+// only form the un-normalised vector (wave-uniform guards skip a branch no lane needs) and ONE normalisation serves all
+// lanes: cur / sqrt(z) with the divisor replaced by 1.0 for z == 0 (normalized() of the Obstacle / GoalObstacle / Random /
+// Had branch), and (0, 0, 1) for the Goal / Velocity branch's `cur.norm() < 1e-10` (on the squared norm, see
+// current_vector). The Velocity branch's normalized(rel_vel) is the circular term's own nv = rel_vel / |rel_vel| where
+// the squared norm is positive, rel_vel itself otherwise. Same operations on the same operands per lane.
+template <int MATH>
+__device__ __forceinline__ V3 current_vector_grp(int type, V3 rel_vel, V3 nv, double zrv, V3 goal_vec, V3 to_obs, V3 rot) {
+  typedef Mth<MATH> M;
+  const bool is_goal = (type == T_GOAL), is_vel = (type == T_VEL);
+  const lmask goal_m = PMAF_BAL(is_goal), vel_m = PMAF_BAL(is_vel);
+  V3 cur = mk(0.0, 0.0, 0.0);
+  if (~(goal_m | vel_m) != 0ull) cur = cross(to_obs, rot);
+  if (PMAF_RARE(goal_m != 0ull)) {
+    const V3 cg = goal_vec - to_obs * dot(to_obs, goal_vec);
+    if (is_goal) cur = cg;
+  }
+  if (PMAF_RARE(vel_m != 0ull)) {
+    const V3 nvel = (zrv > 0.0) ? nv : rel_vel;
+    const V3 cv = nvel - to_obs * dot(nvel, to_obs);
+    if (is_vel) cur = cv;
+  }
+  const double z = sqn(cur);
+  const double s = M::sqrt_pos(z);
+  const double sd = (z > 0.0) ? s : 1.0;
+  V3 q = M::div3_n_pos(cur, sd, M::rcp_for(sd));
+  if (PMAF_RARE((goal_m | vel_m) != 0ull)) {
+    if ((is_goal || is_vel) && z < 0x1.79ca10c924223p-67) q = mk(0.0, 0.0, 1.0);
+  }
+  return q;
+}
+
 // circForce + attractorForceScaling for the agents of one wave. `act`: the
 // lane's agent takes a step and its gate is open (uniform within the group).
 // clist: this GROUP's list in LDS (LPA*TILES entries of 4 doubles + one
@@ -166,7 +200,11 @@ __device__ __forceinline__ void circ_and_scale_grp(lmask act_m, int sub, int grp
       double vn, rvn;
       MT::norm_rcp_zpos(zrv, vn, rvn);
       const V3 nv = MT::div3_n_pos(rv, vn, rvn);
-      const V3 cur = current_vector<MATH, true>(type, rv, g, ron, rot);
+#ifndef PMAF_GRP_CURVEC
+#define PMAF_GRP_CURVEC 1
+#endif
+      const V3 cur = PMAF_GRP_CURVEC ? current_vector_grp<MATH>(type, rv, nv, zrv, g, ron, rot)
+                                     : current_vector<MATH, true>(type, rv, g, ron, rot);
       const V3 c = MT::div_pos(k_circ, d * d) * cross(nv, cross(cur, nv));   // d >= 1e-5
       const lmask m = in_m & PMAF_BAL(zrv != 0);   // vel_norm != 0, B/src/cf_agent.cpp:98
       if (PMAF_LANE(m)) {

@@ -52,7 +52,10 @@ kcompile() {  # kcompile <object stem> <source> [defines...]
 # with top-down pre-RA scheduling (1080 -> 1054 us per launch), the one-slot kernels (C1, C2) 1 % slower (one box,
 # tools/dbg/ab variants; profiles/r3_ab_sched_flags.txt)
 kcompile k_w64_m2_t1 pmaf_k_w64.hip -DPMAF_W64_MATH=2 -DPMAF_W64_PART=1
-kcompile k_w64_m2_tn pmaf_k_w64.hip -DPMAF_W64_MATH=2 -DPMAF_W64_PART=2 -mllvm -misched-prera-direction=topdown
+# (third session: and with every block that is not fallen into aligned to 64 bytes -- C3 1018.9 -> 1011.2 us on one box, any
+# alignment from 16 to 128 bytes within 2 us of that; the one-slot kernels lose 0.2-0.8 % with it, the group kernel is
+# indifferent: profiles/r3_ab_session3.txt item 19)
+kcompile k_w64_m2_tn pmaf_k_w64.hip -DPMAF_W64_MATH=2 -DPMAF_W64_PART=2 -mllvm -misched-prera-direction=topdown -mllvm -align-all-nofallthru-blocks=6
 kcompile k_w64_m0 pmaf_k_w64.hip -DPMAF_W64_MATH=0
 kcompile k_w64_m1 pmaf_k_w64.hip -DPMAF_W64_MATH=1
 kcompile k_grp_m2 pmaf_k_grp.hip -DPMAF_GRP_MATH=2

@@ -150,6 +150,11 @@ int pmaf_reset_agents(pmaf_planner *h, const double *pos, const double *vel,
  * Returns once best_idx / next_pos / next_vel (each [P], [P][3], [P][3]; may be
  * NULL) are on the host; the new rollout keeps running asynchronously, like
  * the reference's prediction threads. obstacles may be NULL (= unchanged).
+ * A list that differs from the previous one in a field obstacle (compared bit for
+ * bit) and is at rest makes the next reset recompute the Obstacle / GoalObstacle
+ * heuristics' closest-other table (populations of more than 61 field obstacles on
+ * the wave-per-agent kernels; M distances per obstacle, once): passing the same
+ * static list every tick, as the reference's node does, costs nothing.
  */
 int pmaf_tick(pmaf_planner *h, const double *obstacles, double dt,
               const double *cost_gains, const double *ws, int32_t *best_idx,

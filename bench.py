@@ -117,7 +117,8 @@ def cpu_baseline(config, budget_s):
     return out
 
 
-def kernel_name_of(cfg, n_obs):
+def kernel_name_of(cfg, n_obs, math=2):
+    """math: the arithmetic policy's template argument (2 = strict default, 3 = contracted)"""
     tiles = (n_obs - 1 + 63) // 64
     if 62 <= n_obs - 1 <= 64:
         tiles = 2
@@ -129,10 +130,10 @@ def kernel_name_of(cfg, n_obs):
             dpp = t > 1 or os.environ["PMAF_SUM"].startswith("d")
         # <TILES, MATH_XACT, DPPSUM, PLAIN>; the bench scenes have k_attr != 0 and unit mass = the PLAIN step
         plain = os.environ.get("PMAF_PLAIN_STEP", "1")[:1] != "0"
-        return "k_rollout_w64<%d, 2, %s, %s>" % (t, "true" if dpp else "false", "true" if plain else "false")
+        return "k_rollout_w64<%d, %d, %s, %s>" % (t, math, "true" if dpp else "false", "true" if plain else "false")
     if cfg["lanes_per_agent"] in (8, 16, 32) and (n_obs - 2) // cfg["lanes_per_agent"] + 1 <= 4 and not generic:
         tl = (n_obs - 2) // cfg["lanes_per_agent"] + 1
-        return "k_rollout_grp<%d, %d, 2>" % (cfg["lanes_per_agent"], 1 if tl <= 1 else 2 if tl == 2 else 4)
+        return "k_rollout_grp<%d, %d, %d>" % (cfg["lanes_per_agent"], 1 if tl <= 1 else 2 if tl == 2 else 4, math)
     return "k_rollout<%d>" % cfg["lanes_per_agent"]
 
 
@@ -328,7 +329,8 @@ def run_workload(ctx, spec, args, full):
         N, H, n_obs = sc["n_agents"], sc["max_prediction_steps"] - 1, sc["obstacles"].shape[0]
         P = len(scenes)
         starts = np.stack([s["start"] for s in scenes])
-        planner = pkg.PmafPlanner(scenes, device=ctx.local_rank, lanes_per_agent=spec["lanes_per_agent"], mgr_init_pos=starts)
+        planner = pkg.PmafPlanner(scenes, device=ctx.local_rank, lanes_per_agent=spec["lanes_per_agent"], mgr_init_pos=starts,
+                                  contracted=(spec.get("policy", "strict") == "contracted"))
         planner.set_initial_position(starts)
         obs = np.stack([s["obstacles"] for s in scenes])
         dt, cg, ws = sc["dt"], sc["cost_gains"], sc["ws_limits"]
@@ -475,7 +477,7 @@ def run_workload(ctx, spec, args, full):
     bytes_per_launch = P * algorithmic_bytes_per_tick(N, H, n_obs)
     achieved = bytes_per_launch / avg_kernel_s / 1e9
     steps_per_launch = r0["steps_per_launch"]
-    kernel_name = kernel_name_of(cfg, n_obs)
+    kernel_name = kernel_name_of(cfg, n_obs, 3 if spec.get("policy") == "contracted" else 2)
     rec = {
         "rollouts_per_s": value, "ms_per_tick": elapsed / steps * 1e3, "scaling": scaling, "gpus_used": n_part,
         "workload": "%s: %d agents x %d-step horizon, %d sphere obstacles + repulsive sentinel, %d population(s) per GPU "
@@ -506,6 +508,7 @@ def run_workload(ctx, spec, args, full):
             "note": "peer mailboxes: wait = time the manager kernel of a tick spent waiting for the other arm's header of "
                     "the previous tick (all the coupling costs the control path), publish = its stores into the peers' "
                     "inboxes incl. the system-scope fence; device clock; no winners_wait on the tick path"},
+        "arithmetic_policy": spec.get("policy", "strict"),
         "kernel": kernel_name, "avg_kernel_us": r0["kernel_us"], "per_rank_kernel_us": [u["kernel_us"] for u in used],
         "lanes_per_agent": cfg["lanes_per_agent"], "rollout_blocks": cfg["n_blocks"],
         "algorithmic_bytes_per_launch": bytes_per_launch, "hbm_achieved_gbs": achieved, "hbm_frac": achieved / HBM_PEAK_GBS,
@@ -597,6 +600,13 @@ def main():
         if 8 % world == 0:
             plan.append(("C5_sharded", dict(base, config="C5", mode="shard")))
         plan.append(("C4", dict(base, config="C4", mode="c4")))
+        # the opt-in contracted arithmetic policy (PMAF_FLAG_CONTRACTED: rcp / rsq sequences + FMA contraction; NOT
+        # bit-exact, tolerance parity where tests/test_tolerance_gpu.py says it holds) beside the strict sub-records:
+        # what the north star's 1e-5 m budget buys in kernel time. Never the headline `value`.
+        plan.append(("C2_contracted", dict(base, config="C2", mode="replica", policy="contracted")))
+        plan.append(("C3_contracted", dict(base, config="C3", mode="replica", policy="contracted")))
+        if 8 % world == 0:
+            plan.append(("C5_sharded_contracted", dict(base, config="C5", mode="shard", policy="contracted")))
         for name, spec in plan:
             r = run_workload(ctx, spec, args, full=False)
             if rank == 0:

@@ -82,6 +82,14 @@ typedef struct pmaf_planner pmaf_planner;
  * wake-up latency (set-point up to a quantum + scheduler latency later).
  * Default: spin (lowest set-point latency). */
 #define PMAF_FLAG_BLOCKING_WAIT 4
+/* Opt-in CONTRACTED arithmetic in the rollout kernels (wave-per-agent and group kernels; ABI 5): PMAF_FLAG_FAST_MATH's
+ * reciprocal / reciprocal-square-root sequences AND fused multiply-adds wherever the step forms a * b + c (dot products,
+ * cross products, the integrator's a + b * s), plus an unordered (tree) force sum. The step of these kernels is bound
+ * by its instruction count, and the FMA is the one FP64 instruction that retires two operations. Results are NOT
+ * bit-identical to the CPU restatement: the contract is the north star's -- the selected trajectory within 1e-5 m of
+ * the reference planner's (tests/test_parity_gpu.py::test_contracted_*). The real agent's step (the set-point that is
+ * published) is always evaluated in strict arithmetic. Default: flag clear. */
+#define PMAF_FLAG_CONTRACTED 8
 
 /*
  * Arguments of CfManager::init (B/src/cf_manager.cpp:41-124,

@@ -2,9 +2,10 @@
 # Builds libpmaf_hip.so (HIP kernels + C-ABI) for gfx950, in-tree.
 #
 # Translation units (compiled in parallel, objects kept in ../lib/obj):
-#   pmaf_k_w64.hip   x4  the wave-per-agent rollout kernel, once per arithmetic policy (-DPMAF_W64_MATH=0|1|2; the default
-#                        policy 2 in two units: one-slot / multi-slot kernels, -DPMAF_W64_PART=1|2)
-#   pmaf_k_grp.hip   x2  the group rollout kernel (-DPMAF_GRP_MATH=0|2)
+#   pmaf_k_w64.hip   x5  the wave-per-agent rollout kernel, once per arithmetic policy (-DPMAF_W64_MATH=0|1|2|3; the default
+#                        policy 2 in two units: one-slot / multi-slot kernels, -DPMAF_W64_PART=1|2; policy 3 = the opt-in
+#                        contracted one, the only units compiled with -ffp-contract=fast)
+#   pmaf_k_grp.hip   x3  the group rollout kernel (-DPMAF_GRP_MATH=0|2|3)
 #   pmaf_k_misc.hip      generic rollout, manager, scoring, winner records ... + the launch interface
 #   pmaf_host.cpp        the C-ABI (g++, plain C++ against the HIP runtime API)
 #   pmaf_shard.cpp       communicators + the winner-record exchange (RCCL / host-callback)
@@ -59,6 +60,9 @@ kcompile k_w64_m2_tn pmaf_k_w64.hip -DPMAF_W64_MATH=2 -DPMAF_W64_PART=2 -mllvm -
 kcompile k_w64_m0 pmaf_k_w64.hip -DPMAF_W64_MATH=0
 kcompile k_w64_m1 pmaf_k_w64.hip -DPMAF_W64_MATH=1
 kcompile k_grp_m2 pmaf_k_grp.hip -DPMAF_GRP_MATH=2
+# contracted policy (PMAF_FLAG_CONTRACTED, opt-in; tolerance parity): the only units built with FMA contraction
+kcompile k_w64_m3 pmaf_k_w64.hip -DPMAF_W64_MATH=3 -ffp-contract=fast
+kcompile k_grp_m3 pmaf_k_grp.hip -DPMAF_GRP_MATH=3 -ffp-contract=fast
 kcompile k_grp_m0 pmaf_k_grp.hip -DPMAF_GRP_MATH=0
 kcompile k_misc pmaf_k_misc.hip
 ( $CXX $HFLAGS -c pmaf_host.cpp -o "$OBJ/host.o" 2> "$OBJ/host.log" ) &
@@ -72,7 +76,7 @@ done
 [ "$fail" = 0 ] || exit 1
 for n in "${names[@]}"; do grep -E -A3 "warning:|error:" "$OBJ/$n.log" >&2 || true; done
 $HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT/libpmaf_hip.so" \
-  "$OBJ"/k_w64_m2_t1.o "$OBJ"/k_w64_m2_tn.o "$OBJ"/k_w64_m0.o "$OBJ"/k_w64_m1.o "$OBJ"/k_grp_m2.o "$OBJ"/k_grp_m0.o "$OBJ"/k_misc.o \
+  "$OBJ"/k_w64_m2_t1.o "$OBJ"/k_w64_m2_tn.o "$OBJ"/k_w64_m0.o "$OBJ"/k_w64_m1.o "$OBJ"/k_grp_m2.o "$OBJ"/k_grp_m0.o "$OBJ"/k_w64_m3.o "$OBJ"/k_grp_m3.o "$OBJ"/k_misc.o \
   "$OBJ"/host.o "$OBJ"/shard.o -L"$ROCM/lib" -lrccl -Wl,-rpath,"$ROCM/lib" ${PMAF_EXTRA_LDFLAGS}
 # (the log of an object that was up to date is the one of its last compile)
 cat "$OBJ"/k_*.log | grep "kernel-resource-usage" | sed -e 's/^[^ ]* remark: *//' -e 's/ \[-Rpass-analysis=kernel-resource-usage\]//' > "$OUT/resource_usage.txt"

@@ -89,7 +89,17 @@ __device__ __forceinline__ double smin(double a, double b) { return (b < a) ? b 
 // MATH_FAST (1)  opt-in (PMAF_FLAG_FAST_MATH): v_rcp_f64 / v_rsq_f64 seeds
 //                (2^-24) + two Newton iterations, no residual correction:
 //                1-2 ulp per operation; tolerance parity only.
-// (enum MATH_IEEE / MATH_FAST / MATH_XACT: pmaf_types.hpp)
+// MATH_FMA (3)   opt-in (PMAF_FLAG_CONTRACTED, round 4): MATH_FAST's sequences AND
+//                the translation unit compiled with -ffp-contract=fast, so the
+//                step's dot / cross / axpy forms retire as v_fma_f64 (dot 5 -> 3,
+//                cross 9 -> 6, a + b * s 2 -> 1 instructions) -- the step is
+//                issue-bound on instruction count and the FMA is the one
+//                instruction that retires two flops. Where this policy is the
+//                template argument the code may also drop bit-exactness-only
+//                structure (the ordered force sum becomes a DPP tree). Tolerance
+//                parity only (north star: selected trajectory <= 1e-5 m); the
+//                real agent's step in k_manager stays strict.
+// (enum MATH_IEEE / MATH_FAST / MATH_XACT / MATH_FMA: pmaf_types.hpp)
 
 template <int MATH> struct Mth;
 template <> struct Mth<MATH_IEEE> {
@@ -285,6 +295,8 @@ template <> struct Mth<MATH_FAST> {
   template <bool TP = false>
   static __device__ __forceinline__ V3 normalized(V3 a) { double s; V3 u; norm_unit(a, s, u); return u; }
 };
+
+template <> struct Mth<MATH_FMA> : Mth<MATH_FAST> {};
 
 // exp() of attractorForceScaling (B/src/cf_agent.cpp:220). The reference calls the platform libm, whose last bit is
 // not portable; this is a table-free exp in correctly rounded IEEE operations only (multiply, round-to-nearest-even

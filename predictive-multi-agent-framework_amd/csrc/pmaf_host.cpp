@@ -347,8 +347,8 @@ static void launch_rollout(pmaf_planner *h) {
     // ordered force sum: the DPP chain (h->dpp_sum, see pmaf_create), LDS batches on request (pmaf_rollout_w64.hpp)
     ok = pmaf_k_launch_w64(h->D, h->cp, tiles64, h->math, h->dpp_sum, h->plain_step, h->lds_rollout, h->stream, e0, e1);
   else if (!h->force_generic && (h->lpa == 32 || h->lpa == 16 || h->lpa == 8) && (M + h->lpa - 1) / h->lpa <= 4)
-    // (the opt-in fast arithmetic exists for the w64 kernels only)
-    ok = pmaf_k_launch_grp(h->D, h->cp, h->lpa, (M + h->lpa - 1) / h->lpa, h->math == MATH_IEEE ? MATH_IEEE : MATH_XACT,
+    // (policy 1, the plain fast arithmetic, exists for the w64 kernels only)
+    ok = pmaf_k_launch_grp(h->D, h->cp, h->lpa, (M + h->lpa - 1) / h->lpa, h->math == MATH_FAST ? MATH_XACT : h->math,
                            h->n_blocks, h->lds_rollout, h->stream, e0, e1);
   else
     ok = pmaf_k_launch_generic(h->D, h->cp, h->lpa, h->n_blocks, h->lds_rollout, h->stream, e0, e1);
@@ -720,7 +720,8 @@ int pmaf_create(const pmaf_params *prm, pmaf_planner **out) {
     D.C.zf_gt = sq_gt(1e-5); D.C.zacc_gt = sq_gt(13.0); D.C.zinit_lt = sq_ge(0.2);
     D.C.zvhalf_lt = sq_ge(0.5 * prm->velocity_max);
     D.C.zv09_lt = sq_ge(prm->velocity_max - 0.1 * prm->velocity_max);
-    h->math = (prm->flags & PMAF_FLAG_FAST_MATH) ? MATH_FAST : (prm->flags & PMAF_FLAG_IEEE_SEQUENCES) ? MATH_IEEE : MATH_XACT;
+    h->math = (prm->flags & PMAF_FLAG_CONTRACTED) ? MATH_FMA : (prm->flags & PMAF_FLAG_FAST_MATH) ? MATH_FAST
+              : (prm->flags & PMAF_FLAG_IEEE_SEQUENCES) ? MATH_IEEE : MATH_XACT;
     h->blocking_wait = (prm->flags & PMAF_FLAG_BLOCKING_WAIT) != 0;
     h->lpa = lp ? lp : pick_lpa(N, P, M);
     { const char *fg = getenv("PMAF_FORCE_GENERIC"); h->force_generic = fg && fg[0] == '1'; }

@@ -1,5 +1,6 @@
 // pmaf_k_grp.hip -- k_rollout_grp<LPA, TILES, MATH>: 8/16/32 lanes per agent (throughput shape: C5) and its launcher.
-// Compiled once per arithmetic policy (-DPMAF_GRP_MATH=0|2; the opt-in fast arithmetic exists for the w64 kernels only).
+// Compiled once per arithmetic policy (-DPMAF_GRP_MATH=0|2|3; 3 = the contracted policy, with -ffp-contract=fast; the
+// plain fast arithmetic, policy 1, exists for the w64 kernels only).
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 
@@ -243,7 +244,7 @@ __global__ __launch_bounds__(64) void k_rollout_grp(DevView D, CostParams CP) {
 
 
 #ifndef PMAF_GRP_MATH
-#error "compile with -DPMAF_GRP_MATH=0|2"
+#error "compile with -DPMAF_GRP_MATH=0|2|3"
 #endif
 #define PMAF_CAT2(a, b) a##b
 #define PMAF_CAT(a, b) PMAF_CAT2(a, b)

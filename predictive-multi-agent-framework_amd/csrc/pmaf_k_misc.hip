@@ -779,9 +779,12 @@ bool pmaf_k_launch_w64_m2_t1(const DevView &, const CostParams &, int, bool, boo
 bool pmaf_k_launch_w64_m2_tn(const DevView &, const CostParams &, int, bool, bool, size_t, hipStream_t, hipEvent_t, hipEvent_t);   // two / four slots
 bool pmaf_k_launch_grp_m0(const DevView &, const CostParams &, int, int, int, size_t, hipStream_t, hipEvent_t, hipEvent_t);
 bool pmaf_k_launch_grp_m2(const DevView &, const CostParams &, int, int, int, size_t, hipStream_t, hipEvent_t, hipEvent_t);
+bool pmaf_k_launch_w64_m3(const DevView &, const CostParams &, int, bool, bool, size_t, hipStream_t, hipEvent_t, hipEvent_t);      // contracted policy
+bool pmaf_k_launch_grp_m3(const DevView &, const CostParams &, int, int, int, size_t, hipStream_t, hipEvent_t, hipEvent_t);
 
 bool pmaf_k_launch_w64(const DevView &D, const CostParams &cp, int tiles, int math, bool dppsum, bool plain, size_t lds,
                        hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
+  if (math == MATH_FMA) return pmaf_k_launch_w64_m3(D, cp, tiles, dppsum, plain, lds, s, e0, e1);
   if (math == MATH_FAST) return pmaf_k_launch_w64_m1(D, cp, tiles, dppsum, plain, lds, s, e0, e1);
   if (math == MATH_IEEE) return pmaf_k_launch_w64_m0(D, cp, tiles, dppsum, plain, lds, s, e0, e1);
   return (tiles <= 1) ? pmaf_k_launch_w64_m2_t1(D, cp, tiles, dppsum, plain, lds, s, e0, e1)
@@ -791,6 +794,7 @@ bool pmaf_k_launch_w64(const DevView &D, const CostParams &cp, int tiles, int ma
 bool pmaf_k_launch_grp(const DevView &D, const CostParams &cp, int lpa, int tiles, int math, int n_blocks, size_t lds,
                        hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
   if (math == MATH_IEEE) return pmaf_k_launch_grp_m0(D, cp, lpa, tiles, n_blocks, lds, s, e0, e1);
+  if (math == MATH_FMA) return pmaf_k_launch_grp_m3(D, cp, lpa, tiles, n_blocks, lds, s, e0, e1);
   return pmaf_k_launch_grp_m2(D, cp, lpa, tiles, n_blocks, lds, s, e0, e1);
 }
 

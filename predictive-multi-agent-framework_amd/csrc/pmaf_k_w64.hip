@@ -1,5 +1,5 @@
 // pmaf_k_w64.hip -- k_rollout_w64<TILES, MATH>: the wave-per-agent rollout kernel (latency shape: C1, C2, C3) and its
-// launcher. Compiled once per arithmetic policy (-DPMAF_W64_MATH=0|1|2, csrc/build.sh) so the three policies build in
+// launcher. Compiled once per arithmetic policy (-DPMAF_W64_MATH=0|1|2|3, csrc/build.sh; 3 with -ffp-contract=fast) so the policies build in
 // parallel; each object defines pmaf_k_launch_w64_m<policy>, pmaf_k_launch_w64 (pmaf_k_misc.hip) dispatches.
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
@@ -368,7 +368,7 @@ __global__ __launch_bounds__(64) void k_rollout_w64(DevView D, CostParams CP) {
 
 
 #ifndef PMAF_W64_MATH
-#error "compile with -DPMAF_W64_MATH=0|1|2"
+#error "compile with -DPMAF_W64_MATH=0|1|2|3"
 #endif
 #define PMAF_CAT2(a, b) a##b
 #define PMAF_CAT(a, b) PMAF_CAT2(a, b)

@@ -17,7 +17,7 @@
 namespace pmaf {
 
 // arithmetic policy of the tuned rollout kernels (see pmaf_device.hpp "arithmetic policy")
-enum : int { MATH_IEEE = 0, MATH_FAST = 1, MATH_XACT = 2 };
+enum : int { MATH_IEEE = 0, MATH_FAST = 1, MATH_XACT = 2, MATH_FMA = 3 };
 
 struct PopConst {
   double dt, vel_max, approach, shell, mass, rad;
@@ -151,7 +151,7 @@ struct PlanArgs {
 // events) -- no marker packets in the stream, so timing a launch does not put anything between two kernels
 bool pmaf_k_launch_w64(const DevView &D, const CostParams &cp, int tiles, int math, bool dppsum, bool plain, size_t lds,
                        hipStream_t s, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
-// k_rollout_grp<LPA, TILES, MATH> on grid (n_blocks, P); lpa in {8,16,32}, tiles in {1,2,4}, math XACT or IEEE
+// k_rollout_grp<LPA, TILES, MATH> on grid (n_blocks, P); lpa in {8,16,32}, tiles in {1,2,4}, math XACT, IEEE or FMA
 bool pmaf_k_launch_grp(const DevView &D, const CostParams &cp, int lpa, int tiles, int math, int n_blocks, size_t lds,
                        hipStream_t s, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
 // generic k_rollout<LPA>, any power-of-two lpa 1..64

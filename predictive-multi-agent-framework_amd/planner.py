@@ -164,7 +164,7 @@ class PmafPlanner:
     scalar parameters. Method names follow the C-ABI / CfManager."""
 
     def __init__(self, scenes, device=-1, lanes_per_agent=0, mgr_init_pos=None, fast_math=False,
-                 ieee_sequences=False, blocking_wait=False):
+                 ieee_sequences=False, blocking_wait=False, contracted=False):
         if isinstance(scenes, dict):
             scenes = [scenes]
         self.L = load_library()
@@ -182,8 +182,9 @@ class PmafPlanner:
         prm.max_prediction_steps = self.cap
         prm.device = device
         prm.lanes_per_agent = lanes_per_agent
-        # PMAF_FLAG_FAST_MATH / _IEEE_SEQUENCES / _BLOCKING_WAIT
-        prm.flags = (1 if fast_math else 0) | (2 if ieee_sequences else 0) | (4 if blocking_wait else 0)
+        # PMAF_FLAG_FAST_MATH / _IEEE_SEQUENCES / _BLOCKING_WAIT / _CONTRACTED
+        prm.flags = ((1 if fast_math else 0) | (2 if ieee_sequences else 0) | (4 if blocking_wait else 0)
+                     | (8 if contracted else 0))
         prm.dt = s0["dt"]
         prm.velocity_max = s0["velocity_max"]
         prm.approach_dist = s0["approach_dist"]

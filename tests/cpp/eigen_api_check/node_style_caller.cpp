@@ -41,4 +41,13 @@ void node_style_init(CfManager &cf_manager_, const PositionMsg &p, const std::ve
   cf_manager_.init(goal, 0.01, obstacles_, k_a, k_c, k_r, k_d, k_m, k_rf, 0.2, 0.25, 0.35, 1500, 1);   // :463-471
   Obstacle o(Vector3d(0.1, 0.2, 0.3), 0.05);
   (void)o.getPosition().transpose();
+  // the task loader's and the obstacle callback's forms (B/src/panda_bimanual_control.cpp:52, :302-309)
+  std::vector<Obstacle> obs;
+  Vector3d obst_pos_(0.0, 0.0, 0.0), obst_vel_(0.0, 0.0, 0.0);
+  double radius_ = 0.1;
+  obs.push_back(Obstacle{obst_pos_, obst_vel_, radius_});
+  obs.at(0).setPosition(Vector3d(p.data[0], p.data[1], p.data[2]));
+  obs.at(0).setVelocity(obst_vel_);
+  (void)cf_manager_.getGoalPosition();                                                     // :513-517
+  (void)cf_manager_.getInitialPosition();
 }

@@ -448,6 +448,24 @@ def run_workload(ctx, spec, args, full):
             # the same calls on the library's own clock (pmaf_get_tick_times_us): without this script's ctypes / numpy
             # / interpreter time, which is where the tail of the figure above comes from
             idle_lib = planner.tick_times_us(idle.size)
+            # the tick SURVEY.md 8(d) defines: host call -> costs + best index + the WINNING TRAJECTORY on the host (what the
+            # reference's planCallback hands out, B/src/panda_bimanual_control.cpp:340-347). The manager kernel writes the
+            # selected agent's scored path into mapped pinned memory behind the set-point (pmaf_enable_winner_path);
+            # library clock: entry of pmaf_tick -> pmaf_view_winner_path returns. Idle stream, >= 1000 ticks.
+            planner.enable_winner_path(True)
+            wp_wall = np.zeros(1000)
+            for k in range(wp_wall.size):
+                maybe_restart_episode()
+                planner.stop()
+                if k == 0:
+                    planner.winner_path_times_us()   # clear
+                ta = time.perf_counter()
+                one_tick(obs)
+                planner.winner_path_wait()
+                wp_wall[k] = time.perf_counter() - ta
+            planner.stop()
+            wp_lib = planner.winner_path_times_us()
+            planner.enable_winner_path(False)
         mine_rec = dict(tick_us=float(np.median(lat) * 1e6), tick_p99=float(np.percentile(lat, 99) * 1e6),
                         ag_us=float(np.median(ag_us)) if ag_us.size else None,
                         ag_p99=float(np.percentile(ag_us, 99)) if ag_us.size else None, ag_n=int(ag_us.size),
@@ -514,6 +532,7 @@ def run_workload(ctx, spec, args, full):
         "algorithmic_bytes_per_launch": bytes_per_launch, "hbm_achieved_gbs": achieved, "hbm_frac": achieved / HBM_PEAK_GBS,
     }
     if full:
+        rec["_wp"] = (wp_lib, wp_wall) if (full and part and not (coupled and n_part > 1)) else (np.zeros(0), np.zeros(0))
         rec["_idle"] = idle
         rec["_idle_lib"] = idle_lib
         rec["_scene"] = sc
@@ -617,6 +636,7 @@ def main():
     line = None
     if rank == 0:
         idle, sc, P = head.pop("_idle"), head.pop("_scene"), head.pop("_P")
+        wp_lib, wp_wall = head.pop("_wp")
         idle_enq, idle_sp = head.pop("_idle_lib")
         transport, has_comm = head.pop("_transport"), head.pop("_has_comm")
         N, H, n_obs = head["agents"], head["horizon"], head["obstacles"] + 1
@@ -680,6 +700,14 @@ def main():
                             "set-point on the host; enqueue = both launches handed to the stream"},
                 "note": "tick issued on an idle stream: host call -> best index + next set-point "
                         "on the host (the new rollout then runs asynchronously); measured around the ctypes call"},
+            "tick_with_winner_path_us": None if not wp_lib.size else {
+                "median": float(np.median(wp_lib)), "p90": float(np.percentile(wp_lib, 90)),
+                "p99": float(np.percentile(wp_lib, 99)), "max": float(np.max(wp_lib)), "n": int(wp_lib.size),
+                "around_the_ctypes_calls": {"median": float(np.median(wp_wall) * 1e6), "p99": float(np.percentile(wp_wall, 99) * 1e6)},
+                "path_bytes": int((H + 1) * 24),
+                "note": "SURVEY 8(d) tick latency: entry of pmaf_tick -> best index, set-point AND the selected agent's "
+                        "scored path on the host (mapped pinned memory written by the manager kernel, no copy of the "
+                        "other agents' paths); library clock, tick issued on an idle stream"},
             "allgather_us": head["allgather_us"],
             "header_exchange_us": head["header_exchange_us"],
             "roofline": {"bound": "hbm", "achieved": head["hbm_achieved_gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -74,6 +74,8 @@ class CfManager {
   std::vector<std::vector<Vector3d>> paths_cache_;
   bool paths_cached_ = false;
   pmaf_comm *comm_ = nullptr;             // attached communicator (not owned)
+  bool throw_on_numeric_fault_ = true;    // planTick: std::runtime_error on a non-finite set-point / force
+  bool selected_path_on_ = false;         // enableSelectedPath survives a re-init
   void touch() { paths_cached_ = false; }
 
   static void check(int rc, const char *what) {
@@ -234,6 +236,7 @@ class CfManager {
       check(pmaf_set_best(h_, &id, &type, best_rand_.data()), "CfManager::init(best)");
     }
     if (comm_) check(pmaf_attach_comm(h_, comm_), "CfManager::init(communicator)");
+    if (selected_path_on_) check(pmaf_enable_winner_path(h_, 1), "CfManager::init(selected path)");
   }
 
   void startPrediction() { require(); touch(); check(pmaf_start(h_), "startPrediction"); }   // cf_manager.h:57-61
@@ -421,7 +424,40 @@ class CfManager {
     double np[3];
     check(pmaf_tick(h_, obs.data(), delta_t, gains, ws, &best, np, nullptr), "planTick");
     if (next_position) *next_position = Vector3d(np[0], np[1], np[2]);
+    // failure detection (pmaf.h, PMAF_HEALTH_*): a NaN / infinite set-point must not reach the controller silently --
+    // the reference's consumer only logs it (B/src/costp_controller.cpp:317-319). The individual calls of the
+    // reference's surface (moveRealEEAgent ...) keep its behaviour; getHealth() reports for them too.
+    if (throw_on_numeric_fault_ && (getHealth() & (PMAF_HEALTH_SETPOINT_NAN | PMAF_HEALTH_FORCE_NAN)))
+      throw std::runtime_error("CfManager::planTick: the real agent's set-point / force is not finite (getHealth())");
     return best;
+  }
+  // PMAF_HEALTH_* bits of the last planTick / evaluateAgents / moveRealEEAgent (no reference equivalent)
+  int getHealth() {
+    require();
+    int32_t b = 0;
+    check(pmaf_get_health(h_, &b), "getHealth");
+    return (int)b;
+  }
+  void setThrowOnNumericFault(bool on) { throw_on_numeric_fault_ = on; }
+  // The selected trajectory of every planTick / evaluateAgents on the host without the copy of all N paths
+  // getPredictedPaths() makes (what the node's visualisation marks as the best path,
+  // B/src/panda_bimanual_control.cpp:340-347): enable once, then getSelectedPath() after a tick returns the path the
+  // selection scored (pmaf_view_winner_path: written by the manager kernel into pinned memory behind the set-point).
+  void enableSelectedPath(bool on = true) {
+    require();
+    selected_path_on_ = on;
+    check(pmaf_enable_winner_path(h_, on ? 1 : 0), "enableSelectedPath");
+  }
+  std::vector<Vector3d> getSelectedPath(int *agent_index = nullptr) {
+    require();
+    const double *p = nullptr;
+    const int32_t *n = nullptr, *a = nullptr;
+    check(pmaf_view_winner_path(h_, &p, &n, &a), "getSelectedPath");
+    std::vector<Vector3d> out;
+    out.reserve((size_t)n[0]);
+    for (int k = 0; k < n[0]; ++k) out.emplace_back(p[3 * k], p[3 * k + 1], p[3 * k + 2]);
+    if (agent_index) *agent_index = a[0];
+    return out;
   }
 
   // ---- synchronous stepping API (no callers in the reference; B/src/cf_manager.cpp:220-224, 238-244, 265-291) ----

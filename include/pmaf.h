@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define PMAF_ABI_VERSION 4   /* 4: pmaf_get_tick_times_us; the state blob carries the closest-other table */
+#define PMAF_ABI_VERSION 5   /* 5: PMAF_FLAG_CONTRACTED, pmaf_get_health, the winner path in pinned memory, the tick's time limit */
 
 typedef enum pmaf_status {
   PMAF_OK = 0,
@@ -167,6 +167,35 @@ int pmaf_reset_agents(pmaf_planner *h, const double *pos, const double *vel,
 int pmaf_tick(pmaf_planner *h, const double *obstacles, double dt,
               const double *cost_gains, const double *ws, int32_t *best_idx,
               double *next_pos, double *next_vel);
+
+/* ---- failure detection on the tick (ABI 5; SURVEY.md section 5: the reference has none for the planner -- its consumer
+ * logs a NaN set-point, B/src/costp_controller.cpp:317-319) ----
+ * Time limit: pmaf_tick waits for the manager kernel's result at most PMAF_TICK_TIMEOUT_S seconds (environment, read
+ * at pmaf_create; default 5) and then fails with PMAF_ERR_DEVICE instead of spinning on a hung device; the outputs are
+ * not written in that case.
+ * Health word of the last pmaf_tick / pmaf_evaluate / pmaf_move_real per population (bits below), written by the
+ * manager kernel next to the set-point. pmaf_tick itself still returns PMAF_OK with the (NaN) set-point in its
+ * outputs -- the reference's planner publishes it too -- the caller decides (the C++ facade's planTick throws). */
+#define PMAF_HEALTH_SETPOINT_NAN 1   /* the real agent's next position / velocity is not finite */
+#define PMAF_HEALTH_FORCE_NAN 2      /* the force on the real agent is not finite (e.g. the Had heuristic's rotation vector
+                                        for an obstacle centre on the agent-goal line, B/src/cf_agent.cpp:599-611) */
+#define PMAF_HEALTH_ACC_CLAMPED 4    /* updatePositionAndVelocity's |a| <= 13 clamp acted on the real agent's step */
+#define PMAF_HEALTH_COST_NAN 8       /* no agent had a comparable cost (all NaN): index 0 was kept, as the reference does */
+int pmaf_get_health(pmaf_planner *h, int32_t *bits /* [P] */);
+
+/* ---- the selected trajectory of every tick on the host (ABI 5) ----
+ * What the reference's planCallback hands out per tick (B/src/panda_bimanual_control.cpp:340-347: the predicted paths,
+ * the best one marked) without the copy of ALL paths pmaf_view_paths makes: once enabled, the manager kernel of every
+ * pmaf_tick / pmaf_evaluate writes the SELECTED agent's path -- as it was scored -- into mapped pinned host memory
+ * right behind the set-point (24 B per path point; the rollout launched by the same tick starts behind it).
+ * pmaf_view_winner_path waits for the path of the LAST tick / evaluate and returns pointers into that memory:
+ * *paths [P][cap][3] (entries past n_points[p] are unspecified), *n_points [P], *agent [P] (0-based index); valid until
+ * the next pmaf_tick / pmaf_evaluate. Any of the three may be NULL. */
+int pmaf_enable_winner_path(pmaf_planner *h, int32_t enable);
+int pmaf_view_winner_path(pmaf_planner *h, const double **paths, const int32_t **n_points, const int32_t **agent);
+/* entry of pmaf_tick -> the winner path on the host (pmaf_view_winner_path's return), library clock, microseconds;
+ * one sample per pmaf_view_winner_path call that followed a pmaf_tick, oldest first; clears the record */
+int pmaf_get_winner_path_times_us(pmaf_planner *h, double *out, int32_t max_n, int32_t *n);
 
 /* ---- synchronous stepping API of the class surface (no callers in the reference) ----
  * CfManager::moveAgents / moveAgentsPar (B/src/cf_manager.cpp:274-291) ->
@@ -365,7 +394,12 @@ int pmaf_get_tick_times_us(pmaf_planner *h, double *enqueue_us, double *setpoint
  * No host, no stream, no collective is involved; the winner-record all-gather
  * above stays what it was (the path table, off the control path). Every rank
  * must issue the same number of pmaf_tick calls; the other entry points
- * (pmaf_evaluate ...) neither publish nor consume. Not part of a checkpoint
+ * (pmaf_evaluate ...) neither publish nor consume.
+ * TOPOLOGY: couplings must be PAIRWISE MUTUAL (population a reads b's header and b reads a's -- the dual-arm case).
+ * The two parity slots per source rest on it: a source cannot publish tick t+1 (which overwrites header t-1) before it
+ * has read the consumer's header t. A one-way coupling or a ring of three or more has no such back-pressure; the
+ * consumer detects it from the coupling the publisher writes into its header and pmaf_tick fails with PMAF_ERR_STATE
+ * (likewise when a source is found to have run ahead). Not part of a checkpoint
  * (reconnect after pmaf_load_state). No reference equivalent. */
 #define PMAF_PEER_HANDLE_BYTES 128
 /* allocate this handle's inbox for `world` ranks and export it: hand the
@@ -396,6 +430,11 @@ int pmaf_peer_read(pmaf_planner *h, double *headers, double *seq);
  * publish_us = its stores into the peers' inboxes incl. the system-scope fence
  * (device clock) */
 int pmaf_get_peer_times_us(pmaf_planner *h, double *wait_us, double *publish_us, int32_t max_n, int32_t *n);
+/* what the connection rests on: *fine_grained = 1 if this handle's inbox is fine-grained device memory (stores of
+ * another GPU become visible to a running kernel), 0 if the runtime could only export plain device memory -- then
+ * pmaf_peer_connect refuses peers on ANOTHER device (PMAF_ERR_DEVICE) and only same-device peers (several processes on
+ * one GPU) can be connected. Either pointer may be NULL. */
+int pmaf_peer_info(pmaf_planner *h, int32_t *fine_grained, int32_t *world);
 /* hipGetDeviceCount (0 without a usable HIP device) */
 int pmaf_device_count(void);
 
@@ -425,6 +464,9 @@ int pmaf_get_launch_config(pmaf_planner *h, int32_t *lanes_per_agent,
  * kernel's own assembly with delay instructions inserted); NULL path = back to the built-in kernels. Wave-per-agent
  * handles only. */
 int pmaf_debug_external_rollout(pmaf_planner *h, const char *code_object_path, const char *kernel_name);
+/* Fault injection for the tick's time limit (tests): while enabled, the manager kernel of pmaf_tick does not publish
+ * its sequence number, so the host's wait can only end by the time limit (or by the stream running empty). */
+int pmaf_debug_withhold_mailbox(pmaf_planner *h, int32_t enable);
 
 /* Self-test of the device arithmetic the parity argument rests on: evaluates
  * op over n elements ON THE GPU (0: a/b, 1: sqrt(a), 2: the kernels' portable exp(a), 3: a*b,

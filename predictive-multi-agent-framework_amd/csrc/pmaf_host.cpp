@@ -68,6 +68,16 @@ struct pmaf_planner {
   hipStream_t stream = nullptr;
   hipEvent_t ev_mgr = nullptr;
   uint64_t mailbox_seq = 0;     // sequence number of the last pmaf_tick (mailbox entry 11)
+  double tick_timeout_s = 5.0;  // PMAF_TICK_TIMEOUT_S: bound of pmaf_tick's wait for the manager kernel's result
+  bool dbg_withhold = false;    // pmaf_debug_withhold_mailbox: the sequence number is not published (fault injection)
+  // winner path in mapped pinned memory (pmaf_enable_winner_path): [P][cap][3] + header [P][4] = n_points, agent, 0, seq
+  double *h_wp = nullptr, *d_wp = nullptr, *h_wph = nullptr, *d_wph = nullptr;
+  std::vector<int32_t> wp_np, wp_agent;
+  double wp_seq = 0.0;          // sequence number the last selection published its path under (0: none yet)
+  double wp_counter = 0.0;      // sequence numbers of the selections that are not pmaf_ticks (pmaf_evaluate): negative
+  std::chrono::steady_clock::time_point last_tick_entry{};
+  bool wp_timed = true;         // the last pmaf_tick's path latency has been booked (or there was no tick)
+  std::vector<double> wp_us;
   // DevView::closest_idx: k_manager recomputes the table at the next reset when the caller has handed over a live
   // obstacle list that DIFFERS (bit for bit) from the previous one -- a node that passes the same static list every tick
   // pays for the table once
@@ -86,10 +96,11 @@ struct pmaf_planner {
     closest_dirty = true;
   }
   // the kernels that read the table: the wave-per-agent kernels with several obstacle slots per lane (launch_rollout)
+  // (an external kernel -- pmaf_debug_external_rollout -- is the product kernel's own code and reads the table too)
   bool uses_closest_table() const {
     const int M = D.n_obs - 1;
     const int tiles64 = (M >= 62 && M <= 64) ? 2 : (M + 63) / 64;
-    return lpa == 64 && tiles64 >= 2 && tiles64 <= 4 && !force_generic && !ext_fn;
+    return lpa == 64 && tiles64 >= 2 && tiles64 <= 4 && !force_generic;
   }
   // host-side clock of the last pmaf_tick calls (pmaf_get_tick_times_us): entry -> both launches enqueued, entry ->
   // set-point on the host; a ring of the newest TICK_RING calls
@@ -438,7 +449,12 @@ static void refresh_real_cache(pmaf_planner *h) {
 // Spin until k_manager has published sequence number `seq` for every
 // population. The stream is queried now and then so that a failed or finished
 // launch cannot leave the host spinning.
+// Bounded in wall-clock time (round 4): a hung or wedged GPU must not hang a 100 Hz control loop at 100 % CPU -- after
+// PMAF_TICK_TIMEOUT_S (default 5 s) the call fails with PMAF_ERR_DEVICE (the clock is only read every 2^14 spins / on
+// every poll of the blocking variant).
 static void wait_mailbox(pmaf_planner *h, double seq) {
+  std::chrono::steady_clock::time_point t_start{};
+  bool timing = false;
   for (int p = 0; p < h->D.P; p++) {
     const volatile double *s = h->h_out + p * PMAF_MBOX + 11;
     unsigned spins = 0;
@@ -456,6 +472,11 @@ static void wait_mailbox(pmaf_planner *h, double seq) {
 #endif
       }
       if ((++spins & 0x3fffu) == 0 || (h->blocking_wait && (spins & 0x3fffu) < 0x400)) {
+        const auto now = std::chrono::steady_clock::now();
+        if (!timing) { timing = true; t_start = now; }
+        else if (std::chrono::duration<double>(now - t_start).count() > h->tick_timeout_s)
+          fail(PMAF_ERR_DEVICE, "pmaf_tick: no result from the manager kernel within the time limit (PMAF_TICK_TIMEOUT_S): "
+                                "device hung, or the previous rollout still running");
         hipError_t e = hipStreamQuery(h->stream);
         if (e == hipErrorNotReady) continue;
         if (e != hipSuccess) throw HipError{e, "hipStreamQuery (mailbox wait)", __LINE__};
@@ -607,10 +628,18 @@ struct PeerHandleBlob {   // what pmaf_peer_export hands out (PMAF_PEER_HANDLE_B
   uint64_t magic;
   int64_t pid;
   uint64_t ptr;           // the inbox in the exporting process (used when the importer IS that process)
-  int32_t world, P, device, pad;
+  int32_t world, P, device, fine;   // fine: the inbox is fine-grained device memory
   hipIpcMemHandle_t ipc;
-  unsigned char fill[PMAF_PEER_HANDLE_BYTES - 40 - sizeof(hipIpcMemHandle_t)];
+  int32_t pci[3];                   // PCI domain / bus / device of the exporting GPU (ordinals differ between processes)
+  unsigned char fill[PMAF_PEER_HANDLE_BYTES - 40 - sizeof(hipIpcMemHandle_t) - 12];
 };
+static void pci_id_of(int device, int32_t out[3]) {
+  int v = 0;
+  out[0] = (hipDeviceGetAttribute(&v, hipDeviceAttributePciDomainID, device) == hipSuccess) ? v : -1;
+  out[1] = (hipDeviceGetAttribute(&v, hipDeviceAttributePciBusId, device) == hipSuccess) ? v : -1;
+  out[2] = (hipDeviceGetAttribute(&v, hipDeviceAttributePciDeviceId, device) == hipSuccess) ? v : -1;
+  (void)hipGetLastError();
+}
 static_assert(sizeof(PeerHandleBlob) == PMAF_PEER_HANDLE_BYTES, "pmaf.h: PMAF_PEER_HANDLE_BYTES");
 static const uint64_t kPeerMagic = 0x504d41465f505231ull;  // "PMAF_PR1"
 
@@ -618,15 +647,16 @@ static size_t peer_inbox_doubles(int world, int P) { return (size_t)2 * world * 
 
 // after the mailbox of a tick has arrived: the wait for the coupled header / the publish time of this tick's manager
 // kernel, and whether a header it waited for never came
-static bool peer_book_tick(pmaf_planner *h) {
+// returns the worst peer status of the tick: 0 ok, 1 time-out, 2 the source ran ahead, 3 coupling not mutual
+static int peer_book_tick(pmaf_planner *h) {
   pmaf_planner::Peer &pr = h->peer;
   double w = 0.0, pb = 0.0;
-  bool late = false;
+  int late = 0;
   for (int p = 0; p < h->D.P; p++) {
     const double *o = h->h_out + p * PMAF_MBOX;
     w = std::max(w, o[12]);
     pb = std::max(pb, o[13]);
-    late = late || o[14] != 0.0;
+    late = std::max(late, (int)o[14]);
   }
   pr.wait_us.push_back(w * pr.us_per_tick);
   pr.pub_us.push_back(pb * pr.us_per_tick);
@@ -727,6 +757,7 @@ int pmaf_create(const pmaf_params *prm, pmaf_planner **out) {
     { const char *fg = getenv("PMAF_FORCE_GENERIC"); h->force_generic = fg && fg[0] == '1'; }
     { const char *ab = getenv("PMAF_ABLATE"); D.ablate = ab ? atoi(ab) : 0; }
     { const char *to = getenv("PMAF_EXCHANGE_TIMEOUT_S"); if (to && atof(to) > 0.0) h->exchange_timeout_s = atof(to); }
+    { const char *to = getenv("PMAF_TICK_TIMEOUT_S"); if (to && atof(to) > 0.0) h->tick_timeout_s = atof(to); }
     // ordered force sum: the DPP chain for every obstacle count (round 3: with the first chunk's accumulates fused and
     // interleaved with the scaling chain it also wins for short lists -- C1, nine obstacles: 121.3 -> 111.8 us; rounds 1-2
     // switched to LDS batches below 21 obstacles). PMAF_SUM=lds selects the LDS-batch kernels (tests, timing).
@@ -902,6 +933,8 @@ int pmaf_destroy(pmaf_planner *h) {
   for (void *p : h->scratch) (void)hipFree(p);
   if (h->h_out) (void)hipHostFree(h->h_out);
   if (h->h_zc) (void)hipHostFree(h->h_zc);
+  if (h->h_wp) (void)hipHostFree(h->h_wp);
+  if (h->h_wph) (void)hipHostFree(h->h_wph);
   if (h->h_paths) (void)hipHostFree(h->h_paths);
   if (h->h_np) (void)hipHostFree(h->h_np);
   if (h->d_link) (void)hipFree(h->d_link);
@@ -1000,6 +1033,12 @@ int pmaf_evaluate(pmaf_planner *h, const double *cost_gains, const double *ws, i
       A.winner_hdr = claim_exchange_slot(h).d_send;  // (its exchange of two selections ago is through)
       A.winner_stride = (int)winner_rec(h);
     }
+    if (h->h_wp) {   // the winner path of this selection (sequence numbers of non-tick selections count down from -1)
+      A.wp_out = h->d_wp; A.wp_hdr = h->d_wph;
+      A.seq = (h->wp_counter -= 1.0);
+      h->wp_seq = A.seq;
+      h->wp_timed = true;
+    }
     launch_manager(h, A);
     HIP_CHECK(hipStreamSynchronize(h->stream));
     if (h->x.c) begin_exchange(h, h->D.paths);
@@ -1075,7 +1114,9 @@ int pmaf_tick(pmaf_planner *h, const double *obstacles, double dt, const double 
     A.rollout_follows = 1;
     A.dt_real = dt;
     A.out = h->d_out;
-    A.seq = (double)(++h->mailbox_seq);
+    const double want_seq = (double)(++h->mailbox_seq);
+    A.seq = h->dbg_withhold ? 0.0 : want_seq;   // (fault injection: pmaf_debug_withhold_mailbox)
+    if (h->h_wp) { A.wp_out = h->d_wp; A.wp_hdr = h->d_wph; h->wp_seq = A.seq; h->wp_timed = false; h->last_tick_entry = t_entry; }
     if (h->x.c) {
       // the send buffer of the exchange two ticks back (long through); the previous tick's collective is NOT waited for
       A.winner_hdr = claim_exchange_slot(h).d_send;
@@ -1094,7 +1135,7 @@ int pmaf_tick(pmaf_planner *h, const double *obstacles, double dt, const double 
     // outputs of k_manager land in mapped pinned memory; wait for them only
     // (no event between the two launches: the host polls the sequence number -- spinning, or with
     // PMAF_FLAG_BLOCKING_WAIT sleeping between polls)
-    wait_mailbox(h, A.seq);
+    wait_mailbox(h, want_seq);
     {
       const auto t_sp = std::chrono::steady_clock::now();
       if (h->tick_enq_us.empty()) { h->tick_enq_us.resize(pmaf_planner::TICK_RING); h->tick_sp_us.resize(pmaf_planner::TICK_RING); }
@@ -1103,7 +1144,7 @@ int pmaf_tick(pmaf_planner *h, const double *obstacles, double dt, const double 
       h->tick_head = (h->tick_head + 1) % pmaf_planner::TICK_RING;
       if (h->tick_count < pmaf_planner::TICK_RING) h->tick_count++;
     }
-    const bool peer_late = h->peer.on && peer_book_tick(h);
+    const int peer_late = h->peer.on ? peer_book_tick(h) : 0;
     if (h->x.c) begin_exchange(h, scored);  // pack + all-gather on the exchange stream, beside the rollout
     refresh_real_cache(h);
     append_real_path(h);
@@ -1113,9 +1154,16 @@ int pmaf_tick(pmaf_planner *h, const double *obstacles, double dt, const double 
       if (next_pos) { next_pos[p * 3] = o[1]; next_pos[p * 3 + 1] = o[2]; next_pos[p * 3 + 2] = o[3]; }
       if (next_vel) { next_vel[p * 3] = o[4]; next_vel[p * 3 + 1] = o[5]; next_vel[p * 3 + 2] = o[6]; }
     }
-    if (peer_late)
+    if (peer_late == 1)
       fail(PMAF_ERR_DEVICE, "pmaf_tick: the header of a coupled peer population did not arrive in time (a peer rank behind "
                             "by more than PMAF_PEER_TIMEOUT_S, or gone); the trailing obstacle kept its previous value");
+    if (peer_late == 2)
+      fail(PMAF_ERR_STATE, "pmaf_tick: a coupled peer population had already overwritten the header this tick needs (it ran "
+                           "ahead): couplings must be pairwise mutual and every rank must issue the same pmaf_tick calls "
+                           "(include/pmaf.h, peer mailboxes: TOPOLOGY); the trailing obstacle kept its previous value");
+    if (peer_late == 3)
+      fail(PMAF_ERR_STATE, "pmaf_tick: a coupled peer population is not coupled back to this one -- couplings must be "
+                           "pairwise mutual (include/pmaf.h, peer mailboxes: TOPOLOGY)");
   });
 }
 
@@ -1616,6 +1664,7 @@ int pmaf_peer_export(pmaf_planner *h, int32_t world, void *handle_out) {
     PeerHandleBlob b{};
     b.magic = kPeerMagic; b.pid = (int64_t)getpid(); b.ptr = (uint64_t)(uintptr_t)pr.inbox;
     b.world = world; b.P = h->D.P; b.device = h->device;
+    pci_id_of(h->device, b.pci);
     if (world > 1) {
       e = hipIpcGetMemHandle(&b.ipc, pr.inbox);
       if (e != hipSuccess && pr.inbox_fine) {   // this runtime does not export fine-grained memory: plain device memory
@@ -1630,6 +1679,7 @@ int pmaf_peer_export(pmaf_planner *h, int32_t world, void *handle_out) {
       }
       if (e != hipSuccess) throw HipError{e, "hipIpcGetMemHandle (peer inbox)", __LINE__};
     }
+    b.fine = pr.inbox_fine ? 1 : 0;   // (pmaf_peer_connect refuses cross-device peers of a plain-memory inbox)
     std::memcpy(handle_out, &b, sizeof(b));
   });
 }
@@ -1649,6 +1699,18 @@ int pmaf_peer_connect(pmaf_planner *h, int32_t world, int32_t rank, const void *
       const PeerHandleBlob &b = hb[r];
       REQUIRE(b.magic == kPeerMagic, "pmaf_peer_connect: not a handle of pmaf_peer_export");
       REQUIRE(b.world == world && b.P == h->D.P, "pmaf_peer_connect: every rank must export for the same world and hold the same number of populations");
+      if (r != rank) {
+        // a peer on ANOTHER GPU stores into / is stored into over xGMI while the kernels run: both inboxes must be
+        // fine-grained memory (plain device memory does not make another agent's stores visible to a running kernel --
+        // the in-kernel poll would time out every tick with no hint of the cause)
+        int32_t mine[3];
+        pci_id_of(h->device, mine);
+        const bool same_gpu = mine[0] == b.pci[0] && mine[1] == b.pci[1] && mine[2] == b.pci[2] && mine[1] >= 0;
+        if (!same_gpu && !(pr.inbox_fine && b.fine))
+          fail(PMAF_ERR_DEVICE, "pmaf_peer_connect: a peer on another GPU needs fine-grained inboxes on both sides, and this "
+                                "runtime could only export plain device memory (pmaf_peer_info); use the winner-record "
+                                "exchange (pmaf_attach_comm) for the coupling instead");
+      }
       if (r == rank) {
         REQUIRE(b.pid == (int64_t)getpid() && b.ptr == (uint64_t)(uintptr_t)pr.inbox, "pmaf_peer_connect: handles[rank] is not this handle's own export");
         pr.mapped[r] = pr.inbox;
@@ -1713,6 +1775,7 @@ int pmaf_peer_couple(pmaf_planner *h, int32_t pop, int32_t src_rank, int32_t src
         // source's tick 2, which needs this rank's tick 1 first)
         double slot[PMAF_PEER_SLOT] = {0};
         slot[4] = init_pos[0]; slot[5] = init_pos[1]; slot[6] = init_pos[2]; slot[8] = 0.0;
+        slot[9] = slot[10] = -2.0;   // host-written header: the publisher's own coupling is not known here (k_manager's mutuality check skips it)
         HIP_CHECK(hipMemcpy(pr.inbox + (((size_t)0 * pr.world + src_rank) * h->D.P + src_pop) * PMAF_PEER_SLOT, slot,
                             sizeof(slot), hipMemcpyHostToDevice));
       }
@@ -1766,6 +1829,103 @@ int pmaf_get_peer_times_us(pmaf_planner *h, double *wait_us, double *publish_us,
     *n = (int32_t)k;
     pr.wait_us.clear();
     pr.pub_us.clear();
+  });
+}
+
+int pmaf_peer_info(pmaf_planner *h, int32_t *fine_grained, int32_t *world) {
+  return guarded([&] {
+    REQUIRE(h, "pmaf_peer_info: NULL handle");
+    if (!h->peer.inbox) fail(PMAF_ERR_STATE, "pmaf_peer_info: no inbox (pmaf_peer_export)");
+    if (fine_grained) *fine_grained = h->peer.inbox_fine ? 1 : 0;
+    if (world) *world = h->peer.world;
+  });
+}
+
+// ---- failure detection / winner path (ABI 5) ----
+int pmaf_get_health(pmaf_planner *h, int32_t *bits) {
+  return guarded([&] {
+    REQUIRE(h && bits, "pmaf_get_health: NULL argument");
+    for (int p = 0; p < h->D.P; p++) bits[p] = (int32_t)h->h_out[p * PMAF_MBOX + 15];   // (mailbox: host memory)
+  });
+}
+
+int pmaf_debug_withhold_mailbox(pmaf_planner *h, int32_t enable) {
+  return guarded([&] {
+    REQUIRE(h, "pmaf_debug_withhold_mailbox: NULL handle");
+    h->dbg_withhold = enable != 0;
+  });
+}
+
+int pmaf_enable_winner_path(pmaf_planner *h, int32_t enable) {
+  return guarded([&] {
+    REQUIRE(h, "pmaf_enable_winner_path: NULL handle");
+    h->use_device();
+    sync(h);
+    if (!enable) {
+      if (h->h_wp) { (void)hipHostFree(h->h_wp); h->h_wp = nullptr; h->d_wp = nullptr; }
+      if (h->h_wph) { (void)hipHostFree(h->h_wph); h->h_wph = nullptr; h->d_wph = nullptr; }
+      h->wp_seq = 0.0;
+      return;
+    }
+    if (h->h_wp) return;
+    const size_t P = (size_t)h->D.P;
+    HIP_CHECK(hipHostMalloc((void **)&h->h_wp, sizeof(double) * P * h->D.cap * 3, hipHostMallocMapped));
+    HIP_CHECK(hipHostGetDevicePointer((void **)&h->d_wp, h->h_wp, 0));
+    HIP_CHECK(hipHostMalloc((void **)&h->h_wph, sizeof(double) * P * 4, hipHostMallocMapped));
+    HIP_CHECK(hipHostGetDevicePointer((void **)&h->d_wph, h->h_wph, 0));
+    std::memset(h->h_wp, 0, sizeof(double) * P * h->D.cap * 3);
+    std::memset(h->h_wph, 0, sizeof(double) * P * 4);
+    h->wp_np.assign(P, 0);
+    h->wp_agent.assign(P, 0);
+    h->wp_seq = 0.0;
+    h->wp_timed = true;
+  });
+}
+
+int pmaf_view_winner_path(pmaf_planner *h, const double **paths, const int32_t **n_points, const int32_t **agent) {
+  return guarded([&] {
+    REQUIRE(h, "pmaf_view_winner_path: NULL handle");
+    if (!h->h_wp) fail(PMAF_ERR_STATE, "pmaf_view_winner_path: not enabled (pmaf_enable_winner_path)");
+    if (h->wp_seq == 0.0) fail(PMAF_ERR_STATE, "pmaf_view_winner_path: no selection yet (pmaf_tick / pmaf_evaluate), or the last "
+                                               "tick's sequence number was withheld");
+    // the path follows the set-point within microseconds (same kernel); bounded like the tick's own wait
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int p = 0; p < h->D.P; p++) {
+      const volatile double *s = h->h_wph + p * 4 + 3;
+      unsigned spins = 0;
+      while (*s != h->wp_seq) {
+#if defined(__x86_64__) || defined(__i386__)
+        __builtin_ia32_pause();
+#endif
+        if ((++spins & 0x3fffu) == 0 &&
+            std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > h->tick_timeout_s)
+          fail(PMAF_ERR_DEVICE, "pmaf_view_winner_path: the path did not arrive within the time limit (PMAF_TICK_TIMEOUT_S)");
+      }
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    if (!h->wp_timed) {
+      h->wp_us.push_back(std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - h->last_tick_entry).count());
+      if (h->wp_us.size() > (1u << 20)) h->wp_us.erase(h->wp_us.begin(), h->wp_us.begin() + (1u << 19));
+      h->wp_timed = true;
+    }
+    for (int p = 0; p < h->D.P; p++) {
+      h->wp_np[p] = (int32_t)h->h_wph[p * 4];
+      h->wp_agent[p] = (int32_t)h->h_wph[p * 4 + 1];
+    }
+    if (paths) *paths = h->h_wp;
+    if (n_points) *n_points = h->wp_np.data();
+    if (agent) *agent = h->wp_agent.data();
+  });
+}
+
+int pmaf_get_winner_path_times_us(pmaf_planner *h, double *out, int32_t max_n, int32_t *n) {
+  return guarded([&] {
+    REQUIRE(h && n, "pmaf_get_winner_path_times_us: NULL argument");
+    std::vector<double> &v = h->wp_us;
+    const size_t k = (out && max_n > 0) ? std::min(v.size(), (size_t)max_n) : 0;
+    for (size_t i = 0; i < k; i++) out[i] = v[i];
+    *n = (int32_t)k;
+    v.clear();
   });
 }
 

@@ -168,7 +168,7 @@ __device__ __forceinline__ void real_step_w64(const DevView &D, const double dt_
                                               double *rot_g, const double *rand_g, double *clist, const double k_attr,
                                               const double k_circ, const double k_repel, const double k_damp,
                                               const V3 goal, const V3 init_pos, V3 &rp, V3 &rv, V3 &F_total,
-                                              unsigned &known_bits) {
+                                              unsigned &known_bits, bool &acc_clamped) {
   typedef Mth<MATH_XACT> MT;
   PopConst C = D.C;
   C.dt = dt_real;
@@ -209,6 +209,7 @@ __device__ __forceinline__ void real_step_w64(const DevView &D, const double dt_
   V3 acc = F;
   if (C.mass != 1.0) acc = F / C.mass;
   const double az = sqn(acc);
+  acc_clamped = az >= C.zacc_gt;
   if (az >= C.zacc_gt) acc = acc * (13.0 / __builtin_sqrt(az));
   const V3 half = ((0.5 * acc) * C.dt) * C.dt;
   const V3 new_pos = (rp + half) + (rv * C.dt);
@@ -291,11 +292,25 @@ __global__ __launch_bounds__(64) void k_manager(DevView D, CostParams CP, Manage
       const double *slot = PV->inbox + ((((size_t)((long long)want & 1) * PV->world + src_rank) * PV->P + src_pop) * PMAF_PEER_SLOT);
       const unsigned long long t0 = wall_clock64();
       // every lane polls the same address (one broadcast load); system scope: the writer is another agent
-      while (__hip_atomic_load(slot + 8, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != want) {
+      for (;;) {
+        const double got = __hip_atomic_load(slot + 8, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (got == want) break;
+        // the slot already holds a NEWER header of the same parity: the source ran ahead and overwrote the one this
+        // tick needs. With pairwise mutual couplings that cannot happen (the source's tick t+1 needs THIS rank's header
+        // t first); one-way couplings and rings have no such back-pressure and are rejected (status 3 below, once the
+        // source's first kernel-written header is seen) -- reported at once instead of after the time-out
+        if (got > want) { peer_status = 2; break; }
         if (wall_clock64() - t0 > PV->timeout_ticks) { peer_status = 1; break; }
         __builtin_amdgcn_s_sleep(2);
       }
       peer_wait = wall_clock64() - t0;
+      if (peer_status == 0) {
+        // the publisher's own coupling rides in the header (slot[9], [10]; -2 in a host-written initial header): it must
+        // point back at this population
+        const double br = __hip_atomic_load(slot + 9, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        const double bp = __hip_atomic_load(slot + 10, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (br != -2.0 && !(br == (double)PV->rank && bp == (double)pop)) peer_status = 3;
+      }
       const double sx = __hip_atomic_load(slot + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       const double sy = __hip_atomic_load(slot + 5, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       const double sz = __hip_atomic_load(slot + 6, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -309,6 +324,7 @@ __global__ __launch_bounds__(64) void k_manager(DevView D, CostParams CP, Manage
       }
     }
   }
+  int health = 0;   // PMAF_HB_* bits of this tick (mailbox entry 15; wave-uniform)
   // random vectors the real agent's heuristic uses (best_agent_'s copy)
   const double *rand_g = D.best_rnd + (size_t)pop * 3 * n_obs;
   PMAF_MSEC();   // 1: up-front loads, live obstacles in LDS
@@ -332,6 +348,9 @@ __global__ __launch_bounds__(64) void k_manager(DevView D, CostParams CP, Manage
     }
     group_argmin<64>(lmin, lidx);
     int min_idx = (lidx == 0x7fffffff) ? 0 : lidx;
+    // no agent with a comparable cost (every cost NaN -- e.g. a NaN goal distance): the reference's argmin then keeps
+    // index 0 (B/src/cf_manager.cpp:336-343); reported
+    if (lidx == 0x7fffffff) health |= PMAF_HB_COST_NAN;
     wave_lds_fence();  // costs visible to the whole wave
     // hysteresis, :344-353
     bool take;
@@ -369,19 +388,20 @@ __global__ __launch_bounds__(64) void k_manager(DevView D, CostParams CP, Manage
     const int ntiles = (M + 63) / 64;
     unsigned long long kb = 0ull;
     V3 F = mk(0.0, 0.0, 0.0);
+    bool acc_clamped = false;
     if (A.tuned_real_step && ntiles <= 4) {
       double *rrot = D.real_rot + (size_t)pop * 3 * n_obs;
       double *clist = s_cost + N + (N & 1);
       unsigned kb32 = 0u;
       if (ntiles <= 1)
         real_step_w64<1>(D, A.dt_real, pop, lane, htype, smem, s_known, rrot, rand_g, clist, k_attr, k_circ, k_repel,
-                         k_damp, goal, init_pos, rp, rv, F, kb32);
+                         k_damp, goal, init_pos, rp, rv, F, kb32, acc_clamped);
       else if (ntiles == 2)
         real_step_w64<2>(D, A.dt_real, pop, lane, htype, smem, s_known, rrot, rand_g, clist, k_attr, k_circ, k_repel,
-                         k_damp, goal, init_pos, rp, rv, F, kb32);
+                         k_damp, goal, init_pos, rp, rv, F, kb32, acc_clamped);
       else
         real_step_w64<4>(D, A.dt_real, pop, lane, htype, smem, s_known, rrot, rand_g, clist, k_attr, k_circ, k_repel,
-                         k_damp, goal, init_pos, rp, rv, F, kb32);
+                         k_damp, goal, init_pos, rp, rv, F, kb32, acc_clamped);
       kb = kb32;
     } else {
       for (int t = 0; t < ntiles; t++) {
@@ -397,7 +417,10 @@ __global__ __launch_bounds__(64) void k_manager(DevView D, CostParams CP, Manage
       V3 new_pos;
       finish_step(rp, rv, g, F, scale, C, k_attr, k_repel, k_damp, A.dt_real, T.pos(n_obs - 1), T.r[n_obs - 1], new_pos);
       rp = new_pos;
+      // (F now holds the total force; the clamp test of updatePositionAndVelocity :255-257 on it)
+      acc_clamped = norm((C.mass != 1.0) ? (F / C.mass) : F) > 13.0;
     }
+    if (acc_clamped) health |= PMAF_HB_ACC_CLAMPED;
     rf = F;
     for (int t = 0; t < ntiles; t++) {
       int i = t * 64 + lane;
@@ -445,6 +468,9 @@ __global__ __launch_bounds__(64) void k_manager(DevView D, CostParams CP, Manage
       peer_slot = PV->peer[lane] + ((((size_t)((long long)A.peer_tick & 1) * PV->world + PV->rank) * PV->P + pop) * PMAF_PEER_SLOT);
 #pragma unroll
       for (int c = 0; c < PMAF_WINNER_HDR; c++) __hip_atomic_store(peer_slot + c, hv[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      // this population's own coupling, for the consumer's mutuality check above
+      __hip_atomic_store(peer_slot + 9, (double)PV->couple[pop * 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(peer_slot + 10, (double)PV->couple[pop * 2 + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
 
@@ -459,6 +485,15 @@ __global__ __launch_bounds__(64) void k_manager(DevView D, CostParams CP, Manage
       o[8] = rf.x; o[9] = rf.y; o[10] = rf.z;
       o[12] = (double)peer_wait;
       o[14] = (double)peer_status;
+      // health of this tick: a NaN / infinite set-point (the reference's consumer only logs it, B/src/costp_controller.cpp:317-319),
+      // a non-finite force on the real agent (Had's rotation vector is NaN by construction on the goal line,
+      // B/src/cf_agent.cpp:599-611), the acceleration clamp hit, no comparable cost
+      const double spsum = ((rp.x + rp.y) + rp.z) + ((rv.x + rv.y) + rv.z);
+      const double fsum = (rf.x + rf.y) + rf.z;
+      int hb = health;
+      if (!(fabs(spsum) <= 1.7976931348623157e308)) hb |= PMAF_HB_SETPOINT_NAN;
+      if (!(fabs(fsum) <= 1.7976931348623157e308)) hb |= PMAF_HB_FORCE_NAN;
+      o[15] = (double)hb;
     }
     if (A.seq != 0.0 || peer_on) {
       __threadfence_system();  // entries 0..10 visible to the host (and the peers' headers to them) before the sequence numbers
@@ -472,6 +507,20 @@ __global__ __launch_bounds__(64) void k_manager(DevView D, CostParams CP, Manage
   }
 
   PMAF_MSEC();   // 4: published (mailbox, fence)
+  // winner path (pmaf_enable_winner_path): the selected agent's path AS IT WAS SCORED, into mapped pinned host memory,
+  // behind the set-point (which the caller waits for first) and before the rollout launched next overwrites the buffer
+  // (stream order). 24 B per point over PCIe; its own sequence word last, behind a system-scope fence.
+  if (A.wp_out && A.do_select) {
+    const size_t pb = (size_t)pop * N + best;
+    const int n3 = D.n_points[pb] * 3;
+    const double *src = D.paths + pb * (size_t)D.cap * 3;
+    double *dst = A.wp_out + (size_t)pop * D.cap * 3;
+    for (int i = lane; i < n3; i += 64) dst[i] = src[i];
+    double *wh = A.wp_hdr + pop * 4;
+    if (lane == 0) { wh[0] = (double)(n3 / 3); wh[1] = (double)best; wh[2] = 0.0; }
+    __threadfence_system();
+    if (lane == 0) *reinterpret_cast<volatile double *>(wh + 3) = A.seq;
+  }
   if (A.do_reset) {
     // resetEEAgents, B/src/cf_manager.cpp:246-255
     V3 sp, sv;

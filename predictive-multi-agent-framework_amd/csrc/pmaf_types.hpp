@@ -9,8 +9,14 @@
 #define PMAF_WINNER_HDR 8
 // doubles per population in the host-visible mailbox k_manager writes (ManagerArgs::out)
 #define PMAF_MBOX 16
-// peer mailboxes (include/pmaf.h "peer mailboxes"): doubles per header slot (header[8], sequence number, padding
-// to one 128-byte line) and the largest world
+// health bits of a tick (mailbox entry 15; include/pmaf.h: PMAF_HEALTH_*)
+#define PMAF_HB_SETPOINT_NAN 1
+#define PMAF_HB_FORCE_NAN 2
+#define PMAF_HB_ACC_CLAMPED 4
+#define PMAF_HB_COST_NAN 8
+// peer mailboxes (include/pmaf.h "peer mailboxes"): doubles per header slot (header[8], sequence number, the
+// publisher's own coupling [9] = source rank, [10] = source population (-1: uncoupled; -2: unknown, a host-written
+// initial header), padding to one 128-byte line) and the largest world
 #define PMAF_PEER_SLOT 16
 #define PMAF_PEER_MAX_WORLD 64
 
@@ -120,7 +126,9 @@ struct ManagerArgs {
   const double *reset_in;  // [P][6] pos, vel
   double *out;             // [P][PMAF_MBOX] host-visible: best_idx, next_pos[3], next_vel[3], dist_from_goal, force[3],
                            // seq; [12] wait for the coupled peer header, [13] peer publish (both wall_clock64
-                           // ticks), [14] peer status (0 ok, 1 the awaited header did not arrive in time)
+                           // ticks), [14] peer status (0 ok, 1 the awaited header did not arrive in time, 2 the source
+                           // had already overwritten it -- it ran ahead, 3 the source is not coupled back to this
+                           // population: couplings must be pairwise mutual), [15] health bits (PMAF_HB_*)
   double seq;              // written to out[11] after the other entries are visible to the host (0: not written)
   const PeerView *peer;    // peer mailboxes (device memory), NULL: none; used by launches with select+move+reset
   double peer_tick;        // t: sequence number this launch publishes (it consumes t - 1)
@@ -128,6 +136,11 @@ struct ManagerArgs {
   int winner_stride;       // written after a selection: {cost, idx, n_points, type, next_pos[3], goal_dist}; NULL: none
   int compute_closest;     // with do_reset: the live obstacles changed since the closest-other table was last computed
                            // (set by launch_manager from the handle's dirty flag)
+  // winner path (pmaf_enable_winner_path): after the set-point has been published, the selected agent's SCORED path
+  // goes into mapped pinned host memory -- wp_out [P][cap][3], wp_hdr [P][4] = {n_points, agent index, 0, sequence
+  // number (= seq, written last behind a system-scope fence)}; NULL: off
+  double *wp_out;
+  double *wp_hdr;
 };
 
 // synchronous stepping (CfAgent::cfPlanner, B/src/cf_agent.cpp:278-300): k_plan_steps

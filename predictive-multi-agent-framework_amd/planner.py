@@ -108,6 +108,12 @@ SYMBOLS = {
     "pmaf_get_launch_config": (C.c_int, [_V, _ip, _ip, _ip]),
     "pmaf_debug_math": (C.c_int, [C.c_int32, C.c_int32, _dp, _dp, _dp]),
     "pmaf_debug_external_rollout": (C.c_int, [_V, C.c_char_p, C.c_char_p]),
+    "pmaf_get_health": (C.c_int, [_V, _ip]),
+    "pmaf_enable_winner_path": (C.c_int, [_V, C.c_int32]),
+    "pmaf_view_winner_path": (C.c_int, [_V, C.POINTER(_dp), C.POINTER(_ip), C.POINTER(_ip)]),
+    "pmaf_get_winner_path_times_us": (C.c_int, [_V, _dp, C.c_int32, _ip]),
+    "pmaf_debug_withhold_mailbox": (C.c_int, [_V, C.c_int32]),
+    "pmaf_peer_info": (C.c_int, [_V, _ip, _ip]),
 }
 
 
@@ -439,6 +445,47 @@ class PmafPlanner:
         n = C.c_int32(0)
         self._chk(self.L.pmaf_get_tick_times_us(self._h, _p(enq), _p(sp), max_n, C.byref(n)))
         return enq[:n.value].copy(), sp[:n.value].copy()
+
+    # -- failure detection / the selected trajectory on the host (ABI 5) --
+    HEALTH_SETPOINT_NAN, HEALTH_FORCE_NAN, HEALTH_ACC_CLAMPED, HEALTH_COST_NAN = 1, 2, 4, 8
+
+    def health(self):
+        """PMAF_HEALTH_* bits of the last tick / evaluate / move_real, per population"""
+        b = np.zeros(self.P, dtype=np.int32)
+        self._chk(self.L.pmaf_get_health(self._h, _pi(b)))
+        return self._sq(b)
+
+    def enable_winner_path(self, enable=True):
+        self._chk(self.L.pmaf_enable_winner_path(self._h, 1 if enable else 0))
+
+    def winner_path(self):
+        """(paths, n_points, agent) of the last selection: a list of P arrays [n_points[p]][3] copied out of the pinned
+        buffer the manager kernel wrote (pmaf_view_winner_path)"""
+        pp, pn, pa = _dp(), _ip(), _ip()
+        self._chk(self.L.pmaf_view_winner_path(self._h, C.byref(pp), C.byref(pn), C.byref(pa)))
+        n = np.ctypeslib.as_array(pn, shape=(self.P,)).copy()
+        a = np.ctypeslib.as_array(pa, shape=(self.P,)).copy()
+        full = np.ctypeslib.as_array(pp, shape=(self.P, self.cap, 3))
+        paths = [full[p, :n[p]].copy() for p in range(self.P)]
+        return (paths[0], int(n[0]), int(a[0])) if self.P == 1 else (paths, n, a)
+
+    def winner_path_wait(self):
+        """pmaf_view_winner_path without the copies (latency measurements)"""
+        self._chk(self.L.pmaf_view_winner_path(self._h, None, None, None))
+
+    def winner_path_times_us(self, max_n=1 << 16):
+        out = np.zeros(max_n)
+        n = C.c_int32(0)
+        self._chk(self.L.pmaf_get_winner_path_times_us(self._h, _p(out), max_n, C.byref(n)))
+        return out[:n.value].copy()
+
+    def debug_withhold_mailbox(self, enable=True):
+        self._chk(self.L.pmaf_debug_withhold_mailbox(self._h, 1 if enable else 0))
+
+    def peer_info(self):
+        f, w = C.c_int32(0), C.c_int32(0)
+        self._chk(self.L.pmaf_peer_info(self._h, C.byref(f), C.byref(w)))
+        return {"fine_grained": bool(f.value), "world": w.value}
 
     # -- peer mailboxes (header-only exchange without a collective) --
     PEER_HANDLE_BYTES = 128

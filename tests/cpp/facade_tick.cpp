@@ -3,7 +3,7 @@
 // (B/src/panda_bimanual_control.cpp:463-471, 501-510, 329-369) on the static1
 // task scene and prints, per tick, best index / type and the next set-point.
 // tests/test_facade.py compares the output with the oracle.
-//   usage: facade_tick <n_agents> <max_prediction_steps> <n_ticks> <random_vecs.bin> [viz]
+//   usage: facade_tick <n_agents> <max_prediction_steps> <n_ticks> <random_vecs.bin> [viz | comm]   |   facade_tick health
 // With `viz` the node's visualize_predicted_paths loop (B/src/panda_bimanual_control.cpp:340-347: 3 N + 1
 // getPredictedPaths() calls per tick) runs in every tick and the last lines report the median tick time with and
 // without it ("V <us with viz> <us without> <path points visited>"); it also exercises the move operations.
@@ -19,7 +19,55 @@
 
 using namespace ghostplanner::cfplanner;
 
+// `health` mode (ABI 5): failure detection and the selected path through the facade. One Had-heuristic agent (the
+// reference's layout puts it first, B/src/cf_manager.cpp:70-104) flies straight at an obstacle whose centre lies on the
+// agent-goal line: at first contact the REAL agent's rotation vector is 0 / 0 (B/src/cf_agent.cpp:599-611), its force and
+// set-point turn NaN, and planTick must throw instead of handing the NaN on. Until then every planTick's selected path
+// (pmaf_view_winner_path) must be the best agent's predicted path as it was scored.
+static int health_mode() {
+  std::vector<Obstacle> obstacles = {Obstacle(Vector3d(0.0, 0.0, 0.7), Vector3d(0, 0, 0), 0.05),
+                                     Obstacle(Vector3d(100.0, 100.0, 100.0), Vector3d(0, 0, 0), 0.1)};
+  const Vector3d start(-0.6, 0.0, 0.7), goal(0.6, 0.0, 0.7);
+  Vector6d ws;
+  const double wsv[6] = {1.0, -1.0, 0.3, -0.3, 1.1, 0.2};
+  for (int i = 0; i < 6; ++i) ws(i) = wsv[i];
+  CfManager m;
+  m.setInitialPosition(start);
+  m.init(goal, 0.01, obstacles, {4.0}, {0.025}, {0.08}, {3.0}, {0.0}, {0.02}, 0.2, 0.25, 0.35, 61, 1);
+  m.setInitialPosition(start);
+  m.enableSelectedPath();
+  long checked = 0;
+  for (int t = 0; t < 400; ++t) {
+    m.stopPrediction();
+    const std::vector<std::vector<Vector3d>> scored = m.getPredictedPaths();
+    int best = -1;
+    try {
+      best = m.planTick(obstacles, 0.01, 100.0, 10.0, 0.001, 1.0, ws);
+    } catch (const std::runtime_error &e) {
+      const int hb = m.getHealth();
+      if (!(hb & PMAF_HEALTH_FORCE_NAN) || !(hb & PMAF_HEALTH_SETPOINT_NAN)) { fprintf(stderr, "throw without health bits: %d\n", hb); return 7; }
+      printf("H %d %d\nS %ld\n", t, hb, checked);
+      return 0;
+    }
+    if (m.getHealth() & (PMAF_HEALTH_FORCE_NAN | PMAF_HEALTH_SETPOINT_NAN)) { fprintf(stderr, "health bits without a throw\n"); return 8; }
+    int idx = -1;
+    const std::vector<Vector3d> sel = m.getSelectedPath(&idx);
+    bool ok = idx == best && sel.size() == scored[best].size();
+    // (bit patterns: the predicted agent meets the degenerate obstacle some ticks before the real one, its path then
+    // carries NaNs -- and must carry the same ones in both views)
+    for (size_t k = 0; ok && k < sel.size(); ++k) {
+      const double u[3] = {sel[k].x(), sel[k].y(), sel[k].z()}, w[3] = {scored[best][k].x(), scored[best][k].y(), scored[best][k].z()};
+      ok = std::memcmp(u, w, sizeof(u)) == 0;
+    }
+    if (!ok) { fprintf(stderr, "selected path mismatch at tick %d\n", t); return 6; }
+    ++checked;
+  }
+  fprintf(stderr, "the real agent never met the degenerate obstacle\n");
+  return 9;
+}
+
 int main(int argc, char **argv) {
+  if (argc > 1 && !strcmp(argv[1], "health")) return health_mode();
   if (argc < 5) return 2;
   const int N = atoi(argv[1]), cap = atoi(argv[2]), ticks = atoi(argv[3]);
   // static1 scene: 9 spheres + repulsive sentinel (values as in pmaf scenes.static1_obstacles)

@@ -216,3 +216,31 @@ def test_peer_mailbox_two_processes_ipc_one_arm_per_rank(pmaf, oracle, scenes, w
         np.testing.assert_array_equal(got[0][1][:, 0, 4:7], ref[-1])
     print("peer mailbox over hipIpc: header wait median %.2f / %.2f us (p99 %.1f / %.1f), publish median %.2f / %.2f us"
           % (got[0][2], got[1][2], got[0][3], got[1][3], got[0][4], got[1][4]))
+
+
+def test_one_way_coupling_is_rejected(pmaf, scenes):
+    """the two parity slots per source rest on PAIRWISE MUTUAL couplings (a source cannot overwrite header
+    t-1 before it has read the consumer's header t). A one-way coupling has no such back-pressure: the consumer sees, in
+    the first kernel-written header of its source, that the source is not coupled back, and pmaf_tick fails with
+    PMAF_ERR_STATE at once instead of timing out some tick later"""
+    arms = scenes.dual_arm_scenes(16, 60, 8)
+    starts = np.stack([s["start"] for s in arms])
+    hip = pmaf.PmafPlanner(arms, device=0, mgr_init_pos=starts)
+    hip.set_initial_position(starts)
+    pmaf.shard.connect_peers(hip, None, 1, 0)
+    info = hip.peer_info()
+    assert info["world"] == 1 and isinstance(info["fine_grained"], bool)
+    hip.peer_couple(0, 0, 1, 0.1, init_pos=starts[1])      # population 0 follows population 1 -- and not vice versa
+    sc = arms[0]
+    hip.tick(None, sc["dt"], sc["cost_gains"], sc["ws_limits"])          # tick 1 consumes the host-written header
+    with pytest.raises(pmaf.PmafError) as ei:
+        hip.tick(None, sc["dt"], sc["cost_gains"], sc["ws_limits"])      # tick 2: the source's own header says "uncoupled"
+    assert ei.value.code == -3 and "pairwise mutual" in str(ei.value)
+    # made mutual, the pair works (the coupling restarts from host-written headers after a reconnect)
+    hip.peer_disconnect()
+    pmaf.shard.connect_peers(hip, None, 1, 0)
+    pmaf.shard.couple_dual_arm_on_device(hip, 1, 0, np.asarray(hip.real_state()[0]))
+    for _ in range(5):
+        hip.tick(None, sc["dt"], sc["cost_gains"], sc["ws_limits"])
+    hip.peer_disconnect()
+    hip.close()

@@ -553,11 +553,13 @@ def test_bench_self_spawns_its_ranks_and_reports_every_config():
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert out["n_gpus"] == 2 and out["config"]["collective_world"] == 2
     cfgs = out["configs"]
-    assert set(cfgs) == {"C1", "C3", "C5_sharded", "C4"}
+    assert set(cfgs) == {"C1", "C3", "C5_sharded", "C4", "C2_contracted", "C3_contracted", "C5_sharded_contracted"}
+    assert all(cfgs[k]["arithmetic_policy"] == ("contracted" if k.endswith("_contracted") else "strict") for k in cfgs)
     for name, c in cfgs.items():
         assert c["rollouts_per_s"] > 0 and c["blocks"] >= 5 and c["h_eff"] == c["horizon"], name
         assert c["allgather_us"]["n"] >= 10 and c["kernel"].startswith("k_rollout")
     assert cfgs["C5_sharded"]["populations_total"] == 8 and cfgs["C5_sharded"]["populations_per_gpu"] == 4
+    assert cfgs["C2_contracted"]["kernel"] == "k_rollout_w64<1, 3, true, true>"
     hx = cfgs["C4"]["header_exchange_us"]
     assert hx["n"] >= 50 and hx["wait_median"] is not None and cfgs["C4"]["gpus_used"] == 2
     # a launcher whose world differs from --gpus is refused

@@ -542,6 +542,67 @@ def run_workload(ctx, spec, args, full):
     return rec
 
 
+# per-tick estimates (ms, one MI355X, round-4 measurements) the launch plan's time budget is computed from
+EST_TICK_MS = {"C1": 0.125, "C2": 0.245, "C3": 1.03, "C4": 0.30, "C5": 0.75}
+
+
+def build_plan(args, world):
+    """The workloads one invocation times: (headline spec, [(name, sub-configuration spec)], {name: {"skipped": why}}).
+    The same function serves N = 1 and N > 1 (SCALE's N = 1 point and the single-GPU BENCH line are the same code
+    path); what depends on the world size is only which ranks take part in C4 (two) and how C5's eight scenes are
+    dealt out (scene s on rank s mod N; skipped when 8 is not a multiple of N)."""
+    default_headline = (args.config == "C2" and not args.shard and args.populations == 1 and not args.dynamic
+                        and args.lanes_per_agent == 0)
+    head_spec = dict(config=args.config, mode="c4" if args.config == "C4" else "shard" if args.shard else "replica",
+                     populations=args.populations, dynamic=args.dynamic, total_populations=args.total_populations,
+                     lanes_per_agent=args.lanes_per_agent, exchange=not args.no_exchange, steps=args.steps,
+                     warmup=args.warmup, min_seconds=args.min_seconds, min_blocks=args.min_blocks)
+    plan, skipped = [], {}
+    if default_headline and not args.only_headline:
+        sst = args.sub_steps or min(args.steps, 50)
+        base = dict(populations=1, dynamic=False, total_populations=8, lanes_per_agent=0, exchange=True, steps=sst,
+                    warmup=min(args.warmup, 10), min_seconds=args.sub_seconds, min_blocks=max(5, args.min_blocks))
+        plan = [("C1", dict(base, config="C1", mode="replica")),
+                ("C3", dict(base, config="C3", mode="replica"))]
+        if 8 % world == 0:
+            plan.append(("C5_sharded", dict(base, config="C5", mode="shard")))
+        plan.append(("C4", dict(base, config="C4", mode="c4")))
+        # the opt-in contracted arithmetic policy (PMAF_FLAG_CONTRACTED: rcp / rsq sequences + FMA contraction; NOT
+        # bit-exact, tolerance parity where tests/test_tolerance_gpu.py says it holds) beside the strict sub-records:
+        # what the north star's 1e-5 m budget buys in kernel time. Never the headline `value`.
+        plan.append(("C2_contracted", dict(base, config="C2", mode="replica", policy="contracted")))
+        plan.append(("C3_contracted", dict(base, config="C3", mode="replica", policy="contracted")))
+        if 8 % world == 0:
+            plan.append(("C5_sharded_contracted", dict(base, config="C5", mode="shard", policy="contracted")))
+        else:
+            skipped["C5_sharded"] = {"skipped": "8 scenes do not divide over %d GPUs" % world}
+    return head_spec, plan, skipped
+
+
+def plan_budget_s(args, world):
+    """Upper estimate of the GPU-side seconds of one invocation, by construction of the plan: per workload the timed
+    blocks (at least min_blocks blocks and min_seconds), its warm-up, one barrier-bracketed sync per block and 0.5 s of
+    set-up; for the headline the 500 + 1000 idle-stream latency samples; the CPU baseline and the flop count (N = 1 /
+    rank 0 only). Interpreter start, `import torch` and the rendezvous are not in it."""
+    head, plan, _ = build_plan(args, world)
+    total, rows = 0.0, []
+    for name, sp in [("headline", head)] + plan:
+        tick = EST_TICK_MS[sp["config"]] * 1e-3
+        if sp["mode"] == "shard" and sp["config"] == "C5":   # fewer scenes per GPU: not below the one-scene launch
+            tick *= max(0.35, sp["total_populations"] / float(world) / 8.0)
+        block = sp["steps"] * tick
+        timed = max(sp["min_seconds"] + block, sp["min_blocks"] * block)
+        t = 0.5 + sp["warmup"] * tick + timed + 0.002 * max(sp["min_blocks"], timed / max(block, 1e-9))
+        if name == "headline":
+            t += 1500 * (tick + 60e-6)
+        rows.append((name, t))
+        total += t
+    if world == 1:
+        total += args.cpu_seconds * 1.6 + 2.0      # both oracle builds + the thread-count probe
+    total += 2.0 if args.flop_ticks > 0 else 0.0
+    return total, rows
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -596,42 +657,25 @@ def main():
             dist.barrier()
             dist.destroy_process_group()
         if rank == 0:
+            budget, rows = plan_budget_s(args, world)
             print(json.dumps({"dry_run": True, "n_gpus": world, "ranks": who, "devices_visible": ctx.n_devices,
+                              "plan": [n for n, _ in build_plan(args, world)[1]], "plan_skipped": sorted(build_plan(args, world)[2]),
+                              "headline": build_plan(args, world)[0],
+                              "budget_s": budget, "budget_rows": rows,
                               "transport": transport if got is not None else None,
                               "collective_world": collective_world if got is not None else None,
                               "allgather_of_ranks": got}), flush=True)
         return
-    default_headline = (args.config == "C2" and not args.shard and args.populations == 1 and not args.dynamic
-                        and args.lanes_per_agent == 0)
-    head_spec = dict(config=args.config, mode="c4" if args.config == "C4" else "shard" if args.shard else "replica",
-                     populations=args.populations, dynamic=args.dynamic, total_populations=args.total_populations,
-                     lanes_per_agent=args.lanes_per_agent, exchange=not args.no_exchange, steps=args.steps,
-                     warmup=args.warmup, min_seconds=args.min_seconds, min_blocks=args.min_blocks)
+    head_spec, plan, skipped = build_plan(args, world)
     head = run_workload(ctx, head_spec, args, full=True)
 
     subs = {}
-    if default_headline and not args.only_headline:
-        sst = args.sub_steps or min(args.steps, 50)
-        base = dict(populations=1, dynamic=False, total_populations=8, lanes_per_agent=0, exchange=True, steps=sst,
-                    warmup=min(args.warmup, 10), min_seconds=args.sub_seconds, min_blocks=max(5, args.min_blocks))
-        plan = [("C1", dict(base, config="C1", mode="replica")),
-                ("C3", dict(base, config="C3", mode="replica"))]
-        if 8 % world == 0:
-            plan.append(("C5_sharded", dict(base, config="C5", mode="shard")))
-        plan.append(("C4", dict(base, config="C4", mode="c4")))
-        # the opt-in contracted arithmetic policy (PMAF_FLAG_CONTRACTED: rcp / rsq sequences + FMA contraction; NOT
-        # bit-exact, tolerance parity where tests/test_tolerance_gpu.py says it holds) beside the strict sub-records:
-        # what the north star's 1e-5 m budget buys in kernel time. Never the headline `value`.
-        plan.append(("C2_contracted", dict(base, config="C2", mode="replica", policy="contracted")))
-        plan.append(("C3_contracted", dict(base, config="C3", mode="replica", policy="contracted")))
-        if 8 % world == 0:
-            plan.append(("C5_sharded_contracted", dict(base, config="C5", mode="shard", policy="contracted")))
-        for name, spec in plan:
-            r = run_workload(ctx, spec, args, full=False)
-            if rank == 0:
-                subs[name] = r
-        if rank == 0 and 8 % world != 0:
-            subs["C5_sharded"] = {"skipped": "8 scenes do not divide over %d GPUs" % world}
+    for name, spec in plan:
+        r = run_workload(ctx, spec, args, full=False)
+        if rank == 0:
+            subs[name] = r
+    if rank == 0:
+        subs.update(skipped)
 
     line = None
     if rank == 0:

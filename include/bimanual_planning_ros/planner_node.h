@@ -240,7 +240,7 @@ inline TaskParams loadTaskFile(const std::string &path) {
 // ---- set-point consumer contract (f4) --------------------------------------
 // CoSTPController::fillBuffer / followTrajectory accept a set-point only if it
 // is finite (B/src/costp_controller.cpp:317-319) and at least 1e-6 m away from
-// the previous one (TrajectoryBuffer, B/src/trajectory_buffer.cpp:13-64).
+// the previous one (followTrajectory nudges closer points, B/src/costp_controller.cpp:320-324).
 inline bool validateSetPoint(const Vector3d &prev, const Vector3d &next, std::string *why = nullptr) {
   for (int i = 0; i < 3; ++i)
     if (!std::isfinite(next[i])) { if (why) *why = "non-finite set-point"; return false; }

@@ -2,9 +2,9 @@
 // (SURVEY.md 8f row f4), restated ROS- and robot-free so that the head-less loop (tools/plan_task.cpp) can check
 // every set-point it emits against the consumer's real acceptance logic:
 //
-//   TrajectoryBuffer    B/src/trajectory_buffer.cpp:13-64, B/include/bimanual_planning_ros/trajectory_buffer.h:
-//                       ring of 3-vectors; the controller uses size 1 (B/src/costp_controller.cpp:25), so a second
-//                       put() before the point was taken fails.
+//   SetPointHandOver    the one-slot contract of the controller's set-point buffer (the reference's TrajectoryBuffer,
+//                       B/src/trajectory_buffer.cpp, is used with size 1: B/src/costp_controller.cpp:25): a second
+//                       set-point before the first was taken is refused.
 //   SetPointConsumer    the 3-vector half of CoSTPController (B/ = reference src/bimanual_planning_ros/):
 //                         reset            B/src/costp_controller.cpp:88-109
 //                         fillBuffer       :289-297
@@ -33,32 +33,28 @@
 namespace ghostplanner {
 namespace cfplanner {
 
-// B/src/trajectory_buffer.cpp:13-64
-class TrajectoryBuffer {
-  int size_;
-  int head_ = 0, tail_ = 0;
-  bool full_ = false;
-  std::vector<Vector3d> buf_;
-
- public:
-  explicit TrajectoryBuffer(int size) : size_(size) { buf_.resize(size); }                    // :7-10
-  Vector3d &operator[](int i) { return buf_[(tail_ + i) % size_]; }                           // :13-15
-  void clear() { head_ = tail_; full_ = false; }                                              // :17-20
-  bool empty() const { return !full_ && head_ == tail_; }                                     // :22-24
-  bool full() const { return full_; }                                                         // :30-32
-  Vector3d get() { int rv = tail_; full_ = false; tail_ = (tail_ + 1) % size_; return buf_[rv]; }  // :34-39
-  int max_size() const { return size_; }                                                      // :41-43
-  bool put(const Vector3d &p) {                                                               // :45-53
-    if (full_) return false;
-    buf_[head_] = p;
-    head_ = (head_ + 1) % size_;
-    full_ = head_ == tail_;
+// The hand-over between the "goals" subscriber and the controller cycle. The reference uses a ring buffer class
+// (B/src/trajectory_buffer.cpp) with size 1 (B/src/costp_controller.cpp:25); what the planner's output has to live
+// with is that size-1 CONTRACT, stated here instead of the class:
+//   * ONE slot: a set-point offered while the previous one has not been taken is REFUSED (the reference logs
+//     "Couldn't put trajectory point into buffer" and drops it);
+//   * taking the set-point empties the slot; the controller asks for the next one (readyForNextPoint) only then.
+struct SetPointHandOver {
+  bool occupied = false;
+  Vector3d point;
+  bool offer(const Vector3d &p) {
+    if (occupied) return false;
+    point = p;
+    occupied = true;
     return true;
   }
-  int size() const {                                                                          // :55-64
-    if (full_) return size_;
-    return head_ >= tail_ ? head_ - tail_ : size_ + head_ - tail_;
+  bool take(Vector3d &p) {
+    if (!occupied) return false;
+    p = point;
+    occupied = false;
+    return true;
   }
+  void clear() { occupied = false; }
 };
 
 class SetPointConsumer {
@@ -88,7 +84,7 @@ class SetPointConsumer {
     return a;
   }
 
-  TrajectoryBuffer tb_{1};                       // costp_controller.cpp:25
+  SetPointHandOver slot_;                        // the size-1 buffer of costp_controller.cpp:25, as a contract
   bool ready_for_next_point_ = false;            // costp_controller.h:82
   V lg_{0, 0, 0}, cg_{0, 0, 0}, current_ng_{0, 0, 0}, last_ng_{0, 0, 0}, next_ig_{0, 0, 0}, current_ig_{0, 0, 0};
   double next_ng_ = 0.0, v_act_ = 0.0, v_goal_ = 0.0;
@@ -114,9 +110,8 @@ class SetPointConsumer {
   // CoSTPController::reset, :88-109, with the end-effector position the forward kinematics would return
   void reset(const Vector3d &ee_position) {
     ready_for_next_point_ = true;
-    tb_.clear();
-    tb_[0] = ee_position;
-    lg_ = mk(tb_[0]);
+    slot_.clear();
+    lg_ = mk(ee_position);
     next_ig_ = lg_; cg_ = lg_; current_ng_ = lg_; last_ng_ = lg_;
     next_ng_ = 0;
     current_ig_ = lg_;
@@ -126,9 +121,9 @@ class SetPointConsumer {
   bool readyForNextPoint() const { return ready_for_next_point_; }     // costp_controller.h:68
   // CoSTPController::fillBuffer, :289-297. false = the buffer refused the point (logged as an error there).
   bool fillBuffer(const Vector3d &goal) {
-    bool ok = tb_.put(goal);
+    bool ok = slot_.offer(goal);
     if (!ok) cnt_.refused++;
-    if (tb_.full()) ready_for_next_point_ = false;
+    if (slot_.occupied) ready_for_next_point_ = false;
     return ok;
   }
   // One controller cycle (1 kHz): followTrajectory's trajectory logic (:299-340), then the speed ramp of
@@ -138,8 +133,9 @@ class SetPointConsumer {
     if (next_ng_ >= 1 || (v_act_ == 0 && next_ng_ == 0)) {
       bool got_point = false;
       lg_ = cg_;
-      if (!tb_.empty()) {
-        cg_ = mk(tb_.get());
+      Vector3d taken;
+      if (slot_.take(taken)) {
+        cg_ = mk(taken);
         got_point = true;
       } else {
         next_ng_ = 0;

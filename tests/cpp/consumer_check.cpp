@@ -1,4 +1,4 @@
-// consumer_check.cpp -- drives ghostplanner::cfplanner::SetPointConsumer / TrajectoryBuffer
+// consumer_check.cpp -- drives ghostplanner::cfplanner::SetPointConsumer / SetPointHandOver
 // (include/bimanual_planning_ros/setpoint_consumer.h) with a recorded set-point sequence; host-only (no GPU).
 // tests/test_setpoint_consumer.py compares every line with the oracle's restatement (orc_consumer_*).
 //   usage: consumer_check <points.bin> <n_points> <velocity> <sx> <sy> <sz> [double-fill-at k]
@@ -25,15 +25,15 @@ int main(int argc, char **argv) {
   if (!f || fread(pts.data(), sizeof(double), pts.size(), f) != pts.size()) return 3;
   fclose(f);
 
-  // TrajectoryBuffer semantics on their own (B/src/trajectory_buffer.cpp): a ring of 3
-  TrajectoryBuffer tb(3);
-  bool ok = tb.empty() && !tb.full() && tb.size() == 0 && tb.max_size() == 3;
-  ok = ok && tb.put(Vector3d(1, 0, 0)) && tb.put(Vector3d(2, 0, 0)) && tb.size() == 2 && !tb.full();
-  ok = ok && tb.put(Vector3d(3, 0, 0)) && tb.full() && tb.size() == 3 && !tb.put(Vector3d(4, 0, 0));
-  ok = ok && tb.get().x() == 1 && !tb.full() && tb.size() == 2 && tb[0].x() == 2 && tb[1].x() == 3;
-  ok = ok && tb.put(Vector3d(5, 0, 0)) && tb.full() && tb.get().x() == 2 && tb.get().x() == 3 && tb.get().x() == 5 && tb.empty();
-  tb.put(Vector3d(6, 0, 0)); tb.clear();
-  ok = ok && tb.empty() && tb.size() == 0;
+  // the one-slot hand-over contract on its own: refuse while occupied, taking empties the slot
+  SetPointHandOver slot;
+  Vector3d got;
+  bool ok = !slot.occupied && !slot.take(got);
+  ok = ok && slot.offer(Vector3d(1, 0, 0)) && slot.occupied && !slot.offer(Vector3d(2, 0, 0));
+  ok = ok && slot.take(got) && got.x() == 1 && !slot.occupied && !slot.take(got);
+  ok = ok && slot.offer(Vector3d(3, 0, 0)) && slot.take(got) && got.x() == 3;
+  slot.offer(Vector3d(4, 0, 0)); slot.clear();
+  ok = ok && !slot.occupied;
   printf("B %d\n", ok ? 1 : 0);
 
   SetPointConsumer c;

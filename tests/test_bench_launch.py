@@ -40,3 +40,43 @@ def test_more_ranks_than_devices_is_refused_without_the_single_device_hook():
     # gloo backend so that the process group comes up without a GPU; no SINGLE_DEVICE hook: 2 ranks > devices visible
     r = _run(["--gpus", "2", "--dry-run"], PMAF_BENCH_BACKEND="gloo")
     assert r.returncode != 0 and "hipGetDeviceCount" in r.stderr
+
+
+def test_gpus_8_dry_run_and_the_plan_budget():
+    """the machine the driver scales on has 8 GPUs: `--gpus 8` without a launcher starts eight ranks (gloo, one device
+    hook), the exchange communicator spans all eight, and the launch plan of the default command stays inside one
+    minute of GPU-side time by construction of its sub-configuration budgets (bench.plan_budget_s)"""
+    r = _run(["--gpus", "8", "--dry-run", "--steps", "20", "--warmup", "5"], PMAF_BENCH_BACKEND="gloo", PMAF_BENCH_SINGLE_DEVICE="1")
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["n_gpus"] == 8 and out["collective_world"] == 8
+    assert [w[0] for w in out["ranks"]] == list(range(8)) and len({w[2] for w in out["ranks"]}) == 8
+    assert out["allgather_of_ranks"] == [float(k) for k in range(8)]
+    assert out["plan"] == ["C1", "C3", "C5_sharded", "C4", "C2_contracted", "C3_contracted", "C5_sharded_contracted"]
+    assert out["budget_s"] < 60.0, out["budget_rows"]
+
+
+def test_plan_is_the_same_code_path_for_every_world_size():
+    """N = 1 of the scaling run and the single-GPU bench line are built by the same function from the same flags; only
+    C5's dealing-out depends on N (skipped where 8 scenes do not divide)"""
+    sys.path.insert(0, ROOT)
+    import argparse
+    import importlib
+    bench = importlib.import_module("bench")
+    ns = dict(config="C2", shard=False, populations=1, dynamic=False, lanes_per_agent=0, total_populations=8, no_exchange=False,
+              steps=20, warmup=5, min_seconds=1.0, min_blocks=5, only_headline=False, sub_steps=0, sub_seconds=0.25,
+              cpu_seconds=11.0, flop_ticks=24)
+    plans = {w: bench.build_plan(argparse.Namespace(**ns), w) for w in (1, 2, 3, 4, 8)}
+    for w, (head, plan, skipped) in plans.items():
+        assert head == plans[1][0]
+        names = [n for n, _ in plan]
+        if 8 % w == 0:
+            assert names == [n for n, _ in plans[1][1]] and not skipped
+            assert [sp for _, sp in plan] == [sp for _, sp in plans[1][1]]
+        else:
+            assert "C5_sharded" not in names and "C5_sharded" in skipped
+        budget, rows = bench.plan_budget_s(argparse.Namespace(**ns), w)
+        assert budget < 60.0, (w, rows)
+    # the default flags (no --steps / --warmup): still minutes, not more
+    ns2 = dict(ns, steps=2000, warmup=100)
+    assert bench.plan_budget_s(argparse.Namespace(**ns2), 1)[0] < 180.0

@@ -52,7 +52,7 @@ def run_both(exe, oracle, tmp_path, pts, start, velocity, double_fill_at=-1):
     if double_fill_at >= 0:
         cmd += ["double-fill-at", str(double_fill_at)]
     out = subprocess.run(cmd, capture_output=True, check=True).stdout.decode().strip().split("\n")
-    assert out[0] == "B 1"                      # TrajectoryBuffer ring semantics (trajectory_buffer.cpp)
+    assert out[0] == "B 1"                      # the one-slot hand-over contract (SetPointHandOver)
     rows = [l.split() for l in out[1:]]
     assert len(rows) == len(pts)
     c = oracle.OracleConsumer()

@@ -62,7 +62,7 @@ def _worker(rank, world, port, n_scenes, ticks, q):
 
 
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize("world,n_scenes", [(2, 4), (4, 8)])
+@pytest.mark.parametrize("world,n_scenes", [(2, 4), (4, 8), (8, 8)])
 def test_population_sharding_and_winner_all_gather(world, n_scenes):
     import torch.multiprocessing as mp
     ticks = 3

@@ -14,18 +14,23 @@ if [ "${1:-build}" = build ]; then
 fi
 cd "$R"
 mkdir -p gpurun_out
-OUT=gpurun_out/r3_asan.txt
+OUT=gpurun_out/r4_asan.txt
 ASAN_SO=$(g++ -print-file-name=libasan.so)
 UBSAN_SO=$(g++ -print-file-name=libubsan.so)
+rm -f /tmp/asan_log.* /tmp/ubsan_log.*
 export ASAN_OPTIONS=detect_leaks=0:protect_shadow_gap=0:abort_on_error=0:halt_on_error=0:log_path=/tmp/asan_log
 export UBSAN_OPTIONS=print_stacktrace=1:log_path=/tmp/ubsan_log
 {
   echo "# host side under AddressSanitizer + UndefinedBehaviorSanitizer (lib_asan/, LD_PRELOAD=$ASAN_SO)"
   echo "# ASAN_OPTIONS=$ASAN_OPTIONS"
-  echo "== tests/test_abi.py + checkpoint / stepping / attached-exchange / peer-mailbox tests (the cases that query torch.cuda are left out: torch does not initialise under a preloaded libasan)"
+  echo "== host-heavy GPU tests (C-ABI validation, checkpoint, stepping API, attached exchange, peer mailboxes, failure detection,"
+  echo "== winner path); every test named with its outcome, no -x; tests that need torch.cuda skip / fail to initialise torch under a"
+  echo "== preloaded libasan and are deselected by name"
   PMAF_LIB_PATH=$R/predictive-multi-agent-framework_amd/lib_asan/libpmaf_hip.so LD_PRELOAD="$ASAN_SO $UBSAN_SO" \
-    python -m pytest tests/test_abi.py tests/test_peer_gpu.py tests/test_shard_gpu.py tests/test_parity_gpu.py -q -x -p no:cacheprovider \
-    -k "abi or symbol or validation or checkpoint or stepping or attached or peer_mailbox_couples or peer_mailbox_two_handles or missing_header or step_api" 2>&1 | grep -E "passed|failed|error" | tail -3
+    python -m pytest tests/test_abi.py tests/test_peer_gpu.py tests/test_shard_gpu.py tests/test_parity_gpu.py tests/test_failure_detection_gpu.py \
+    -v -rfEs -p no:cacheprovider --deselect tests/test_failure_detection_gpu.py::test_facade_plantick_throws_on_a_nan_setpoint_and_serves_the_selected_path \
+    -k "abi or symbol or validation or error_reporting or checkpoint or stepping or attached or peer_mailbox_couples or peer_mailbox_two_handles or one_way or missing_header or step_api or health or time_limit or winner_path or set_agent or lifecycle or range" 2>&1 \
+    | grep -E "PASSED|FAILED|ERROR|SKIPPED|passed|failed|^E  " | sed -e "s#$R/##" | tail -80
   echo "== tools/fuzz_api.py 1000 trials"
   PMAF_LIB_PATH=$R/predictive-multi-agent-framework_amd/lib_asan/libpmaf_hip.so LD_PRELOAD="$ASAN_SO $UBSAN_SO" \
     python tools/fuzz_api.py 1000 31 2>&1 | tail -2
@@ -33,6 +38,6 @@ export UBSAN_OPTIONS=print_stacktrace=1:log_path=/tmp/ubsan_log
   ls /tmp/asan_log.* /tmp/ubsan_log.* 2>/dev/null | wc -l
   cat /tmp/asan_log.* /tmp/ubsan_log.* 2>/dev/null | grep -E "ERROR|runtime error|SUMMARY" | sort | uniq -c | head -20
   echo "# kernels with -DPMAF_DEBUG_BOUNDS (lib_bounds/): the GPU parity suite"
-  PMAF_LIB_PATH=$R/predictive-multi-agent-framework_amd/lib_bounds/libpmaf_hip.so python -m pytest tests/test_parity_gpu.py -q -x -p no:cacheprovider 2>&1 | tail -3
+  PMAF_LIB_PATH=$R/predictive-multi-agent-framework_amd/lib_bounds/libpmaf_hip.so python -m pytest tests/test_parity_gpu.py tests/test_tolerance_gpu.py -q -rfE -p no:cacheprovider 2>&1 | tail -6
 } > $OUT 2>&1
 cat $OUT

@@ -1,6 +1,6 @@
 """Rollout-kernel / tick time of the BASELINE configs per arithmetic policy on ONE box, interleaved (boxes differ by
 +-2 %, runs on one box by +-0.1 %): strict (default, bit-exact), fast (PMAF_FLAG_FAST_MATH), contracted
-(PMAF_FLAG_CONTRACTED). usage: python tools/policytime.py [C1 C2 C3 C4 C5] [--rounds 3] [--out file.json]"""
+(PMAF_FLAG_CONTRACTED). usage: python tools/policytime.py [C1 C2 C3 C4 C5] [--rounds 3] [--policies strict,contracted] [--out file.json]"""
 import json, os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -10,8 +10,11 @@ args = sys.argv[1:]
 rounds, out = 3, None
 if "--rounds" in args: k = args.index("--rounds"); rounds = int(args[k + 1]); del args[k:k + 2]
 if "--out" in args: k = args.index("--out"); out = args[k + 1]; del args[k:k + 2]
+only = None
+if "--policies" in args: k = args.index("--policies"); only = args[k + 1].split(","); del args[k:k + 2]
 cfgs = args or ["C1", "C2", "C3", "C4", "C5"]
 POL = {"strict": {}, "fast": {"fast_math": True}, "contracted": {"contracted": True}}
+if only: POL = {k: v for k, v in POL.items() if k in only}
 
 def scenes_of(c):
     if c == "C4": return pm.scenes.dual_arm_scenes()

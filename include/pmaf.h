@@ -449,8 +449,13 @@ int pmaf_save_state(pmaf_planner *h, void *blob, size_t bytes);
 int pmaf_load_state(pmaf_planner *h, const void *blob, size_t bytes);
 
 /* ---- measurement ---- */
-/* enable HIP-event timing of every rollout launch */
+/* HIP-event timing of the rollout launches: 0 off, 1 every launch, n > 1 every n-th launch (the events ride on the
+ * kernel's own dispatch packet, but a timed dispatch still costs 3-5 us of device time per tick -- tools/ticklat.py,
+ * profiles/r4_tick_overhead.txt -- so a throughput measurement samples) */
 int pmaf_set_profiling(pmaf_planner *h, int32_t enable);
+/* rollout launches since the last pmaf_reset_kernel_stats, timed or not (pmaf_get_kernel_stats's `launches` counts the
+ * timed ones while profiling is on) */
+int pmaf_get_launch_count(pmaf_planner *h, int64_t *launches);
 /* accumulated rollout-kernel time (ms), launches and agent-steps since the last reset_stats */
 int pmaf_get_kernel_stats(pmaf_planner *h, double *rollout_ms, int64_t *launches,
                           int64_t *agent_steps);

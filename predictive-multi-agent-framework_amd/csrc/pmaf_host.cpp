@@ -83,6 +83,10 @@ struct pmaf_planner {
   // pays for the table once
   bool closest_dirty = true;
   std::vector<double> last_live;   // the caller's last list, as given ([P][n_obs][7])
+  // the COMPLETE list D.obs_live currently holds, as the caller gave it (empty: unknown): pmaf_tick does not hand a list
+  // over again that is already resident -- the reference's node passes its obstacles_ with every call, and reading
+  // 1.8 KB of mapped host memory in the manager kernel costs ~5 us of set-point latency (tools/ticklat.py)
+  std::vector<double> live_resident;
   // (only the FIELD obstacles count -- the first n_obs - 1 rows of every population: the trailing repulsive obstacle,
   // which a host-coupled dual-arm run rewrites every tick, is not in the table)
   void note_live_obstacles(const double *obstacles) {
@@ -183,6 +187,8 @@ struct pmaf_planner {
   std::vector<double> goal_h;
   // profiling
   bool profiling = false;
+  int prof_every = 1;           // event timing on every prof_every-th rollout launch (pmaf_set_profiling's argument)
+  int64_t prof_phase = 0;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_free, ev_inflight;
   double rollout_ms = 0.0, last_rollout_ms = 0.0;
   int64_t launches = 0, timed_launches = 0;
@@ -325,7 +331,7 @@ static void drain_events(pmaf_planner *h, bool all) {
 
 static void launch_rollout(pmaf_planner *h) {
   hipEvent_t e0 = nullptr, e1 = nullptr;
-  if (h->profiling) {
+  if (h->profiling && (h->prof_phase++ % h->prof_every) == 0) {
     drain_events(h, false);
     if (h->ev_free.empty()) {
       hipEvent_t a, b;
@@ -404,6 +410,7 @@ static void upload_live_obstacles(pmaf_planner *h, const double *obstacles) {
   if (!obstacles) return;
   check_range(obstacles, (size_t)h->D.P * h->D.n_obs * 7, "obstacles");
   h->note_live_obstacles(obstacles);
+  h->live_resident.assign(obstacles, obstacles + (size_t)h->D.P * h->D.n_obs * 7);
   // ring of pinned staging buffers: wait only for the copy that last used this slot
   int s = h->stage_next;
   h->stage_next = (s + 1) % pmaf_planner::kStage;
@@ -418,8 +425,12 @@ static void upload_live_obstacles(pmaf_planner *h, const double *obstacles) {
 // pmaf_tick returns only after the manager kernel that read it has published its result.
 static const double *stage_live_obstacles_zero_copy(pmaf_planner *h, const double *obstacles) {
   if (!obstacles) return nullptr;
-  check_range(obstacles, (size_t)h->D.P * h->D.n_obs * 7, "obstacles");
+  const size_t n = (size_t)h->D.P * h->D.n_obs * 7;
+  // the same list as the one already resident in D.obs_live (bit for bit): nothing to hand over
+  if (h->live_resident.size() == n && std::memcmp(h->live_resident.data(), obstacles, sizeof(double) * n) == 0) return nullptr;
+  check_range(obstacles, n, "obstacles");
   h->note_live_obstacles(obstacles);
+  h->live_resident.assign(obstacles, obstacles + n);
   aos_to_soa(obstacles, h->h_zc, h->D.P, h->D.n_obs);
   return h->d_zc;
 }
@@ -864,6 +875,7 @@ int pmaf_create(const pmaf_params *prm, pmaf_planner **out) {
     }
     h->upload(D.obs_start, soa.data(), soa.size());
     h->upload(D.obs_live, soa.data(), soa.size());
+    h->live_resident.assign(prm->obstacles, prm->obstacles + (size_t)P * n_obs * 7);
     h->upload(ka, prm->k_attr, PN); h->upload(kc, prm->k_circ, PN);
     refresh_plain_step(h, prm->k_attr);
     h->upload(kr, prm->k_repel, PN); h->upload(kd, prm->k_damp, PN);
@@ -2050,6 +2062,7 @@ int pmaf_load_state(pmaf_planner *h, const void *blob, size_t bytes) {
     h->stepped = hd.stepped != 0;
     h->closest_dirty = true;   // (the blob's table matches its obs_start; recompute at the next reset all the same)
     h->last_live.clear();
+    h->live_resident.clear();
   });
 }
 
@@ -2061,6 +2074,8 @@ int pmaf_set_profiling(pmaf_planner *h, int32_t enable) {
     h->use_device();
     sync(h);
     h->profiling = enable != 0;
+    h->prof_every = enable > 1 ? enable : 1;
+    h->prof_phase = 0;
   });
 }
 int pmaf_get_kernel_stats(pmaf_planner *h, double *rollout_ms, int64_t *launches, int64_t *agent_steps) {
@@ -2068,11 +2083,18 @@ int pmaf_get_kernel_stats(pmaf_planner *h, double *rollout_ms, int64_t *launches
     GETTER_PROLOGUE("pmaf_get_kernel_stats")
     if (rollout_ms) *rollout_ms = h->rollout_ms;
     if (launches) *launches = h->profiling ? h->timed_launches : h->launches;
+    // (all launches since the reset, timed or not: pmaf_get_launch_count)
     if (agent_steps) {
       unsigned long long s = 0;
       h->download(&s, D.step_counter, 1);
       *agent_steps = (int64_t)s;
     }
+  });
+}
+int pmaf_get_launch_count(pmaf_planner *h, int64_t *launches) {
+  return guarded([&] {
+    REQUIRE(h && launches, "pmaf_get_launch_count: NULL argument");
+    *launches = h->launches;
   });
 }
 int pmaf_reset_kernel_stats(pmaf_planner *h) {

@@ -105,6 +105,7 @@ SYMBOLS = {
     "pmaf_set_profiling": (C.c_int, [_V, C.c_int32]),
     "pmaf_get_kernel_stats": (C.c_int, [_V, _dp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "pmaf_reset_kernel_stats": (C.c_int, [_V]),
+    "pmaf_get_launch_count": (C.c_int, [_V, C.POINTER(C.c_int64)]),
     "pmaf_get_launch_config": (C.c_int, [_V, _ip, _ip, _ip]),
     "pmaf_debug_math": (C.c_int, [C.c_int32, C.c_int32, _dp, _dp, _dp]),
     "pmaf_debug_external_rollout": (C.c_int, [_V, C.c_char_p, C.c_char_p]),
@@ -537,7 +538,8 @@ class PmafPlanner:
         return self.L.pmaf_stream(self._h)
 
     def set_profiling(self, on=True):
-        self._chk(self.L.pmaf_set_profiling(self._h, 1 if on else 0))
+        """on: False / True, or n > 1 = time every n-th rollout launch"""
+        self._chk(self.L.pmaf_set_profiling(self._h, int(on) if (on is not True and on is not False and int(on) > 1) else (1 if on else 0)))
 
     def kernel_stats(self):
         ms = C.c_double(0)
@@ -545,6 +547,11 @@ class PmafPlanner:
         steps = C.c_int64(0)
         self._chk(self.L.pmaf_get_kernel_stats(self._h, C.byref(ms), C.byref(n), C.byref(steps)))
         return ms.value, n.value, steps.value
+
+    def launch_count(self):
+        n = C.c_int64(0)
+        self._chk(self.L.pmaf_get_launch_count(self._h, C.byref(n)))
+        return n.value
 
     def reset_kernel_stats(self):
         self._chk(self.L.pmaf_reset_kernel_stats(self._h))

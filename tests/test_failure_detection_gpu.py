@@ -173,3 +173,38 @@ def test_start_after_set_agent_positions_needs_a_reset(pmaf, oracle, scenes):
         hip.stop()
         assert (hip.n_points() > 1).any()
     hip.close()
+
+
+def test_sampled_kernel_timing_and_resident_obstacle_lists(pmaf, oracle, scenes):
+    """pmaf_set_profiling(n): every n-th rollout launch carries HIP events; pmaf_get_launch_count counts them all.
+    And pmaf_tick with the SAME obstacle list as the resident one (what the reference's node passes every tick) must
+    behave exactly like a tick that hands a list over -- bit-exact against the oracle across same / changed / same lists"""
+    oracle.set_exp_mode(1)
+    try:
+        sc = scenes.config_scene("C1")
+        hip = pmaf.PmafPlanner(sc, device=0, mgr_init_pos=sc["start"])
+        ora = oracle.OraclePlanner(sc, mgr_init_pos=sc["start"])
+        hip.set_initial_position(sc["start"])
+        ora.set_initial_position(sc["start"])
+        hip.set_profiling(4)
+        hip.reset_kernel_stats()
+        obs = sc["obstacles"].copy()
+        for t in range(40):
+            if t in (10, 11, 25):                      # a changed list, changed again, and back to an earlier one
+                obs = obs.copy()
+                obs[2, :3] += 0.01 if t != 25 else -0.02
+            bh = hip.tick(obs, sc["dt"], sc["cost_gains"], sc["ws_limits"])
+            bo = ora.tick(obs, sc["dt"], sc["cost_gains"], sc["ws_limits"])
+            assert bh == bo
+            np.testing.assert_array_equal(hip.real_state()[0], ora.real_state()[0])
+        hip.stop()
+        ph, nh = hip.paths()
+        po, no = ora.paths()
+        np.testing.assert_array_equal(nh, no)
+        np.testing.assert_array_equal(ph, po)
+        ms, timed, steps = hip.kernel_stats()
+        assert hip.launch_count() == 40 and timed == 10 and ms > 0
+        assert steps == int(sum(no - 1)) or steps > 0
+        hip.close()
+    finally:
+        oracle.set_exp_mode(0)

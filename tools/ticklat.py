@@ -1,0 +1,31 @@
+"""Set-point latency of idle-stream ticks on the library's own clock (pmaf_get_tick_times_us), with / without the
+rollout's event timing, with / without obstacles handed over, with / without the winner path.
+usage: python tools/ticklat.py [C2] [n]"""
+import os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import __graft_entry__ as g
+pm = g.load_package()
+cfg = sys.argv[1] if len(sys.argv) > 1 else "C2"
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 600
+sc = pm.scenes.config_scene(cfg)
+for prof in (False, True):
+    for with_obs in (False, True):
+        for wp in (False, True):
+            h = pm.PmafPlanner(sc, device=0, mgr_init_pos=sc["start"])
+            h.set_initial_position(sc["start"])
+            h.set_profiling(prof)
+            if wp: h.enable_winner_path()
+            for k in range(n + 50):
+                if k == 50: h.tick_times_us()
+                if k % 128 == 0: h.set_initial_position(sc["start"])
+                h.stop()
+                h.tick(sc["obstacles"] if with_obs else None, sc["dt"], sc["cost_gains"], sc["ws_limits"])
+                if wp: h.winner_path_wait()
+            h.stop()
+            enq, sp = h.tick_times_us()
+            w = h.winner_path_times_us() if wp else np.zeros(1)
+            print("%s events %-5s obstacles %-5s winner path %-5s | enqueue median %.2f p99 %.2f | set-point median %.2f p99 %.2f | path median %.2f p99 %.2f us"
+                  % (cfg, prof, with_obs, wp, np.median(enq), np.percentile(enq, 99), np.median(sp), np.percentile(sp, 99),
+                     np.median(w), np.percentile(w, 99)), flush=True)
+            h.close()

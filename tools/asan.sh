@@ -25,10 +25,15 @@ export UBSAN_OPTIONS=print_stacktrace=1:log_path=/tmp/ubsan_log
   echo "# ASAN_OPTIONS=$ASAN_OPTIONS"
   echo "== host-heavy GPU tests (C-ABI validation, checkpoint, stepping API, attached exchange, peer mailboxes, failure detection,"
   echo "== winner path); every test named with its outcome, no -x; tests that need torch.cuda skip / fail to initialise torch under a"
-  echo "== preloaded libasan and are deselected by name"
+  echo "== preloaded libasan and are deselected by name (the two *_does_not_leak tests read torch.cuda.mem_get_info: under LD_PRELOAD=libasan"
+  echo "== torch fails with 'Error in dlopen: libcaffe2_nvrtc.so' -- the one failure of profiles/r3_asan.txt; test_no_kernel_touches_scratch_memory"
+  echo "== inspects the product build's object files, not this library; the facade driver is linked against the product library)"
   PMAF_LIB_PATH=$R/predictive-multi-agent-framework_amd/lib_asan/libpmaf_hip.so LD_PRELOAD="$ASAN_SO $UBSAN_SO" \
     python -m pytest tests/test_abi.py tests/test_peer_gpu.py tests/test_shard_gpu.py tests/test_parity_gpu.py tests/test_failure_detection_gpu.py \
     -v -rfEs -p no:cacheprovider --deselect tests/test_failure_detection_gpu.py::test_facade_plantick_throws_on_a_nan_setpoint_and_serves_the_selected_path \
+    --deselect tests/test_abi.py::test_no_kernel_touches_scratch_memory \
+    --deselect tests/test_shard_gpu.py::test_exchange_lifecycle_does_not_leak \
+    --deselect tests/test_parity_gpu.py::test_handle_lifecycle_does_not_leak_device_memory \
     -k "abi or symbol or validation or error_reporting or checkpoint or stepping or attached or peer_mailbox_couples or peer_mailbox_two_handles or one_way or missing_header or step_api or health or time_limit or winner_path or set_agent or lifecycle or range" 2>&1 \
     | grep -E "PASSED|FAILED|ERROR|SKIPPED|passed|failed|^E  " | sed -e "s#$R/##" | tail -80
   echo "== tools/fuzz_api.py 1000 trials"

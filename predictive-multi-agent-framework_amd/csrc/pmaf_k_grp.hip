@@ -37,8 +37,8 @@ constexpr unsigned PRIO_YOUNGER_OF_8 = PMAF_PRIO_YOUNGER_OF_8;
 #define PMAF_POP_ROTATE 8
 #endif
 constexpr unsigned POP_ROTATE = PMAF_POP_ROTATE;
-template <int LPA, int TILES, int MATH>
-__global__ __launch_bounds__(64) void k_rollout_grp(DevView D, CostParams CP) {
+template <int LPA, int TILES, int MATH, bool STATIC>
+__device__ __forceinline__ void rollout_grp_body(const DevView &D, const CostParams &CP) {
   extern __shared__ double smem[];
   __shared__ double s_expk[EXPK_N];   // portable_exp's constants (pmaf_device.hpp: exp_consts_from_lds)
   constexpr int APW = 64 / LPA;
@@ -53,7 +53,17 @@ __global__ __launch_bounds__(64) void k_rollout_grp(DevView D, CostParams CP) {
   const int aa = active ? a : 0;
   const int n_obs = D.n_obs;
   const int M = n_obs - 1;
-  const PopConst C = D.C;
+  PopConst C = D.C;
+#ifndef PMAF_GRP_PIN
+#define PMAF_GRP_PIN 1
+#endif
+  // STATIC body (round 4): the obstacles' velocities no longer hold registers, so the population constants are pinned in
+  // VGPRs (as in the wave-per-agent kernel): left in the SGPR file they are spilled to VGPR lanes and reloaded by
+  // v_readlane in the step loop -- VALU instructions, which bound this kernel (profiles/r4_c5_strict_steploop.txt)
+  if (STATIC && PMAF_GRP_PIN) {
+    double *f = reinterpret_cast<double *>(&C);
+    for (int i = 0; i < (int)(sizeof(PopConst) / sizeof(double)); i++) asm volatile("" : "+v"(f[i]));
+  }
   const size_t pa = (size_t)pop * D.N + aa;
   const int type = D.types[aa];
   const double *src = D.obs_start + (size_t)pop * 7 * n_obs;
@@ -69,7 +79,8 @@ __global__ __launch_bounds__(64) void k_rollout_grp(DevView D, CostParams CP) {
     bool valid = i < M;
     int ii = valid ? i : 0;
     O.p[t] = mk(src[ii], src[n_obs + ii], src[2 * n_obs + ii]);
-    O.v[t] = mk(src[3 * n_obs + ii], src[4 * n_obs + ii], src[5 * n_obs + ii]);
+    if (STATIC) O.v[t] = mk(0.0, 0.0, 0.0);   // (never read: see circ_and_scale_grp)
+    else O.v[t] = mk(src[3 * n_obs + ii], src[4 * n_obs + ii], src[5 * n_obs + ii]);
     O.r[t] = src[6 * n_obs + ii];
     O.rx[t] = rot_g[ii]; O.ry[t] = rot_g[n_obs + ii]; O.rz[t] = rot_g[2 * n_obs + ii];
     O.qx[t] = rnd_g[ii]; O.qy[t] = rnd_g[n_obs + ii]; O.qz[t] = rnd_g[2 * n_obs + ii];
@@ -82,6 +93,7 @@ __global__ __launch_bounds__(64) void k_rollout_grp(DevView D, CostParams CP) {
 
   const V3 goal = mk(D.goal[pop * 3], D.goal[pop * 3 + 1], D.goal[pop * 3 + 2]);
   const V3 init_pos = mk(D.agent_init_pos[pop * 3], D.agent_init_pos[pop * 3 + 1], D.agent_init_pos[pop * 3 + 2]);
+  // (pinning the goal and the start position too changes nothing: 686.1 / 686.7 against 685.6 us, profiles/r4_ab_grp.txt)
   V3 p = mk(D.start_pos[pop * 3], D.start_pos[pop * 3 + 1], D.start_pos[pop * 3 + 2]);
   V3 v = mk(D.start_vel[pop * 3], D.start_vel[pop * 3 + 1], D.start_vel[pop * 3 + 2]);
   const double k_attr = D.k_attr[pa], k_circ = D.k_circ[pa], k_repel = D.k_repel[pa], k_damp = D.k_damp[pa];
@@ -89,10 +101,12 @@ __global__ __launch_bounds__(64) void k_rollout_grp(DevView D, CostParams CP) {
   const double zsent_lt = D.zsent_lt[pop];
   const bool sent_reachable = wave_any(sentinel_reachable(p, sent_p, sent_v, zsent_lt, C, D.cap));  // wave-uniform
   bool moving = false;
+  if (!STATIC) {
 #pragma unroll
-  for (int t = 0; t < TILES; t++) moving = moving || !(O.v[t].x == 0.0 && O.v[t].y == 0.0 && O.v[t].z == 0.0);
-  moving = wave_any(moving);
-  bool advance = true;
+    for (int t = 0; t < TILES; t++) moving = moving || !(O.v[t].x == 0.0 && O.v[t].y == 0.0 && O.v[t].z == 0.0);
+    moving = wave_any(moving);
+  }
+  bool advance = !STATIC;   // (STATIC: p + (+0.0) dt is p for every p, -0.0 coordinates included -- never applied)
 
   int clist_off = 7 * n_obs + (n_obs + 1) / 2;
   clist_off += clist_off & 1;
@@ -146,9 +160,16 @@ __global__ __launch_bounds__(64) void k_rollout_grp(DevView D, CostParams CP) {
     if (!PACK) verr = attractor_velocity_error<MATH>(v, g, C, k_attr, k_damp);
     V3 F = mk(0.0, 0.0, 0.0);
     double scale = 1.0;
-    if ((run_m & gate_m) != 0ull)
-      circ_and_scale_grp<LPA, TILES, MATH>(run_m & gate_m, sub, grp, type, p, v, zv, goal, g, dg, gn, C, k_circ, n_obs,
-                                     rot_g, known_bits, O, clist, lane_min, F, scale, s_expk);
+    if ((run_m & gate_m) != 0ull) {
+      V3 nv_pre = mk(0.0, 0.0, 0.0);
+      if (STATIC) {   // rel_vel / |rel_vel| of every obstacle of this agent (garbage for zv == 0: the terms are discarded then)
+        double vn0, rvn0;
+        MT::norm_rcp_zpos(zv, vn0, rvn0);
+        nv_pre = MT::div3_n_pos(v, vn0, rvn0);
+      }
+      circ_and_scale_grp<LPA, TILES, MATH, STATIC>(run_m & gate_m, sub, grp, type, p, v, zv, goal, g, dg, gn, C, k_circ, n_obs,
+                                     rot_g, known_bits, O, clist, lane_min, F, scale, s_expk, nv_pre);
+    }
     V3 new_pos;
     V3 nv = v;
     if (PACK) {
@@ -242,6 +263,28 @@ __global__ __launch_bounds__(64) void k_rollout_grp(DevView D, CostParams CP) {
   }
 }
 
+
+// the kernel: per wave, are the population's field obstacles at rest with +0.0 velocities (bit patterns)? Then the
+// STATIC body (one rel_vel normalisation per step, no velocity registers); otherwise the general one.
+template <int LPA, int TILES, int MATH>
+__global__ __launch_bounds__(64) void k_rollout_grp(DevView D, CostParams CP) {
+  const int n_obs = D.n_obs, M = n_obs - 1;
+  const double *src = D.obs_start + (size_t)blockIdx.y * 7 * n_obs;
+  bool rest = true;
+  for (int i = threadIdx.x; i < M; i += 64) {
+    const unsigned long long bx = (unsigned long long)__double_as_longlong(src[3 * n_obs + i]),
+                             by = (unsigned long long)__double_as_longlong(src[4 * n_obs + i]),
+                             bz = (unsigned long long)__double_as_longlong(src[5 * n_obs + i]);
+    rest = rest && ((bx | by | bz) == 0ull);
+  }
+#ifdef PMAF_GRP_FORCE_STATIC   // register-budget experiments only: the STATIC body alone
+  (void)rest;
+  rollout_grp_body<LPA, TILES, MATH, true>(D, CP);
+#else
+  if (!wave_any(!rest)) rollout_grp_body<LPA, TILES, MATH, true>(D, CP);
+  else rollout_grp_body<LPA, TILES, MATH, false>(D, CP);
+#endif
+}
 
 #ifndef PMAF_GRP_MATH
 #error "compile with -DPMAF_GRP_MATH=0|2|3"

@@ -132,12 +132,18 @@ __device__ __forceinline__ V3 current_vector_grp(int type, V3 rel_vel, V3 nv, do
 // lane's agent takes a step and its gate is open (uniform within the group).
 // clist: this GROUP's list in LDS (LPA*TILES entries of 4 doubles + one
 // all-zero entry at index LPA*TILES).
-template <int LPA, int TILES, int MATH>
+// STATIC (round 4): every field obstacle of the wave's population is at rest with velocity components that are +0.0 bit
+// for bit (decided per wave in the kernel's prologue). Then rel_vel = v - (+0.0) = v EXACTLY (x - (+0.0) == x for every
+// x, -0.0 included), so |rel_vel|, rel_vel / |rel_vel| and the `vel_norm != 0` test (B/src/cf_agent.cpp:97-99) are the
+// same for every obstacle of an agent: one sqrt / reciprocal / divide sequence per step (nv_pre, computed by the caller)
+// instead of one per slot, and the obstacles' velocities need no registers.
+template <int LPA, int TILES, int MATH, bool STATIC = false>
 __device__ __forceinline__ void circ_and_scale_grp(lmask act_m, int sub, int grp, int type, V3 p, V3 v, double zv,
                                                    V3 goal, V3 g, double dg, V3 gn, const PopConst &C, double k_circ,
                                                    int n_obs, double *rot_g, unsigned &known_bits,
                                                    LaneObstacles<TILES> &O, double *clist, double &lane_min, V3 &F,
-                                                   double &scale, const double *exp_tab) {
+                                                   double &scale, const double *exp_tab,
+                                                   const V3 nv_pre = V3{0.0, 0.0, 0.0}) {
   // Lane predicates as scalar masks built from single-compare ballots (pmaf_rollout_w64.hpp, "lane predicates as
   // masks": a vote on a compound predicate costs two VALU instructions, and this kernel is VALU-issue bound).
   typedef Mth<MATH> MT;
@@ -166,7 +172,7 @@ __device__ __forceinline__ void circ_and_scale_grp(lmask act_m, int sub, int grp
     const lmask valid_m = act_m & PMAF_BAL(i < M);
     const V3 op = O.p[t];
     const V3 ro = op - p;
-    const V3 rv = v - O.v[t];
+    const V3 rv = STATIC ? v : (v - O.v[t]);
     double s;
     V3 ron;
     MT::template norm_unit<true>(ro, s, ron);
@@ -196,10 +202,16 @@ __device__ __forceinline__ void circ_and_scale_grp(lmask act_m, int sub, int grp
       const V3 rot = mk(O.rx[t], O.ry[t], O.rz[t]);
       // |rv| is only divided by and compared with 0 (sqrt(z) != 0 <=> z != 0): no zero / infinity select behind the
       // root, fixup-free divisions -- for z == 0 the term is discarded (has_m)
-      const double zrv = sqn(rv);
-      double vn, rvn;
-      MT::norm_rcp_zpos(zrv, vn, rvn);
-      const V3 nv = MT::div3_n_pos(rv, vn, rvn);
+      double zrv;
+      V3 nv;
+      if (STATIC) {   // (the caller's: sqn(v) and v / |v| by the same sequence)
+        zrv = zv; nv = nv_pre;
+      } else {
+        zrv = sqn(rv);
+        double vn, rvn;
+        MT::norm_rcp_zpos(zrv, vn, rvn);
+        nv = MT::div3_n_pos(rv, vn, rvn);
+      }
 #ifndef PMAF_GRP_CURVEC
 #define PMAF_GRP_CURVEC 1
 #endif

@@ -333,18 +333,34 @@ __global__ __launch_bounds__(64) void k_manager(DevView D, CostParams CP, Manage
     // cost assembly + argmin, B/src/cf_manager.cpp:325-343
     double lmin = 1.7976931348623157e308;
     int lidx = 0x7fffffff;
-    for (int a = lane; a < N; a += 64) {
-      size_t pa = (size_t)pop * N + a;
-      double cost = D.cost_ws[pa];
-      double gd = D.goal_dist[pa];
-      if (gd > C.approach) cost += gd * CP.k_goal_dist;
-      cost += D.path_len[pa] * CP.k_path_len;
-      double mo = D.min_obs[pa];
-      cost += CP.k_safe_dist / mo;
-      if (mo < 2e-5) cost += 10000.0;
-      D.costs[pa] = cost;
-      s_cost[a] = cost;
-      if (cost < lmin) { lmin = cost; lidx = a; }
+    // (round 4: four agents per lane and pass with their sixteen loads issued together -- the stores to D.costs may alias
+    // the result arrays as far as the compiler knows, so the rolled loop paid one memory round trip per agent: 7.4 us of
+    // the 15 us manager kernel at 1024 agents; same operations per agent, ascending agent index per lane as before)
+    for (int a0 = lane; a0 < N; a0 += 256) {
+      double cw[4], gdv[4], pl[4], mov[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int a = a0 + 64 * k;
+        const size_t pa = (size_t)pop * N + (a < N ? a : a0);
+        cw[k] = D.cost_ws[pa]; gdv[k] = D.goal_dist[pa]; pl[k] = D.path_len[pa]; mov[k] = D.min_obs[pa];
+      }
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int a = a0 + 64 * k;
+        if (a < N) {
+          const size_t pa = (size_t)pop * N + a;
+          double cost = cw[k];
+          const double gd = gdv[k];
+          if (gd > C.approach) cost += gd * CP.k_goal_dist;
+          cost += pl[k] * CP.k_path_len;
+          const double mo = mov[k];
+          cost += CP.k_safe_dist / mo;
+          if (mo < 2e-5) cost += 10000.0;
+          D.costs[pa] = cost;
+          s_cost[a] = cost;
+          if (cost < lmin) { lmin = cost; lidx = a; }
+        }
+      }
     }
     group_argmin<64>(lmin, lidx);
     int min_idx = (lidx == 0x7fffffff) ? 0 : lidx;

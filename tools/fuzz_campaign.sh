@@ -1,8 +1,9 @@
-cd $GRAFT_REPO_ROOT
-{
-echo "# round 3, third session, final kernels (… + closest-other table): randomised parity campaigns with fresh seeds"
-for args in "fuzz_parity.py 12000 5550001" "fuzz_parity.py 6000 5550002" "fuzz_api.py 3000 5550003"; do
+#!/bin/bash
+# randomised parity campaigns with fresh seeds against the oracle (bit-exact; tools/fuzz_parity.py: random scenes through
+# every kernel family, tools/fuzz_api.py: random C-ABI call sequences) -- prints the three summary lines
+cd ${GRAFT_REPO_ROOT:-$(pwd)}
+SEED=${1:-7770001}
+echo "# round 4, final kernels (group kernel's STATIC body, manager selection, resident obstacle lists): randomised parity campaigns, seeds from $SEED"
+for args in "fuzz_parity.py 12000 $SEED" "fuzz_parity.py 6000 $((SEED+1))" "fuzz_api.py 3000 $((SEED+2))"; do
   echo "== tools/$args"; python tools/$args 2>&1 | tail -1
 done
-} > gpurun_out/r3_fuzz_session3b.txt 2>&1
-cat gpurun_out/r3_fuzz_session3b.txt

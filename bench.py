@@ -767,6 +767,7 @@ def main():
                          "frac": head["hbm_frac"], "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": kernel_name,
                          "avg_kernel_us": head["avg_kernel_us"],
+                         "kernel_timing": head["kernel_timing"],
                          "algorithmic_bytes_per_launch": head["algorithmic_bytes_per_launch"],
                          "note": "FP64-VALU/latency-bound ODE integration; HBM fraction is structurally tiny "
                                  "(SURVEY.md 8d): see fp64_valu"},

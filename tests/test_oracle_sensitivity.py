@@ -65,3 +65,33 @@ def test_unpinned_eigen_details_move_the_set_points_by_less_than_a_nanometre(tmp
             # C3's 500-step rollouts through 128 obstacles amplify a last-bit difference in a few non-selected agents
             # (DESIGN.md section 2); the selected trajectory / set-points are what the tolerance is about
             assert d < 1e-9 and (dp < 1e-9 or cfg == "C3"), (tag, cfg, d, dp)
+
+
+def test_shipped_task_scenes_conditioning_under_the_unpinned_eigen_details():
+    """The same question on the reference's OWN operating point: the nine shipped task scenes, closed loop until reached /
+    900 ticks (tools/oracle_conditioning.py, record: profiles/r4_oracle_conditioning.txt). The six dual_arms_* scenes are
+    well conditioned -- same best-index sequence, set-points within 1e-9 m whichever way the dot product associates and
+    the quotient is formed. The three sim_kobo_dyn_spheres* scenes (H = 1500 / 1200 through moving spheres) are NOT: two
+    IEEE-conformant evaluation orders of the same algorithm part ways there (set-points by centimetres, a best-index
+    difference at tick 1 of spheres3), so against a reference whose evaluation order cannot be pinned no implementation
+    can promise 1e-5 m on them -- bit-exact parity is against THIS oracle's order. This test pins
+    which scenes are which."""
+    r = subprocess.run([sys.executable, os.path.join(conftest.ROOT, "tools", "oracle_conditioning.py")], capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    import re
+    rows = {}
+    variant = None
+    for line in r.stdout.splitlines():
+        if line.startswith("== variant:"):
+            variant = line.split(":", 1)[1].strip()
+        m = re.match(r"(\S+)\s+(\d+) ticks \| first best-index difference: (\S+)\s*\| set-point (\S+) m \| selected trajectory (\S+) m", line)
+        if m and variant:
+            rows[(variant, m.group(1))] = (int(m.group(2)), m.group(3), float(m.group(4)), float(m.group(5)))
+    assert len(rows) == 27
+    for (variant, task), (ticks, flip, dset, dsel) in rows.items():
+        if task.startswith("dual_arms_"):
+            assert flip == "None" and dset < 1e-9, (variant, task, flip, dset)
+    chaotic = {task for (variant, task), (ticks, flip, dset, dsel) in rows.items() if flip != "None" or dset > 1e-5}
+    print("task scenes on which the oracle's own evaluation-order variants part ways:", sorted(chaotic))
+    assert chaotic <= {"sim_kobo_dyn_spheres1", "sim_kobo_dyn_spheres2", "sim_kobo_dyn_spheres3"}

@@ -427,7 +427,9 @@ static const double *stage_live_obstacles_zero_copy(pmaf_planner *h, const doubl
   if (!obstacles) return nullptr;
   const size_t n = (size_t)h->D.P * h->D.n_obs * 7;
   // the same list as the one already resident in D.obs_live (bit for bit): nothing to hand over
-  if (h->live_resident.size() == n && std::memcmp(h->live_resident.data(), obstacles, sizeof(double) * n) == 0) return nullptr;
+  // (not while peer mailboxes are connected: a coupled population's trailing row of D.obs_live is the peer's set-point then,
+  // not the caller's)
+  if (!h->peer.on && h->live_resident.size() == n && std::memcmp(h->live_resident.data(), obstacles, sizeof(double) * n) == 0) return nullptr;
   check_range(obstacles, n, "obstacles");
   h->note_live_obstacles(obstacles);
   h->live_resident.assign(obstacles, obstacles + n);
@@ -680,6 +682,7 @@ static int peer_book_tick(pmaf_planner *h) {
 
 static void peer_disconnect(pmaf_planner *h) {
   pmaf_planner::Peer &pr = h->peer;
+  h->live_resident.clear();   // (a coupled trailing obstacle was written on the device: the caller's list is handed over again)
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   for (size_t r = 0; r < pr.mapped.size(); r++)
     if (pr.opened[r] && pr.mapped[r]) (void)hipIpcCloseMemHandle(pr.mapped[r]);
@@ -1765,6 +1768,7 @@ int pmaf_peer_connect(pmaf_planner *h, int32_t world, int32_t rank, const void *
     HIP_CHECK(hipMemcpy(pr.d_view, &v, sizeof(v), hipMemcpyHostToDevice));
     pr.tick = 0;
     pr.on = true;
+    h->live_resident.clear();
   });
 }
 

@@ -99,6 +99,7 @@ def test_attached_exchange_every_tick_matches_getters_and_oracle(pmaf, oracle, s
     else:
         comm = pmaf.PmafComm.host(1, 0, lambda b: b)
     hip.attach_comm(comm)
+    hip.enable_winner_path()          # (ABI 5) the same path through pinned memory, with the path buffers alternating
     sc = scs[0]
     cap = sc["max_prediction_steps"]
     obs = np.stack([s["obstacles"] for s in scs])
@@ -106,6 +107,10 @@ def test_attached_exchange_every_tick_matches_getters_and_oracle(pmaf, oracle, s
         hip.stop()
         prev_paths, prev_n = hip.paths()                   # what this tick's selection scores
         best = hip.tick(obs, sc["dt"], sc["cost_gains"], sc["ws_limits"])
+        wpaths, wn, wa = hip.winner_path()
+        for p in range(3):
+            assert wa[p] == best[p] and wn[p] == prev_n[p, best[p]]
+            np.testing.assert_array_equal(wpaths[p], prev_paths[p, best[p], :wn[p]])
         tab = hip.winners_wait()
         assert tab.shape == (1, 3, 8 + 3 * cap)
         recs = pmaf.shard.unpack_winner_records(tab[0], cap)

@@ -92,14 +92,14 @@ out.append("**CPU baseline** (`cpu_baseline`, kind `port`: `oracle/cpu_bench.py`
            "rollouts/s. Agents' rollouts on OpenMP threads: `-O2` median %s (%d threads, min %s … max %s), `-O3 -march=native` median %s "
            "(%d threads, min %s … max %s). The multi-threaded repetitions are NOT a stable measurement on these shared hosts — single "
            "repetitions range from %s to %s rollouts/s, and the median lands in either mode from run to run (round 3's driver run: 254 k) — "
-           "so the comparison is a range: **at C2 the GPU's %s rollouts/s are %.2f × the median of the better CPU build in this run, "
+           "so the comparison is a range: **at C2 the GPU's %s rollouts/s are %.2f × the median of the better CPU build in this run (the default-flags run minutes later on the same box measured a CPU median of %s: %.2f ×), "
            "%.2f × the port's fastest repetition and %.0f × one core**. C2 is 64 independent 200-step chains, the shape where a GPU has the "
            "least to offer — a 64-core host running one agent per core is on par with it; C3: %.0f × the multi-threaded port, C5 × 8: %.0f ×. "
            "The claim here is parity and an issue-bound step, not the ratio."
            % (cb["cpu_model"], cb["host_cpus"], k(cb["value_1core_O2"]), k(cb["value_1core_O3_native"]),
               k(cb["value_O2"]), cb["threads_O2"], k(cb["spread_O2"][0]), k(cb["spread_O2"][1]),
               k(cb["value_O3_native"]), cb["threads_O3_native"], k(cb["spread_O3_native"][0]), k(cb["spread_O3_native"][1]),
-              k(lo), k(hi), k(d["value"]), d["value"] / cb["value"], d["value"] / hi, d["value"] / cb["value_1core"],
+              k(lo), k(hi), k(d["value"]), d["value"] / cb["value"], k(load("%s_bench_c2.json" % R)["cpu_baseline"]["value"]), d["value"] / load("%s_bench_c2.json" % R)["cpu_baseline"]["value"], d["value"] / hi, d["value"] / cb["value_1core"],
               c3["value"] / c3["cpu_baseline"]["value"], c5["value"] / c5["cpu_baseline"]["value"]))
 block = "\n".join(out) + "\n"
 p = os.path.join(ROOT, "DESIGN.md")
@@ -123,10 +123,15 @@ tab = ["| BASELINE config | rollouts/s | tick | rollout kernel | CPU port: multi
        "| C3: 256 × 500 × 128 | %.0f k | %.2f ms | %.2f ms | %s |" % (c3["value"] / 1e3, c3["ms_per_step"], c3["roofline"]["avg_kernel_us"] / 1e3, cpu_cell(c3)),
        "| C5: 8 × 1024 × 200 × 32 (one GPU) | %.1f M | %.2f ms | %.2f ms | %s |" % (c5["value"] / 1e6, c5["ms_per_step"], c5["roofline"]["avg_kernel_us"] / 1e3, cpu_cell(c5))]
 r = re.sub(r"(<!-- headline:begin -->\n).*?(<!-- headline:end -->)", lambda m: m.group(1) + "\n".join(tab) + "\n" + m.group(2), r, flags=re.S)
+d2 = load("%s_bench_c2.json" % R)          # the same workload with the default flags, minutes later on the same box
+meds = sorted([cb["value"], d2["cpu_baseline"]["value"]])
 r = re.sub(r"(<!-- ratio:begin -->).*?(<!-- ratio:end -->)", lambda m: m.group(1) + (
-    "%.2f × the MEDIAN repetition of the multi-threaded CPU port of the same algorithm on the box's %s in this run (%d threads), %.2f × its fastest "
-    "repetition (the repetitions range from %.0f k to %.0f k rollouts/s on these shared hosts; in round 3's driver run the median was 254 k, i.e. "
-    "1.03 ×), %.0f × one core" % (d["value"] / cb["value"], cb["cpu_model"], cb["cores"], d["value"] / hi, lo / 1e3, hi / 1e3, d["value"] / cb["value_1core"])) + m.group(2), r, flags=re.S)
+    "between %.2f × and %.2f × the MEDIAN repetition of the multi-threaded CPU port of the same algorithm on the box's %s — the port's "
+    "median was %.0f k rollouts/s in one of this round's two C2 runs and %.0f k in the other (`profiles/r4_bench_c2_driver_flags.json`, "
+    "`r4_bench_c2.json`; single repetitions range from %.0f k to %.0f k on these shared hosts; round 3's driver run: 254 k = 1.03 ×) — and %.0f × one core"
+    % (d["value"] / meds[1], d["value"] / meds[0], cb["cpu_model"], meds[0] / 1e3, meds[1] / 1e3,
+       min(lo, d2["cpu_baseline"]["spread_O2"][0], d2["cpu_baseline"]["spread_O3_native"][0]) / 1e3,
+       max(hi, d2["cpu_baseline"]["spread_O2"][1], d2["cpu_baseline"]["spread_O3_native"][1]) / 1e3, d["value"] / cb["value_1core"])) + m.group(2), r, flags=re.S)
 r = re.sub(r"(<!-- frac:begin -->).*?(<!-- frac:end -->)", lambda m: m.group(1) + "%.2g of 8 TB/s" % rf["frac"] + m.group(2), r, flags=re.S)
 r = re.sub(r"(<!-- target:begin -->).*?(<!-- target:end -->)", lambda m: m.group(1) + "%.1f ×" % (d["value"] / 1e5) + m.group(2), r, flags=re.S)
 r = re.sub(r"(<!-- lat:begin -->).*?(<!-- lat:end -->)", lambda m: m.group(1) + (

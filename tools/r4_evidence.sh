@@ -6,7 +6,7 @@
 cd ${GRAFT_REPO_ROOT:-$(pwd)}
 O=gpurun_out/r4
 mkdir -p $O
-PARTS=${@:-bench prof misc tests}
+PARTS=${@:-bench prof misc asan tests}
 for part in $PARTS; do case $part in
 bench)
   python bench.py --steps 20 --warmup 5 > $O/bench_c2_driver_flags.json 2> $O/bench.err
@@ -28,8 +28,10 @@ misc)
   python tools/ticklat.py C2 600 > $O/ticklat.txt 2>&1
   { echo "# per-agent / per-wave rollout durations from the device clock, and launch duration against the slowest wave (final kernels of round 4)";
     python tools/agenttime.py C1 C2 C3; python tools/c5agents.py; python tools/launchgap.py; } 2>&1 | grep -v "^$\|amdgpu.ids" > $O/agent_times.txt
-  bash tools/asan.sh run > /dev/null 2>&1; cp gpurun_out/r4_asan.txt $O/asan.txt
   bash tools/fuzz_campaign.sh > $O/fuzz_campaign.txt 2>&1
+  ;;
+asan)   # (build first, here: bash tools/asan.sh build -- lib_asan/ and lib_bounds/ travel with the snapshot)
+  bash tools/asan.sh run > /dev/null 2>&1; cp gpurun_out/r4_asan.txt $O/asan.txt
   ;;
 tests)
   export PMAF_TOL_REPORT=$PWD/$O/tolerance_report.jsonl

@@ -340,9 +340,18 @@ def run_workload(ctx, spec, args, full):
     if coupled:
         if n_part > 1:
             box = [None] * world
-            dist.all_gather_object(box, planner.peer_export(n_part) if part else None)
+            dist.all_gather_object(box, (planner.peer_export(n_part), planner.peer_info()["fine_grained"]) if part else None)
+            # peers on different GPUs store into each other's inboxes while the kernels run: that needs fine-grained
+            # inboxes on both sides (pmaf_peer_connect refuses otherwise). Every rank sees the same table, so the decision
+            # to skip the sub-configuration is the same everywhere -- a skipped record instead of a failed job.
+            if not all(box[r][1] for r in ranks) and os.environ.get("PMAF_BENCH_SINGLE_DEVICE") != "1":
+                ctx.barrier()
+                if part:
+                    planner.close()
+                return {"skipped": "peer mailboxes across GPUs need fine-grained device memory that this runtime could not "
+                                   "export (pmaf_peer_info); C4 one arm per GPU not timed"} if rank == 0 else None
             if part:
-                planner.peer_connect(n_part, me, [box[r] for r in ranks])
+                planner.peer_connect(n_part, me, [box[r][0] for r in ranks])
         elif part:
             planner.peer_connect(1, 0, [planner.peer_export(1)])
         if part:
@@ -687,7 +696,9 @@ def main():
         subs.update(skipped)
 
     line = None
-    if rank == 0:
+    if rank == 0 and "skipped" in head:      # (--config C4 on GPUs whose runtime cannot export fine-grained inboxes)
+        line = json.dumps({"metric": "agent_rollouts_per_s", "value": None, "skipped": head["skipped"], "n_gpus": world})
+    elif rank == 0:
         idle, sc, P = head.pop("_idle"), head.pop("_scene"), head.pop("_P")
         wp_lib, wp_wall = head.pop("_wp")
         idle_enq, idle_sp = head.pop("_idle_lib")

@@ -62,6 +62,11 @@ __device__ __forceinline__ V3 normalized(V3 a) {
 __device__ __forceinline__ V3 cross(V3 a, V3 b) {
   return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
 }
+// v x (c x v), the circular term's direction (B/src/cf_agent.cpp:103). CONTRACTED policy only: for the unit vector v the
+// triple product is c (v.v) - v (v.c) = c - v (v.c) up to the rounding of |v| = 1 -- one dot product and three fused
+// multiply-adds instead of two cross products (18 -> 6 instructions per obstacle slot)
+template <int MATH>
+__device__ __forceinline__ V3 unit_triple(V3 v, V3 c);
 // std::max(a,b) / std::min(a,b) semantics incl. NaN behaviour
 __device__ __forceinline__ double smax(double a, double b) { return (a < b) ? b : a; }
 __device__ __forceinline__ double smin(double a, double b) { return (b < a) ? b : a; }
@@ -297,6 +302,15 @@ template <> struct Mth<MATH_FAST> {
 };
 
 template <> struct Mth<MATH_FMA> : Mth<MATH_FAST> {};
+template <int MATH>
+__device__ __forceinline__ V3 unit_triple(V3 v, V3 c) {
+  if constexpr (MATH == MATH_FMA) {
+    const double vc = dot(v, c);
+    return mk(c.x - v.x * vc, c.y - v.y * vc, c.z - v.z * vc);
+  } else {
+    return cross(v, cross(c, v));
+  }
+}
 
 // exp() of attractorForceScaling (B/src/cf_agent.cpp:220). The reference calls the platform libm, whose last bit is
 // not portable; this is a table-free exp in correctly rounded IEEE operations only (multiply, round-to-nearest-even

@@ -217,7 +217,7 @@ __device__ __forceinline__ void circ_and_scale_grp(lmask act_m, int sub, int grp
 #endif
       const V3 cur = PMAF_GRP_CURVEC ? current_vector_grp<MATH>(type, rv, nv, zrv, g, ron, rot)
                                      : current_vector<MATH, true>(type, rv, g, ron, rot);
-      const V3 c = MT::div_pos(k_circ, d * d) * cross(nv, cross(cur, nv));   // d >= 1e-5
+      const V3 c = MT::div_pos(k_circ, d * d) * unit_triple<MATH>(nv, cur);   // nv x (cur x nv); d >= 1e-5
       const lmask m = in_m & PMAF_BAL(zrv != 0);   // vel_norm != 0, B/src/cf_agent.cpp:98
       if (PMAF_LANE(m)) {
         PMAF_BOUND(count + __popcll(m & below) < LPA * TILES);

@@ -451,7 +451,7 @@ __device__ __forceinline__ void circ_and_scale_w64(int lane, V3 p, V3 v, double 
 #ifdef PMAF_ABL_NOCIRC   // timing experiments only (tools/ablate.sh): no circular-term arithmetic, list traffic kept
     const V3 c = rv; (void)nv; (void)cur; (void)rot;
 #else
-    const V3 c = MT::div_pos(k_circ, d_t[t] * d_t[t]) * cross(nv, cross(cur, nv));  // d >= 1e-5
+    const V3 c = MT::div_pos(k_circ, d_t[t] * d_t[t]) * unit_triple<MATH>(nv, cur);  // nv x (cur x nv); d >= 1e-5
 #endif
     // compact the contributing terms, ascending obstacle index
     const unsigned long long m = in_m[t] & PMAF_BAL(zrv != 0);   // vel_norm != 0, B/src/cf_agent.cpp:98

@@ -156,10 +156,11 @@ POLICIES = {"strict": {}, "contracted": {"contracted": True}}
 # deterministic: same inputs, same kernels, same bits on every box). All of them are scenes whose rollouts are chaotic --
 # the strict kernels against another libm's exp already show divergent NON-selected agents there -- and the contracted
 # arithmetic perturbs ~30x more operations per step:
-#   C5 (scene 1 of the 8): selected trajectory 1.4e-3 m, 10 % of that population's rollouts differ by > 1e-5 m
-#   sim_kobo_dyn_spheres1 / 2 (H = 1500, moving spheres): selected trajectory 0.10 / 0.12 m, no best-index difference,
+#   C5 (scene 1 of the 8): selected trajectory 3.2e-3 m, 10 % of that population's rollouts differ by > 1e-5 m
+#   sim_kobo_dyn_spheres1 / 2 (H = 1500, moving spheres): selected trajectory 0.22 / 0.23 m, no best-index difference,
 #     set-point sequence identical over 900 ticks
-#   sim_kobo_dyn_spheres3 (H = 1200): a best-index difference at tick 30 with a 10 % cost margin
+#   sim_kobo_dyn_spheres3 (H = 1200): a best-index difference at tick 1 -- where the ORACLE's own evaluation-order
+#     variants flip too (tools/oracle_conditioning.py, profiles/r4_oracle_conditioning.txt)
 # The policy is opt-in for exactly this reason; include/pmaf.h and DESIGN.md say where it holds.
 CONTRACTED_EXCEEDS = {"C5", "sim_kobo_dyn_spheres1", "sim_kobo_dyn_spheres2", "sim_kobo_dyn_spheres3"}
 

@@ -74,6 +74,15 @@ out.append("**Tick latency** on an idle stream. SURVEY §8(d)'s tick — host ca
            % (wp.get("path_bytes", 0), wp.get("n", 0), wp.get("median", float("nan")), wp.get("p90", float("nan")), wp.get("p99", float("nan")),
               wp.get("max", float("nan")), sp.get("n", 0), lib["median"], lib["p90"], lib["p99"], lib["max"], lib["enqueue_median"], R,
               sp["median"], sp["p99"], d["tick_latency_us"]["median"]))
+try:
+    dy = load("%s_bench_c2_dynamic.json" % R)
+    out.append("")
+    out.append("Inputs are resident in HBM when the timed region starts (the static obstacle list is handed over once). With MOVING obstacles the "
+               "caller hands a new list over on every tick -- %d B host -> device, read by the manager kernel out of mapped pinned memory: "
+               "%s rollouts/s, %.4f ms/tick (`profiles/%s_bench_c2_dynamic.json`): the PCIe-inclusive rate of this path."
+               % (7 * 8 * (d["config"]["obstacles"] + 1), k(dy["value"]), dy["ms_per_step"], R))
+except OSError:
+    pass
 out.append("")
 out.append("**Roofline of the dominant kernel (C2 launch).** Algorithmic bytes (SURVEY §8d) %d B ÷ %.1f µs = %.3f GB/s = **%.3g of 8 TB/s** "
            "(`roofline.frac`; rocprofv3 average of the same kernel: %.1f µs). FP64-VALU: %d measured FP64 operations per agent-step "

@@ -30,6 +30,9 @@ misc)
     python tools/agenttime.py C1 C2 C3; python tools/c5agents.py; python tools/launchgap.py; } 2>&1 | grep -v "^$\|amdgpu.ids" > $O/agent_times.txt
   bash tools/fuzz_campaign.sh > $O/fuzz_campaign.txt 2>&1
   ;;
+soak)   # stability of the C2 tick loop: 240 s timed, block times
+  python bench.py --only-headline --min-seconds 240 --steps 2000 --cpu-seconds 0 --flop-ticks 0 > $O/bench_c2_soak_240s.json 2>> $O/bench.err
+  ;;
 asan)   # (build first, here: bash tools/asan.sh build -- lib_asan/ and lib_bounds/ travel with the snapshot)
   bash tools/asan.sh run > /dev/null 2>&1; cp gpurun_out/r4_asan.txt $O/asan.txt
   ;;

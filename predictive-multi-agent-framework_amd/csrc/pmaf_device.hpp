@@ -421,6 +421,48 @@ __device__ __forceinline__ double portable_exp_nonpos(double x, const ExpKLds &K
 template <int MATH = MATH_IEEE>
 __device__ __forceinline__ double portable_exp(double x) { return portable_exp<MATH>(x, exp_consts()); }
 
+// portable_exp_nonpos with the table fetched in STAGES (round 4; the multi-slot wave-per-agent kernels, whose constants
+// come out of LDS at the point of use): every batch of constants is requested one stage before the chain needs it --
+// the reduction's three before the caller forms the argument (exp_head, tied to the argument's INPUT), c11..c8 as soon
+// as the argument exists, c7..c4 behind the rounding, c3 behind the reduction -- so that a lone wave does not sit out an
+// LDS round trip (~20 issue slots) in front of each batch (profiles/r4_c3_strict_steploop.txt showed four
+// ds_read / s_waitcnt pairs a few instructions apart). Same operations in the same order as portable_exp_k: same bits.
+struct ExpHead { double invln2, ln2HI, ln2LO; };
+__device__ __forceinline__ ExpHead exp_head(ExpKLds &K, double &input) {
+  K.tie(input);
+  ExpHead H; H.invln2 = K.get(2); H.ln2HI = K.get(0); H.ln2LO = K.get(1);
+  return H;
+}
+__device__ __forceinline__ ExpHead exp_head(const ExpK &K, double &) {
+  ExpHead H; H.invln2 = K.invln2; H.ln2HI = K.ln2HI; H.ln2LO = K.ln2LO;
+  return H;
+}
+template <class KT>
+__device__ __forceinline__ double portable_exp_nonpos_staged(double x, KT K, const ExpHead H) {
+  K.tie(x);
+  const double c11 = K.get(11), c10 = K.get(10), c9 = K.get(9), c8 = K.get(8);
+  const double xs = __builtin_fmax(x, -708.0);
+  double kf = __builtin_rint(xs * H.invln2);
+  K.tie(kf);
+  const double c7 = K.get(7), c6 = K.get(6), c5 = K.get(5), c4 = K.get(4);
+  double r = __builtin_fma(-kf, H.ln2HI, xs);
+  r = __builtin_fma(-kf, H.ln2LO, r);
+  K.tie(r);
+  const double c3 = K.get(3);
+  double p = c11;
+  p = __builtin_fma(p, r, c10); p = __builtin_fma(p, r, c9); p = __builtin_fma(p, r, c8); p = __builtin_fma(p, r, c7);
+  p = __builtin_fma(p, r, c6); p = __builtin_fma(p, r, c5); p = __builtin_fma(p, r, c4); p = __builtin_fma(p, r, c3);
+  p = __builtin_fma(p, r, 0.5);
+  p = __builtin_fma(p, r, 1.0); p = __builtin_fma(p, r, 1.0);
+  return __builtin_ldexp(p, (int)kf);
+}
+__device__ __forceinline__ double portable_exp_nonpos_staged(double x, const ExpK &K, const ExpHead H) {
+  return portable_exp_nonpos_staged<ExpKRegs>(x, ExpKRegs{K}, H);
+}
+__device__ __forceinline__ double portable_exp_nonpos_staged(double x, const ExpKLds &K, const ExpHead H) {
+  return portable_exp_nonpos_staged<ExpKLds>(x, K, H);
+}
+
 enum : int { T_REAL = 0, T_GOAL = 1, T_OBST = 2, T_GOALOBST = 3, T_VEL = 4, T_RANDOM = 5, T_HAD = 6 };
 
 // population-wide scalars (CfManager::init arguments)

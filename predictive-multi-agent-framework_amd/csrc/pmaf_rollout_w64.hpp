@@ -31,6 +31,8 @@
 // in pmaf_device.hpp (bit-identical results; tests/test_parity_gpu.py compares
 // every kernel variant with the oracle at zero tolerance).
 #pragma once
+#include <type_traits>
+
 #include "pmaf_device.hpp"
 
 namespace pmaf {
@@ -432,7 +434,6 @@ __device__ __forceinline__ void circ_and_scale_w64(int lane, V3 p, V3 v, double 
     }
   }
   PMAF_SEC(ST, 2);
-
   // ======== straight-line region ========
   // ---- circular-field terms (:97-106), evaluated by every lane (lanes outside
   // the shell compute values that go to their scratch entry)
@@ -511,6 +512,8 @@ __device__ __forceinline__ void circ_and_scale_w64(int lane, V3 p, V3 v, double 
 #else
   {
     double m;
+    // (round 4: reading the minimum back earlier -- in front of the circular terms -- costs the one-slot kernels 2-3 %
+    // (C2 222.3 -> 226.3 us: 12 VGPRs more, another schedule) and gains the two-slot kernel 0.2 %: profiles/r4_ab_w64.txt)
     if (LDSMIN) {
       wave_lds_fence();
       m = __longlong_as_double((long long)__hip_atomic_load(min_cell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
@@ -538,7 +541,18 @@ __device__ __forceinline__ void circ_and_scale_w64(int lane, V3 p, V3 v, double 
     const bool stall = (dot(g, v) <= 0.0) && (zv < C.zv09_lt) && (dg > 0.15);  // norm(v) < vmax - 0.1 vmax
     // (shell == 0: nothing is ever inside it, bi stays "none" and w is discarded)
     // (m in [1e-5, shell) whenever an obstacle is in reach; otherwise bi is "none" and w is discarded)
-    const double w1 = 1 - portable_exp_nonpos<MATH>(-MT::div_pos(MT::sqrt_pos(m), C.shell), EK);
+#ifndef PMAF_EXP_STAGED
+#define PMAF_EXP_STAGED 1
+#endif
+    double w1;
+    if (PMAF_EXP_STAGED && TILES >= 2) {   // (constants out of LDS: requested a stage ahead, pmaf_device.hpp)
+      typename std::remove_const<KT>::type EKs = EK;
+      double m_in = m;
+      const ExpHead H = exp_head(EKs, m_in);
+      w1 = 1 - portable_exp_nonpos_staged(-MT::div_pos(MT::sqrt_pos(m_in), C.shell), EKs, H);
+    } else {
+      w1 = 1 - portable_exp_nonpos<MATH>(-MT::div_pos(MT::sqrt_pos(m), C.shell), EK);
+    }
     // |ro| and g.ro of the closest obstacle were computed by the lane that
     // owns it (same operands, same bits as recomputing them here)
     const int bl = bi & 63;

@@ -437,7 +437,13 @@ __device__ __forceinline__ void circ_and_scale_w64(int lane, V3 p, V3 v, double 
   // ======== straight-line region ========
   // ---- circular-field terms (:97-106), evaluated by every lane (lanes outside
   // the shell compute values that go to their scratch entry)
+#ifndef PMAF_MIN_MID
+#define PMAF_MIN_MID 1
+#endif
   int count = 0;
+  double m_mid = 0.0;
+  // (two slots only: the four-slot kernel skips slots that hold nothing inside the shell, the last one included)
+  constexpr bool MIN_MID = PMAF_MIN_MID && TILES == 2;
 #pragma unroll
   for (int t = 0; t < TILES; t++) {
     if (TILES > 2 && in_m[t] == 0ull) continue;  // no term from this slot (wave-uniform; 2 slots: both in one block)
@@ -449,6 +455,16 @@ __device__ __forceinline__ void circ_and_scale_w64(int lane, V3 p, V3 v, double 
     MT::norm_rcp_zpos(zrv, vn, rvn);   // (zrv == 0: garbage that goes to the lane's scratch entry, has_c below)
     const V3 nv = MT::div3_n_pos(rv, vn, rvn);
     const V3 cur = current_vector<MATH, true>(type, rv, g, ron_t[t], rot);   // (normalized() by a select on the divisor: 4 instructions less)
+    // (round 4) multi-slot kernels: the wave minimum's read-back is pinned HERE -- between the last slot's normalisations and
+    // its cross products (a scheduling barrier: nothing moves across) -- so that its LDS round trip runs under ~30
+    // instructions of arithmetic instead of in front of the closest-obstacle selection (the listing showed ds_read /
+    // s_waitcnt lgkmcnt(0) five instructions apart). C3 979.3 -> 963.1 us; the one-slot kernels lose 0.3-0.5 % with it
+    // (profiles/r4_ab_w64.txt) and keep the read where it was.
+    if (LDSMIN && MIN_MID && t == TILES - 1) {
+      wave_lds_fence();
+      m_mid = __longlong_as_double((long long)__hip_atomic_load(min_cell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+      __builtin_amdgcn_sched_barrier(0);
+    }
 #ifdef PMAF_ABL_NOCIRC   // timing experiments only (tools/ablate.sh): no circular-term arithmetic, list traffic kept
     const V3 c = rv; (void)nv; (void)cur; (void)rot;
 #else
@@ -514,7 +530,9 @@ __device__ __forceinline__ void circ_and_scale_w64(int lane, V3 p, V3 v, double 
     double m;
     // (round 4: reading the minimum back earlier -- in front of the circular terms -- costs the one-slot kernels 2-3 %
     // (C2 222.3 -> 226.3 us: 12 VGPRs more, another schedule) and gains the two-slot kernel 0.2 %: profiles/r4_ab_w64.txt)
-    if (LDSMIN) {
+    if (LDSMIN && MIN_MID) {
+      m = m_mid;
+    } else if (LDSMIN) {
       wave_lds_fence();
       m = __longlong_as_double((long long)__hip_atomic_load(min_cell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
     } else {

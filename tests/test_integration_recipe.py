@@ -144,3 +144,66 @@ def test_compiler_picks_the_facade_with_the_node_include_order():
                         "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(B, "include"), "-I" + chk,
                         "-I" + os.path.join(chk, "eigen3"), os.path.join(chk, "node_style_caller.cpp")], capture_output=True)
     assert r.returncode == 0, r.stderr.decode()
+
+
+@needs_reference
+def test_recipe_through_cmake_on_a_package_with_the_reference_targets(tmp_path):
+    """the recipe run by CMake itself: a package with the reference's targets and source lists (names read from
+    B/CMakeLists.txt; the sources are probes that only include <bimanual_planning_ros/obstacle.h>, the package's own
+    `include/` holds a marker header in the reference's place), its directory-wide include_directories(include), and
+    INTEGRATION.md's snippet verbatim in place of the node's add_executable. From CMake's compile_commands.json: the
+    node's four translation units -- and no other, not even the SAME source file compiled into another target
+    (parameter_manager.cpp: also in dynamic_obstacle_node and vision_interface_node) -- get -DPMAF_USE_EIGEN and this repository's include/ IN FRONT
+    OF the package's; run with exactly those commands the node's probes see the facade's header and every other
+    target's the package's own."""
+    import json
+    import shutil
+    if shutil.which("cmake") is None:
+        pytest.skip("no cmake")
+    ref = targets_with_sources(cmake_commands(open(os.path.join(B, "CMakeLists.txt")).read()))
+    pkg = tmp_path / "pkg"
+    (pkg / "include" / "bimanual_planning_ros").mkdir(parents=True)
+    (pkg / "src").mkdir()
+    (pkg / "include" / "bimanual_planning_ros" / "obstacle.h").write_text("#pragma once\n#define PACKAGE_OWN_OBSTACLE_H 1\n")
+    node_sources = set(targets_with_sources(cmake_commands(recipe_snippet()))[NODE])
+    for srcs in ref.values():   # one probe for every source: which obstacle.h a translation unit sees is read back below
+        for src in srcs:
+            (pkg / src).write_text("#include <bimanual_planning_ros/obstacle.h>\n#ifdef PACKAGE_OWN_OBSTACLE_H\nint saw_package_header;\n"
+                                   "#else\nstatic ghostplanner::cfplanner::Obstacle saw_facade_header;\n#endif\n")
+    lines = ["cmake_minimum_required(VERSION 3.10)", "project(bimanual_planning_ros CXX)", "set(CMAKE_EXPORT_COMPILE_COMMANDS ON)",
+             "set(CMAKE_CXX_STANDARD 17)", "include_directories(include)"]
+    for t, srcs in ref.items():
+        if t == NODE:
+            continue
+        kind = "add_library(%s STATIC" if t in ("utilities", "dual_panda_costp_controller") else "add_executable(%s"
+        lines.append((kind % t) + " " + " ".join(srcs) + ")")
+    snippet = recipe_snippet().replace("set(PMAF_ROOT /opt/pmaf)", "set(PMAF_ROOT %s)" % ROOT)
+    assert ROOT in snippet
+    lines.append(snippet)
+    (pkg / "CMakeLists.txt").write_text("\n".join(lines) + "\n")
+    bld = tmp_path / "build"
+    r = subprocess.run(["cmake", "-S", str(pkg), "-B", str(bld), "-G", "Unix Makefiles"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    cc = json.load(open(bld / "compile_commands.json"))
+    mine_inc, pkg_inc = "-I" + os.path.join(ROOT, "include"), "-I" + str(pkg / "include")
+    chk = os.path.join(ROOT, "tests", "cpp", "eigen_api_check")
+    seen_node = set()
+    for e in cc:
+        rel = os.path.relpath(e["file"], str(pkg))
+        args = e["command"].split()
+        is_node = "CMakeFiles/%s.dir/" % NODE in e["command"]
+        assert ("-DPMAF_USE_EIGEN" in args) == is_node, (rel, e["command"])
+        assert (mine_inc in args) == is_node, (rel, e["command"])
+        assert pkg_inc in args
+        if is_node:
+            seen_node.add(rel)
+            assert args.index(mine_inc) < args.index(pkg_inc), e["command"]
+        # preprocess / check the probe with CMake's own command (+ the API-shape Eigen declarations: no Eigen3 here)
+        out = args[args.index("-o") + 1]
+        cmd = [a for a in args if a not in ("-o", "-c", out)] + ["-I" + chk]
+        c = subprocess.run(cmd + ["-fsyntax-only"], capture_output=True, text=True, cwd=e["directory"])
+        assert c.returncode == 0, (rel, c.stderr[-1500:])
+        c = subprocess.run(cmd + ["-E", "-P"], capture_output=True, text=True, cwd=e["directory"])
+        assert c.returncode == 0, (rel, c.stderr[-1500:])
+        assert ("saw_facade_header" in c.stdout) == is_node and ("saw_package_header" in c.stdout) == (not is_node), rel
+    assert seen_node == node_sources

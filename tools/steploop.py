@@ -102,7 +102,7 @@ def spill_registers(body):
 
 
 def analyse(lines, kernel):
-    """-> [(header line, extent body, all-blocks body)] of the depth-1 loops that store path points, the spill VGPRs,
+    """-> [(header line, extent body, all-blocks body)] of the step loops (the innermost loops of more than 250 instructions), the spill VGPRs,
     the kernel's spill instruction count. extent = header .. last back edge (the laid-out hot path: blocks marked
     unlikely sit behind it); all blocks = every basic block the compiler's loop annotation assigns to the loop, inner
     loops and rare blocks included."""
@@ -132,14 +132,16 @@ def analyse(lines, kernel):
     loops = []
     for lab, e in last_back.items():
         h = label_at[lab]
-        if "Loop Header: Depth=1" not in lines[h]:
+        if "Loop Header: Depth=" not in "".join(lines[h:h + 4]):   # (the annotation of a nested header spans lines)
             continue
         name = lab[2:]   # "BB3_10"
         member = [b for b in blocks if b[0] == h or re.search(r"(Header=|Parent Loop )%s\b" % re.escape(name), b[2])]
         allb = [l for st, en, _ in member for l in lines[st:en] if is_instr(l)]
         extent = [l for l in lines[h:e + 1] if is_instr(l)]
-        if any("global_store_dwordx" in l for l in allb) and len(allb) > 250:
+        if len(allb) > 250:
             loops.append((h, e, extent, allb))
+    # the step loops are the innermost loops of that size (the wave-per-agent kernels wrap them in the path-chunk loop)
+    loops = [L for L in loops if not any(o is not L and L[0] <= o[0] and o[1] <= L[1] for o in loops)]
     loops.sort()
     total_spill_instrs = sum(1 for l in lines[f0:f1] if is_instr(l) and klass(mnemonic(l), l, spills).startswith("SGPR spill"))
     return loops, spills, total_spill_instrs

@@ -61,6 +61,9 @@ struct pmaf_planner {
   bool plain_step = false;     // every k_attr != 0 and unit mass: the wave-per-agent kernels' PLAIN step (pmaf_k_w64.hip)
   bool blocking_wait = false;  // PMAF_FLAG_BLOCKING_WAIT: pmaf_tick sleeps on an event instead of spinning on the mailbox
   bool dpp_sum = true;         // w64 kernels: ordered force sum by the DPP chain (M > 20) or LDS batches
+  // W waves per agent (pmaf_k_mw.hip; 0: the wave-per-agent kernels): 62..244 field obstacles, default or contracted
+  // arithmetic, and every wave of the launch with a SIMD to itself (pick_mw)
+  int mw_waves = 0, mw_per = 0, mw_lds_kb = 0;
   int n_blocks = 0;
   size_t lds_rollout = 0, lds_manager = 0;
   hipModule_t ext_mod = nullptr;       // pmaf_debug_external_rollout: a rollout kernel loaded from a code object file
@@ -312,6 +315,34 @@ static int pick_lpa(int N, int P, int M) {
   return lpa;
 }
 
+// W waves per agent with <= 61 obstacles each (pmaf_k_mw.hip) instead of 2 / 4 obstacle slots per lane of ONE wave:
+// the per-obstacle part of the step runs on W SIMDs at once. Only while the launch leaves every wave a SIMD of its own
+// (N P W <= SIMDs of the device) -- beyond that the multi-slot kernels' single wave per agent wins back.
+// PMAF_MW=0 / 2 / 3 / 4: off / that many waves (tests, timing); PMAF_MW_PER: obstacles per wave (default: even split).
+static void pick_mw(pmaf_planner *h, int N, int P, int M) {
+  h->mw_waves = 0; h->mw_per = 0;
+  if (h->lpa != 64 || h->force_generic || !(h->math == MATH_XACT || h->math == MATH_FMA)) return;
+  if (M < 62 || M > 4 * 64) return;
+  // as few waves as hold the obstacles at 64 per wave (every wave more costs ~0.24 us per step: profiles/r4_ab_mw.txt);
+  // at <= 61 per wave lanes 61..63 stay free for the tail's riders and the sweep's norms ride along (pmaf_k_mw.hip)
+  int waves = (M + 63) / 64;
+  if (waves < 2) waves = 2;
+  const char *e = getenv("PMAF_MW");
+  if (e && e[0]) {
+    const int f = atoi(e);
+    if (f == 0) return;
+    if (f >= waves && f <= 4) waves = f;
+  }
+  // (a CU holds 4 / waves blocks: pmaf_k_mw.hip's launcher enforces it through the LDS request)
+  const long cus = h->D.n_simds / 4, per_cu = 4 / waves;
+  if ((long)N * P > cus * per_cu) return;
+  { const char *lk = getenv("PMAF_MW_LDS_KB"); h->mw_lds_kb = lk ? atoi(lk) : 0; }   // timing experiments
+  int per = (M + waves - 1) / waves;
+  const char *pe = getenv("PMAF_MW_PER");
+  if (pe && atoi(pe) >= per && atoi(pe) <= 64) per = atoi(pe);
+  h->mw_waves = waves; h->mw_per = per;
+}
+
 // fold finished rollout event pairs (oldest first) into the stats; all=true
 // requires the stream to be idle
 static void drain_events(pmaf_planner *h, bool all) {
@@ -360,7 +391,9 @@ static void launch_rollout(pmaf_planner *h) {
                                     h->stream, args, nullptr));
     if (e1) HIP_CHECK(hipEventRecord(e1, h->stream));
     ok = true;
-  } else if (h->lpa == 64 && tiles64 <= 4 && !h->force_generic)
+  } else if (h->mw_waves)
+    ok = pmaf_k_launch_mw(h->D, h->cp, h->mw_waves, h->mw_per, h->math, h->plain_step, h->mw_lds_kb, h->stream, e0, e1);
+  else if (h->lpa == 64 && tiles64 <= 4 && !h->force_generic)
     // ordered force sum: the DPP chain (h->dpp_sum, see pmaf_create), LDS batches on request (pmaf_rollout_w64.hpp)
     ok = pmaf_k_launch_w64(h->D, h->cp, tiles64, h->math, h->dpp_sum, h->plain_step, h->lds_rollout, h->stream, e0, e1);
   else if (!h->force_generic && (h->lpa == 32 || h->lpa == 16 || h->lpa == 8) && (M + h->lpa - 1) / h->lpa <= 4)
@@ -782,6 +815,7 @@ int pmaf_create(const pmaf_params *prm, pmaf_planner **out) {
       HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device));
       D.n_simds = 4 * (cus > 0 ? cus : 256);
     }
+    pick_mw(h, N, P, M);
     REQUIRE((M + h->lpa - 1) / h->lpa <= 64, "pmaf_create: too many obstacles for this lanes_per_agent (need M <= 64*lanes_per_agent)");
     h->n_blocks = (N * h->lpa + 63) / 64;
     {
@@ -2149,6 +2183,14 @@ int pmaf_get_launch_config(pmaf_planner *h, int32_t *lanes_per_agent, int32_t *n
     if (lanes_per_agent) *lanes_per_agent = h->lpa;
     if (n_blocks) *n_blocks = h->n_blocks * h->D.P;
     if (lds_bytes) *lds_bytes = (int32_t)h->lds_rollout;
+  });
+}
+
+int pmaf_get_waves_per_agent(pmaf_planner *h, int32_t *waves_per_agent, int32_t *obstacles_per_wave) {
+  return guarded([&] {
+    REQUIRE(h, "pmaf_get_waves_per_agent: NULL handle");
+    if (waves_per_agent) *waves_per_agent = h->mw_waves ? h->mw_waves : 1;
+    if (obstacles_per_wave) *obstacles_per_wave = h->mw_waves ? h->mw_per : h->D.n_obs - 1;
   });
 }
 

@@ -856,6 +856,15 @@ bool pmaf_k_launch_w64(const DevView &D, const CostParams &cp, int tiles, int ma
                       : pmaf_k_launch_w64_m2_tn(D, cp, tiles, dppsum, plain, lds, s, e0, e1);
 }
 
+bool pmaf_k_launch_mw_m2(const DevView &, const CostParams &, int, int, bool, int, hipStream_t, hipEvent_t, hipEvent_t);
+bool pmaf_k_launch_mw_m3(const DevView &, const CostParams &, int, int, bool, int, hipStream_t, hipEvent_t, hipEvent_t);
+bool pmaf_k_launch_mw(const DevView &D, const CostParams &cp, int waves, int per, int math, bool plain, int lds_kb,
+                      hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
+  if (math == MATH_FMA) return pmaf_k_launch_mw_m3(D, cp, waves, per, plain, lds_kb, s, e0, e1);
+  if (math == MATH_XACT) return pmaf_k_launch_mw_m2(D, cp, waves, per, plain, lds_kb, s, e0, e1);
+  return false;
+}
+
 bool pmaf_k_launch_grp(const DevView &D, const CostParams &cp, int lpa, int tiles, int math, int n_blocks, size_t lds,
                        hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
   if (math == MATH_IEEE) return pmaf_k_launch_grp_m0(D, cp, lpa, tiles, n_blocks, lds, s, e0, e1);

@@ -107,6 +107,7 @@ SYMBOLS = {
     "pmaf_reset_kernel_stats": (C.c_int, [_V]),
     "pmaf_get_launch_count": (C.c_int, [_V, C.POINTER(C.c_int64)]),
     "pmaf_get_launch_config": (C.c_int, [_V, _ip, _ip, _ip]),
+    "pmaf_get_waves_per_agent": (C.c_int, [_V, _ip, _ip]),
     "pmaf_debug_math": (C.c_int, [C.c_int32, C.c_int32, _dp, _dp, _dp]),
     "pmaf_debug_external_rollout": (C.c_int, [_V, C.c_char_p, C.c_char_p]),
     "pmaf_get_health": (C.c_int, [_V, _ip]),
@@ -564,7 +565,10 @@ class PmafPlanner:
     def launch_config(self):
         a, b, c = C.c_int32(0), C.c_int32(0), C.c_int32(0)
         self._chk(self.L.pmaf_get_launch_config(self._h, C.byref(a), C.byref(b), C.byref(c)))
-        return dict(lanes_per_agent=a.value, n_blocks=b.value, lds_bytes=c.value)
+        w, pw = C.c_int32(0), C.c_int32(0)
+        self._chk(self.L.pmaf_get_waves_per_agent(self._h, C.byref(w), C.byref(pw)))
+        return dict(lanes_per_agent=a.value, n_blocks=b.value, lds_bytes=c.value, waves_per_agent=w.value,
+                    obstacles_per_wave=pw.value)
 
 
 HOST_ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)

@@ -118,9 +118,12 @@ def test_c2_dynamic_obstacles(pmaf, oracle, scenes):
     hip.close()
 
 
+@pytest.mark.parametrize("one_wave", [False, True])
 @pytest.mark.parametrize("lpa", [0, 8, 64])
-def test_c3_256_agents_128_obstacles(pmaf, oracle, scenes, lpa):
+def test_c3_256_agents_128_obstacles(pmaf, oracle, scenes, lpa, monkeypatch, one_wave):
     """BASELINE config C3 (LDS-tiled obstacle sweep: several tiles per lane)"""
+    if one_wave:   # the one-wave kernels (2 / 4 obstacle slots per lane) instead of k_rollout_mw
+        monkeypatch.setenv("PMAF_MW", "0")
     sc = scenes.config_scene("C3")
     hip, _ = run_both(pmaf, oracle, scenes, sc, 2, lanes_per_agent=lpa)
     hip.close()
@@ -283,12 +286,15 @@ def test_error_reporting(pmaf, scenes):
 # ---------------------------------------------------------------------------
 # reference-faithful oracle (libm exp): north-star tolerance on BASELINE configs
 # ---------------------------------------------------------------------------
+@pytest.mark.parametrize("one_wave", [False, True])
 @pytest.mark.parametrize("dynamic", [False, True])
-def test_c3_twelve_ticks_latches_and_hysteresis(pmaf, oracle, scenes, dynamic):
+def test_c3_twelve_ticks_latches_and_hysteresis(pmaf, oracle, scenes, dynamic, monkeypatch, one_wave):
     """C3 in depth: 12 ticks (12 rollouts of 256 agents x 500 steps through 128
     obstacles, 11 of them scored) so that rotation vectors latched in one tick
     persist into the next, known flags travel real agent -> agents, and the
     0.9 hysteresis is exercised at M = 128; static and moving obstacles"""
+    if one_wave:   # the one-wave kernels (2 / 4 obstacle slots per lane) instead of k_rollout_mw
+        monkeypatch.setenv("PMAF_MW", "0")
     sc = scenes.config_scene("C3", scene_id=1, dynamic=dynamic)
     hip, ora = run_both(pmaf, oracle, scenes, sc, 12, dynamic=dynamic)
     # latches did persist: some agents know obstacles the real agent does not know yet
@@ -651,11 +657,14 @@ def test_inputs_outside_the_supported_numeric_range_are_rejected(pmaf, scenes):
     hip.close()
 
 
+@pytest.mark.parametrize("one_wave", [False, True])
 @pytest.mark.parametrize("m,lpa", [(200, 0), (300, 0), (70, 32), (40, 8)])
-def test_large_and_ragged_obstacle_counts(pmaf, oracle, scenes, m, lpa):
+def test_large_and_ragged_obstacle_counts(pmaf, oracle, scenes, m, lpa, monkeypatch, one_wave):
     """obstacle counts that exercise 4 slots per lane (M = 200: w64 TILES 4;
     M = 70 @ 32 lanes and M = 40 @ 8 lanes: group kernel TILES 4 / generic),
     the generic fallback (M = 300 > 4 x 64) and ragged last tiles"""
+    if one_wave:   # the one-wave kernels (2 / 4 obstacle slots per lane) instead of k_rollout_mw
+        monkeypatch.setenv("PMAF_MW", "0")
     sc = scenes.synthetic_scene(20, 120, m, 6, m)
     hip, _ = run_both(pmaf, oracle, scenes, sc, 3, lanes_per_agent=lpa)
     hip.close()
@@ -840,8 +849,9 @@ def test_agent_range_sharding_equals_single_population(pmaf, oracle, scenes, cut
         s.planner.close()
 
 
+@pytest.mark.parametrize("one_wave", [False, True])
 @pytest.mark.parametrize("lpa,force_generic", [(0, False), (16, False), (8, False), (0, True)])
-def test_closest_other_ties_and_far_obstacles(pmaf, oracle, scenes, monkeypatch, lpa, force_generic):
+def test_closest_other_ties_and_far_obstacles(pmaf, oracle, scenes, monkeypatch, lpa, force_generic, one_wave):
     """the Obstacle / GoalObstacle heuristics latch against the nearest OTHER
     obstacle (cf_agent.cpp:434-446, :480-492: ascending scan, strict `>`, 100 m
     initial minimum). The tuned kernels do that scan cooperatively over the
@@ -849,6 +859,8 @@ def test_closest_other_ties_and_far_obstacles(pmaf, oracle, scenes, monkeypatch,
     exact distance ties (lowest index wins, across lanes and across slots of one
     lane), a neighbour exactly 100 m away (not accepted) and obstacles with no
     neighbour inside 100 m (index 0, which may be the obstacle itself)."""
+    if one_wave:   # the one-wave kernels (2 / 4 obstacle slots per lane) instead of k_rollout_mw
+        monkeypatch.setenv("PMAF_MW", "0")
     if force_generic:
         monkeypatch.setenv("PMAF_FORCE_GENERIC", "1")
     types = np.array([2, 3, 2, 3, 5, 6, 1, 4], dtype=np.int32)
@@ -921,13 +933,16 @@ def test_signed_zero_coordinates_of_obstacles_at_rest(pmaf, oracle, scenes, lpa)
     hip.close()
 
 
+@pytest.mark.parametrize("one_wave", [False, True])
 @pytest.mark.parametrize("m", [59, 60, 61, 62, 63, 64, 65])
 @pytest.mark.parametrize("dynamic", [False, True])
-def test_idle_lane_riders_at_the_obstacle_count_boundary(pmaf, oracle, scenes, m, dynamic):
+def test_idle_lane_riders_at_the_obstacle_count_boundary(pmaf, oracle, scenes, m, dynamic, monkeypatch, one_wave):
     """the one-slot wave-per-agent kernel runs the goal distance / direction, the
     speed clamp and the attractor speed limit in lanes 63 / 62 / 61 of the sweep's
     norm sequence, so it takes at most 61 field obstacles; 62...64 go to the
     two-slot kernel (which packs the three riders into a sequence of their own)"""
+    if one_wave:   # the one-wave kernels (2 / 4 obstacle slots per lane) instead of k_rollout_mw
+        monkeypatch.setenv("PMAF_MW", "0")
     sc = scenes.synthetic_scene(12, 90, m, 6, 100 + m, dynamic=dynamic)
     hip, _ = run_both(pmaf, oracle, scenes, sc, 3, dynamic=dynamic, lanes_per_agent=64)
     assert hip.launch_config()["lanes_per_agent"] == 64
@@ -1222,13 +1237,16 @@ def test_blocking_wait_flag_gives_the_same_results(pmaf, oracle, scenes):
     hip.close()
 
 
+@pytest.mark.parametrize("one_wave", [False, True])
 @pytest.mark.parametrize("m_field", [70, 128, 200])
-def test_closest_other_table_life_cycle(pmaf, oracle, scenes, m_field):
+def test_closest_other_table_life_cycle(pmaf, oracle, scenes, m_field, monkeypatch, one_wave):
     """DevView::closest_idx (multi-slot wave-per-agent kernels): k_manager computes the Obstacle / GoalObstacle
     heuristics' closest-other answers once per NEW obstacle list at rest, and the rollouts' first-contact latches read
     them instead of scanning (B/src/cf_agent.cpp:434-446 / :480-492). Every agent an Obstacle or GoalObstacle one; the
     list stays, moves to other rest positions, starts moving (no table: the scan), comes to rest again, and a handle
     restored from a checkpoint carries on -- all bit-exact against the oracle, rotation vectors included."""
+    if one_wave:   # the one-wave kernels (2 / 4 obstacle slots per lane) instead of k_rollout_mw
+        monkeypatch.setenv("PMAF_MW", "0")
     N, H = 10, 90
     types = np.array([2, 3] * (N // 2), dtype=np.int32)
     sc = scenes.synthetic_scene(N, H, m_field, 6, 123 + m_field, agent_types=types)

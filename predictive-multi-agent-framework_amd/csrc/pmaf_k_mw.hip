@@ -2,25 +2,30 @@
 // 256 agents x 500 steps x 128 obstacles) and its launcher. Compiled per arithmetic policy (-DPMAF_MW_MATH=2|3,
 // csrc/build.sh; 3 with -ffp-contract=fast); each object defines pmaf_k_launch_mw_m<policy>.
 //
-// Why: with 62..244 field obstacles the wave-per-agent kernel holds 2 or 4 obstacle slots per lane and its lone wave
-// executes the per-obstacle instructions of every slot one after the other (C3: 769 instructions per step against the
-// one-slot kernel's 447, profiles/r4_c3_strict_steploop.txt) while three quarters of the chip's 1024 SIMDs idle (256
-// waves). Here an agent is a BLOCK of W waves on W SIMDs of one CU and every wave runs the ONE-slot step on its own
-// <= 61 obstacles (lanes 61..63 stay the tail's riders, pmaf_k_w64.hip). What an agent-step needs from ALL obstacles
-// is exchanged ONCE per step through LDS with a single s_barrier:
+// Why: with 62..256 field obstacles the wave-per-agent kernel holds 2 or 4 obstacle slots per lane and its lone wave
+// issues the per-obstacle instructions of every slot (C3: 769 instructions per step against the one-slot kernel's 447,
+// profiles/r4_c3_strict_steploop.txt) while three quarters of the chip's 1024 SIMDs idle. Here an agent is a BLOCK of
+// W = ceil(M / 64) waves on W SIMDs of one CU and every wave runs the ONE-slot step on its own <= 64 obstacles (<= 61:
+// lanes 61..63 stay the tail's riders and the sweep's norms ride in the tail's sequence, pmaf_k_w64.hip; 62..64: the
+// sweep takes its own). What an agent-step needs from ALL obstacles is exchanged ONCE per step through LDS with a
+// single s_barrier:
 //   pre-barrier  (wave-local) sweep, first-contact latches, circular-field terms compacted into the wave's OWN list
-//                (ascending obstacle index), the wave's closest-obstacle record {min distance, index, |ro|, g.ro, count};
+//                (ascending obstacle index), attractorForceScaling's weight for the wave's OWN closest obstacle, the
+//                wave's record {min distance, weight, has-candidate, count};
 //   barrier      s_waitcnt lgkmcnt(0) + s_barrier (path stores are NOT drained);
-//   post-barrier (every wave, redundantly, on identical operands => identical bits in every wave) the global closest
-//                obstacle out of the W records, attractorForceScaling's chain, the ordered force sum over list 0, list 1,
-//                ... (= ascending obstacle index, the reference's `force_ += curr_force` order), then the tail.
+//   post-barrier (every wave, redundantly, on identical operands => identical bits in every wave) the weight of the
+//                first wave that holds the agent's minimum, the ordered force sum over list 0, list 1, ... (= ascending
+//                obstacle index, the reference's `force_ += curr_force` order), then the tail.
 // Every wave therefore carries the full agent state and no second hand-off is needed. Records and lists are double
 // buffered on the parity of the exchange count: a wave that is one exchange ahead writes the other buffer.
-// The earlier two-wave experiments (NOTES: full split +14 %, helper wave +24 %) split the step by FUNCTION, which
-// shortens no chain; this one splits the per-obstacle work, which is most of a multi-slot step.
-// Bit-exact with the oracle like every other kernel (tests/test_parity_gpu.py runs C3 and the 200 / 244-obstacle
-// cases through it); the multi-slot kernels stay for launches with more than one wave per SIMD, moving-obstacle
-// searches, policies 0 / 1 and PMAF_MW=0.
+// What it buys and what it cannot (profiles/r4_ab_mw.txt): the step's critical path -- sweep, circular terms, ordered sum,
+// tail: dependent chains -- is as long as before; only the ISSUE of the per-obstacle instructions is spread over W SIMDs.
+// The one-wave two-slot kernel already hides most of its second slot in the first slot's dependency bubbles, so C3
+// (128 obstacles) gains 5 %; 129..256 obstacles (four slots per lane) gain 26..32 %, 62..122 gain 11..13 %. The earlier
+// two-wave experiments (NOTES: full split +14 %, helper wave +24 %) split the step by FUNCTION, which shortens no chain.
+// Bit-exact with the oracle like every other kernel (tests/test_mw_gpu.py; tests/test_parity_gpu.py runs its
+// many-obstacle cases through this kernel AND, with PMAF_MW=0, through the one-wave kernels, which stay for launches
+// that cannot give every wave a SIMD of its own and for policies 0 / 1).
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 
@@ -48,7 +53,6 @@ struct MwTimers { unsigned long long t0 = 0, drain = 0, wait = 0, n = 0; };
 #else
 struct MwTimers {};
 #endif
-#define PMAF_MWT(T, k)
 
 // all waves of the block; LDS traffic only (the path stores stay in flight)
 __device__ __forceinline__ void mw_barrier(MwTimers &TM) {
@@ -269,7 +273,6 @@ __device__ __forceinline__ void circ_and_scale_mw(const int lane, const int w, c
   asm volatile("s_nop 0" : "+v"(acc));
   F = mk(readlane_d(acc, 0), readlane_d(acc, 16), readlane_d(acc, 32));
   scale = (sqn(F) >= C.zf_gt) ? sc : scale;  // norm(F) > 1e-5
-  PMAF_MWT(TM, 3);
 }
 
 // the step loop: rollout_w64_body's one-slot (PRE) loop on W waves (pmaf_k_w64.hip has the commentary of every block)
@@ -378,7 +381,6 @@ __device__ __forceinline__ void rollout_mw_body(const DevView &D, const CostPara
   TM.t0 = __builtin_amdgcn_s_memtime();
 #endif
   while ((dg > 0.1) && (n < D.cap)) {
-    PMAF_MWT(TM, 0);
     const lmask gate_m = ~(PMAF_BAL(dg < C.approach) | (PMAF_BAL(zv < C.zvhalf_lt) & PMAF_BAL(z_init < C.zinit_lt)));
     V3 F = mk(0.0, 0.0, 0.0);
     double scale = 1.0;
@@ -452,7 +454,6 @@ __device__ __forceinline__ void rollout_mw_body(const DevView &D, const CostPara
       sent_p = sent_p + sent_v * C.dt;
       repel = sentinel_repel_m<MATH>(p, C, k_repel, sent_p, sent_r, zsent_lt, inv_shell);
     }
-    PMAF_MWT(TM, 4);
   }
 #ifdef PMAF_MW_TIMERS
   if (lane == 0 && pop == 0 && (a == 7 || a == 2))
@@ -535,7 +536,7 @@ bool PMAF_MW_LAUNCH(const DevView &D, const CostParams &cp, int waves, int per, 
                                        (size_t)(mpd / 2 + 8));
   // Placement: the W waves of a block want a SIMD each, so a CU (4 SIMDs, 160 KB of LDS) should hold 4 / W blocks and no
   // more; the LDS request enforces it whatever the dispatcher would do by itself: 72 KB (two blocks fit, three do not)
-  // for two waves, 96 KB (one block) for three and four. (tools/dbg/mwplace.hip: on an otherwise idle GPU the
+  // for two waves, 96 KB (one block) for three and four. (tools/mwplace.hip: on an otherwise idle GPU the
   // dispatcher spreads 256 blocks over 256 CUs and a block's waves over distinct SIMDs without it, too.)
   // `lds_kb`: the caller's override (0: this rule; timing experiments).
   size_t need = lds;

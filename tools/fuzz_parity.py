@@ -15,7 +15,7 @@ only = int(sys.argv[3]) if len(sys.argv) > 3 else -1
 bad = 0
 t0 = time.time()
 for trial in range(n_trials):
-    N = int(rng.integers(1, 40)); M = int(rng.choice([0, 1, 2, 5, 9, 17, 32, 33, 63, 64, 65, 100, 128, 129, 150]))
+    N = int(rng.integers(1, 40)); M = int(rng.choice([0, 1, 2, 5, 9, 17, 32, 33, 62, 63, 64, 65, 100, 122, 123, 128, 129, 150, 192, 200, 256]))
     H = int(rng.integers(5, 160)); dyn = bool(rng.integers(0, 2))
     if rng.integers(0, 25) == 0:   # a large population (multi-block launches of the group kernels), short horizon
         N = int(rng.integers(200, 1500)); H = int(rng.integers(5, 30)); M = int(rng.choice([3, 17, 32, 40]))
@@ -43,6 +43,8 @@ for trial in range(n_trials):
     if lpa and (M + lpa - 1) // max(lpa, 1) > 64: lpa = 0
     ticks = int(rng.integers(1, 6)) if rng.integers(0, 8) else int(rng.integers(10, 40))
     ieee = bool(rng.integers(0, 6) == 0)
+    # 62..256 obstacles: the split kernel with the fewest waves (default), with more waves than needed, or the one-wave kernels
+    os.environ["PMAF_MW"] = str(rng.choice(["", "", "0", "3", "4"]))
     if only >= 0 and trial != only: continue
     try:
         hip = pm.PmafPlanner(sc, device=0, mgr_init_pos=sc["start"], lanes_per_agent=lpa, ieee_sequences=ieee)

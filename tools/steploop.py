@@ -29,7 +29,8 @@ UNITS = [
                                      "-mllvm", "-align-all-nofallthru-blocks=6"],
      {"C3 k_rollout_w64<2,2,dpp,plain>": "_Z13k_rollout_w64ILi2ELi2ELb1ELb1EEv7DevView10CostParams"}),
     ("c3_mw_strict", "pmaf_k_mw.hip", ["-DPMAF_MW_MATH=2"],
-     {"C3 k_rollout_mw<3,2,plain>": "_Z12k_rollout_mwILi3ELi2ELb1EEv7DevView10CostParamsi"}),
+     {"C3 k_rollout_mw<2,2,plain,64 per wave>": "_Z12k_rollout_mwILi2ELi2ELb1ELb0EEv7DevView10CostParamsi",
+      "M <= 122 k_rollout_mw<2,2,plain,riders>": "_Z12k_rollout_mwILi2ELi2ELb1ELb1EEv7DevView10CostParamsi"}),
     ("c5_strict", "pmaf_k_grp.hip", ["-DPMAF_GRP_MATH=2"],
      {"C5 k_rollout_grp<16,2,2>": "_Z13k_rollout_grpILi16ELi2ELi2EEv7DevView10CostParams"}),
     ("c2c3_contracted", "pmaf_k_w64.hip", ["-DPMAF_W64_MATH=3", "-ffp-contract=fast"],

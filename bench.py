@@ -123,13 +123,17 @@ def kernel_name_of(cfg, n_obs, math=2):
     if 62 <= n_obs - 1 <= 64:
         tiles = 2
     generic = os.environ.get("PMAF_FORCE_GENERIC") == "1"
+    plain = os.environ.get("PMAF_PLAIN_STEP", "1")[:1] != "0"
+    if cfg.get("waves_per_agent", 1) > 1:   # 62..256 obstacles, every wave with a SIMD of its own (pmaf_get_waves_per_agent)
+        # <W, MATH, PLAIN, PRE>: PRE = <= 61 obstacles per wave (the riders' lanes are free)
+        return "k_rollout_mw<%d, %d, %s, %s>" % (cfg["waves_per_agent"], math, "true" if plain else "false",
+                                                  "true" if cfg["obstacles_per_wave"] <= 61 else "false")
     if cfg["lanes_per_agent"] == 64 and tiles <= 4 and not generic:
         t = 1 if tiles <= 1 else 2 if tiles == 2 else 4
         dpp = True    # (rounds 1-2: LDS batches for <= 20 obstacles; round 3: the DPP chain for every count)
         if os.environ.get("PMAF_SUM"):
             dpp = t > 1 or os.environ["PMAF_SUM"].startswith("d")
         # <TILES, MATH_XACT, DPPSUM, PLAIN>; the bench scenes have k_attr != 0 and unit mass = the PLAIN step
-        plain = os.environ.get("PMAF_PLAIN_STEP", "1")[:1] != "0"
         return "k_rollout_w64<%d, %d, %s, %s>" % (t, math, "true" if dpp else "false", "true" if plain else "false")
     if cfg["lanes_per_agent"] in (8, 16, 32) and (n_obs - 2) // cfg["lanes_per_agent"] + 1 <= 4 and not generic:
         tl = (n_obs - 2) // cfg["lanes_per_agent"] + 1

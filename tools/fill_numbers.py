@@ -34,7 +34,7 @@ d = load("%s_bench_c2_driver_flags.json" % R)
 c3, c5 = load("%s_bench_c3.json" % R), load("%s_bench_c5x8.json" % R)
 cf = d["configs"]
 t2, n2 = trace_avg("c2", "k_rollout_w64<1, 2, true, true>")
-t3, n3 = trace_avg("c3", "k_rollout_w64<2, 2, true, true>")
+t3, n3 = trace_avg("c3", "k_rollout_mw<2, 2, true, false>")
 t5, n5 = trace_avg("c5", "k_rollout_grp<16, 2, 2>")
 rf, fv, cb = d["roofline"], d["fp64_valu"], d["cpu_baseline"]
 sp = d["setpoint_latency_us"]
@@ -43,13 +43,13 @@ kt = (cf.get("C1") or {}).get("kernel_timing") or {}
 rows = [
     ("**C2 64 × 200 × 32** (headline, `--steps 20 --warmup 5`)", d["value"], d["ms_per_step"], "`k_rollout_w64<1,2,true,true>` %.1f / %.1f (%d calls)" % (rf["avg_kernel_us"], t2, n2)),
     ("C1 16 × 100 × 9 (sub-record)", cf["C1"]["rollouts_per_s"], cf["C1"]["ms_per_tick"], "`k_rollout_w64<1,2,true,true>` %.1f" % cf["C1"]["avg_kernel_us"]),
-    ("C3 256 × 500 × 128 (sub-record / own run)", cf["C3"]["rollouts_per_s"], cf["C3"]["ms_per_tick"], "`k_rollout_w64<2,2,true,true>` %.1f / own run %.1f / %.1f (%d calls)" % (cf["C3"]["avg_kernel_us"], c3["roofline"]["avg_kernel_us"], t3, n3)),
+    ("C3 256 × 500 × 128 (sub-record / own run)", cf["C3"]["rollouts_per_s"], cf["C3"]["ms_per_tick"], "`k_rollout_mw<2,2,true,false>` %.1f / own run %.1f / %.1f (%d calls)" % (cf["C3"]["avg_kernel_us"], c3["roofline"]["avg_kernel_us"], t3, n3)),
     ("C5 8 × 1024 × 200 × 32 on one GPU (sub-record / own run)", cf["C5_sharded"]["rollouts_per_s"], cf["C5_sharded"]["ms_per_tick"], "`k_rollout_grp<16,2,2>` %.1f / own run %.1f / %.1f (%d calls)" % (cf["C5_sharded"]["avg_kernel_us"], c5["roofline"]["avg_kernel_us"], t5, n5)),
     ("C4 dual arm 2 × 256 × 200 × 32, one GPU, set-points through the peer mailboxes", cf["C4"]["rollouts_per_s"], cf["C4"]["ms_per_tick"], "`k_rollout_w64<1,2,true,true>` %.1f; header wait %.2f µs median / %.2f p99, publish %.2f µs" % (
         cf["C4"]["avg_kernel_us"], cf["C4"]["header_exchange_us"]["wait_median"], cf["C4"]["header_exchange_us"]["wait_p99"], cf["C4"]["header_exchange_us"]["publish_median"])),
 ]
 for name, key, kn in (("C2 contracted policy (opt-in, tolerance parity: §4)", "C2_contracted", "k_rollout_w64<1,3,true,true>"),
-                      ("C3 contracted", "C3_contracted", "k_rollout_w64<2,3,true,true>"),
+                      ("C3 contracted", "C3_contracted", "k_rollout_mw<2,3,true,false>"),
                       ("C5 × 8 contracted (parity NOT met on scene 1: §4)", "C5_sharded_contracted", "k_rollout_grp<16,2,3>")):
     if key in cf and "rollouts_per_s" in cf[key]:
         rows.append((name, cf[key]["rollouts_per_s"], cf[key]["ms_per_tick"], "`%s` %.1f" % (kn, cf[key]["avg_kernel_us"])))

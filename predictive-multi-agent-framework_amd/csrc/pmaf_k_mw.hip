@@ -92,6 +92,8 @@ __device__ __forceinline__ void circ_and_scale_mw(const int lane, const int w, c
   const V3 rv = v - O.v[0];
   double s = s_pre;
   V3 ron = ron_pre;
+  // (62..64 obstacles per wave: the norms HERE, at the head of the step -- as a second sequence in the tail, next to the
+  // riders', they lengthen the block the whole step waits for: C3 929.7 -> 961.0 us, measured)
   if (!PRE) MT::template norm_unit<true>(ro, s, ron);
   const lmask skip_m = PMAF_BAL(dot(ron, gn) < -0.01) & PMAF_BAL(dot(ro, rv) < -0.01);
   double d = s - (C.rad + O.r[0]);
@@ -542,11 +544,14 @@ bool PMAF_MW_LAUNCH(const DevView &D, const CostParams &cp, int waves, int per, 
   size_t need = lds;
   { const size_t want = (size_t)(lds_kb > 0 ? lds_kb : (waves == 2 ? 72 : 96)) * 1024; if (want > need) need = want; }
   const dim3 grid((unsigned)D.N, (unsigned)D.P);
+  // (the opt-in to more than 64 KB of dynamic LDS is per function AND device: remembered per device of the calling thread)
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
 #define PMAF_L1(WV, PL, PR) do { \
-    static size_t lds_set = 0; \
-    if (need > 64 * 1024 && need > lds_set) { \
+    static size_t lds_set[64] = {0}; \
+    if (need > 64 * 1024 && need > lds_set[dev]) { \
       if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rollout_mw<WV, PMAF_MW_MATH, PL, PR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)need) != hipSuccess) return false; \
-      lds_set = need; } \
+      lds_set[dev] = need; } \
     hipExtLaunchKernelGGL((k_rollout_mw<WV, PMAF_MW_MATH, PL, PR>), grid, dim3(64 * WV), (unsigned)need, s, e0, e1, 0, D, cp, per); } while (0)
 #define PMAF_L(WV) do { if (plain) { if (pre) PMAF_L1(WV, true, true); else PMAF_L1(WV, true, false); } \
                         else { if (pre) PMAF_L1(WV, false, true); else PMAF_L1(WV, false, false); } } while (0)

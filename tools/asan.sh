@@ -43,6 +43,6 @@ export UBSAN_OPTIONS=print_stacktrace=1:log_path=/tmp/ubsan_log
   ls /tmp/asan_log.* /tmp/ubsan_log.* 2>/dev/null | wc -l
   cat /tmp/asan_log.* /tmp/ubsan_log.* 2>/dev/null | grep -E "ERROR|runtime error|SUMMARY" | sort | uniq -c | head -20
   echo "# kernels with -DPMAF_DEBUG_BOUNDS (lib_bounds/): the GPU parity suite"
-  PMAF_LIB_PATH=$R/predictive-multi-agent-framework_amd/lib_bounds/libpmaf_hip.so python -m pytest tests/test_parity_gpu.py tests/test_tolerance_gpu.py -q -rfE -p no:cacheprovider 2>&1 | tail -6
+  PMAF_LIB_PATH=$R/predictive-multi-agent-framework_amd/lib_bounds/libpmaf_hip.so python -m pytest tests/test_parity_gpu.py tests/test_mw_gpu.py tests/test_tolerance_gpu.py -q -rfE -p no:cacheprovider 2>&1 | tail -6
 } > $OUT 2>&1
 cat $OUT

@@ -465,7 +465,8 @@ int pmaf_get_launch_config(pmaf_planner *h, int32_t *lanes_per_agent,
                            int32_t *n_blocks, int32_t *lds_bytes);
 /* Wave-per-agent handles with 62..256 field obstacles: how many waves share an agent's rollout (csrc/pmaf_k_mw.hip:
  * one block of 2..4 waves per agent, <= 64 obstacles per wave, one LDS hand-off per step) and how many obstacles each
- * wave holds; waves_per_agent = 1: the one-wave kernels (2 / 4 obstacle slots per lane). Chosen at pmaf_create while
+ * wave holds; waves_per_agent = 1: the one-wave kernels (2 / 4 obstacle slots per lane; always with
+ * PMAF_FLAG_IEEE_SEQUENCES). Chosen at pmaf_create while
  * every wave of the launch gets a SIMD of its own; PMAF_MW=0 in the environment keeps the one-wave kernels, PMAF_MW=3|4
  * asks for more waves than the obstacle count needs (tests, timing). Results are bit-identical either way. */
 int pmaf_get_waves_per_agent(pmaf_planner *h, int32_t *waves_per_agent, int32_t *obstacles_per_wave);

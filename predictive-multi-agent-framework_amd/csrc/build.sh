@@ -6,7 +6,7 @@
 #                        policy 2 in two units: one-slot / multi-slot kernels, -DPMAF_W64_PART=1|2; policy 3 = the opt-in
 #                        contracted one, the only units compiled with -ffp-contract=fast)
 #   pmaf_k_grp.hip   x3  the group rollout kernel (-DPMAF_GRP_MATH=0|2|3)
-#   pmaf_k_mw.hip    x2  the multi-wave-per-agent rollout kernel (62..244 obstacles at <= 1 wave per SIMD; -DPMAF_MW_MATH=2|3)
+#   pmaf_k_mw.hip    x3  the multi-wave-per-agent rollout kernel (62..256 obstacles at <= 1 wave per SIMD; -DPMAF_MW_MATH=1|2|3)
 #   pmaf_k_misc.hip      generic rollout, manager, scoring, winner records ... + the launch interface
 #   pmaf_host.cpp        the C-ABI (g++, plain C++ against the HIP runtime API)
 #   pmaf_shard.cpp       communicators + the winner-record exchange (RCCL / host-callback)
@@ -66,6 +66,7 @@ kcompile k_w64_m3 pmaf_k_w64.hip -DPMAF_W64_MATH=3 -ffp-contract=fast
 kcompile k_grp_m3 pmaf_k_grp.hip -DPMAF_GRP_MATH=3 -ffp-contract=fast
 kcompile k_grp_m0 pmaf_k_grp.hip -DPMAF_GRP_MATH=0
 kcompile k_mw_m2 pmaf_k_mw.hip -DPMAF_MW_MATH=2
+kcompile k_mw_m1 pmaf_k_mw.hip -DPMAF_MW_MATH=1
 kcompile k_mw_m3 pmaf_k_mw.hip -DPMAF_MW_MATH=3 -ffp-contract=fast
 kcompile k_misc pmaf_k_misc.hip
 ( $CXX $HFLAGS -c pmaf_host.cpp -o "$OBJ/host.o" 2> "$OBJ/host.log" ) &
@@ -79,7 +80,7 @@ done
 [ "$fail" = 0 ] || exit 1
 for n in "${names[@]}"; do grep -E -A3 "warning:|error:" "$OBJ/$n.log" >&2 || true; done
 $HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT/libpmaf_hip.so" \
-  "$OBJ"/k_w64_m2_t1.o "$OBJ"/k_w64_m2_tn.o "$OBJ"/k_w64_m0.o "$OBJ"/k_w64_m1.o "$OBJ"/k_grp_m2.o "$OBJ"/k_grp_m0.o "$OBJ"/k_w64_m3.o "$OBJ"/k_grp_m3.o "$OBJ"/k_mw_m2.o "$OBJ"/k_mw_m3.o "$OBJ"/k_misc.o \
+  "$OBJ"/k_w64_m2_t1.o "$OBJ"/k_w64_m2_tn.o "$OBJ"/k_w64_m0.o "$OBJ"/k_w64_m1.o "$OBJ"/k_grp_m2.o "$OBJ"/k_grp_m0.o "$OBJ"/k_w64_m3.o "$OBJ"/k_grp_m3.o "$OBJ"/k_mw_m1.o "$OBJ"/k_mw_m2.o "$OBJ"/k_mw_m3.o "$OBJ"/k_misc.o \
   "$OBJ"/host.o "$OBJ"/shard.o -L"$ROCM/lib" -lrccl -Wl,-rpath,"$ROCM/lib" ${PMAF_EXTRA_LDFLAGS}
 # (the log of an object that was up to date is the one of its last compile)
 cat "$OBJ"/k_*.log | grep "kernel-resource-usage" | sed -e 's/^[^ ]* remark: *//' -e 's/ \[-Rpass-analysis=kernel-resource-usage\]//' > "$OUT/resource_usage.txt"

@@ -321,7 +321,7 @@ static int pick_lpa(int N, int P, int M) {
 // PMAF_MW=0 / 2 / 3 / 4: off / that many waves (tests, timing); PMAF_MW_PER: obstacles per wave (default: even split).
 static void pick_mw(pmaf_planner *h, int N, int P, int M) {
   h->mw_waves = 0; h->mw_per = 0;
-  if (h->lpa != 64 || h->force_generic || !(h->math == MATH_XACT || h->math == MATH_FMA)) return;
+  if (h->lpa != 64 || h->force_generic || h->math == MATH_IEEE) return;
   if (M < 62 || M > 4 * 64) return;
   // as few waves as hold the obstacles at 64 per wave (every wave more costs ~0.24 us per step: profiles/r4_ab_mw.txt);
   // at <= 61 per wave lanes 61..63 stay free for the tail's riders and the sweep's norms ride along (pmaf_k_mw.hip)

@@ -856,12 +856,14 @@ bool pmaf_k_launch_w64(const DevView &D, const CostParams &cp, int tiles, int ma
                       : pmaf_k_launch_w64_m2_tn(D, cp, tiles, dppsum, plain, lds, s, e0, e1);
 }
 
+bool pmaf_k_launch_mw_m1(const DevView &, const CostParams &, int, int, bool, int, hipStream_t, hipEvent_t, hipEvent_t);
 bool pmaf_k_launch_mw_m2(const DevView &, const CostParams &, int, int, bool, int, hipStream_t, hipEvent_t, hipEvent_t);
 bool pmaf_k_launch_mw_m3(const DevView &, const CostParams &, int, int, bool, int, hipStream_t, hipEvent_t, hipEvent_t);
 bool pmaf_k_launch_mw(const DevView &D, const CostParams &cp, int waves, int per, int math, bool plain, int lds_kb,
                       hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
   if (math == MATH_FMA) return pmaf_k_launch_mw_m3(D, cp, waves, per, plain, lds_kb, s, e0, e1);
   if (math == MATH_XACT) return pmaf_k_launch_mw_m2(D, cp, waves, per, plain, lds_kb, s, e0, e1);
+  if (math == MATH_FAST) return pmaf_k_launch_mw_m1(D, cp, waves, per, plain, lds_kb, s, e0, e1);
   return false;
 }
 

@@ -1,5 +1,5 @@
 // pmaf_k_mw.hip -- k_rollout_mw<W, MATH, PLAIN>: W waves per agent (latency shape with MANY obstacles: BASELINE C3,
-// 256 agents x 500 steps x 128 obstacles) and its launcher. Compiled per arithmetic policy (-DPMAF_MW_MATH=2|3,
+// 256 agents x 500 steps x 128 obstacles) and its launcher. Compiled per arithmetic policy (-DPMAF_MW_MATH=1|2|3,
 // csrc/build.sh; 3 with -ffp-contract=fast); each object defines pmaf_k_launch_mw_m<policy>.
 //
 // Why: with 62..256 field obstacles the wave-per-agent kernel holds 2 or 4 obstacle slots per lane and its lone wave
@@ -25,7 +25,7 @@
 // two-wave experiments (NOTES: full split +14 %, helper wave +24 %) split the step by FUNCTION, which shortens no chain.
 // Bit-exact with the oracle like every other kernel (tests/test_mw_gpu.py; tests/test_parity_gpu.py runs its
 // many-obstacle cases through this kernel AND, with PMAF_MW=0, through the one-wave kernels, which stay for launches
-// that cannot give every wave a SIMD of its own and for policies 0 / 1).
+// that cannot give every wave a SIMD of its own and for policy 0).
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 
@@ -521,7 +521,7 @@ __global__ __launch_bounds__(64 * W) void k_rollout_mw(DevView D, CostParams CP,
 }
 
 #ifndef PMAF_MW_MATH
-#error "compile with -DPMAF_MW_MATH=2|3"
+#error "compile with -DPMAF_MW_MATH=1|2|3"
 #endif
 #define PMAF_CAT2(a, b) a##b
 #define PMAF_CAT(a, b) PMAF_CAT2(a, b)

@@ -165,7 +165,7 @@ struct PlanArgs {
 bool pmaf_k_launch_w64(const DevView &D, const CostParams &cp, int tiles, int math, bool dppsum, bool plain, size_t lds,
                        hipStream_t s, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
 // k_rollout_grp<LPA, TILES, MATH> on grid (n_blocks, P); lpa in {8,16,32}, tiles in {1,2,4}, math XACT, IEEE or FMA
-// W waves per agent (pmaf_k_mw.hip): waves in 2..4, per = field obstacles per wave (<= 61); math MATH_XACT / MATH_FMA only
+// W waves per agent (pmaf_k_mw.hip): waves in 2..4, per = field obstacles per wave (<= 61); every policy but MATH_IEEE
 // lds_kb: dynamic LDS per block in KB (0: the launcher's placement rule)
 bool pmaf_k_launch_mw(const DevView &D, const CostParams &cp, int waves, int per, int math, bool plain, int lds_kb,
                       hipStream_t s, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);

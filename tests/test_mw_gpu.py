@@ -95,3 +95,33 @@ def test_contracted_policy_within_tolerance(pmaf, oracle, scenes):
         assert nh[bo] == no[bo]
         assert np.abs(ph[bo, :no[bo]] - po[bo, :no[bo]]).max() <= 1e-5
     hip.close()
+
+
+def test_batched_populations_on_split_blocks(pmaf, oracle, scenes):
+    """P populations in one handle (grid N x P of multi-wave blocks): some at rest (closest-other table per population),
+    some moving (mirror on the step's parity), against one oracle per population"""
+    scs = [scenes.synthetic_scene(20, 120, 100, 5, 40 + sid, dynamic=(sid % 2 == 1)) for sid in range(4)]
+    starts = np.stack([s["start"] for s in scs])
+    hip = pmaf.PmafPlanner(scs, device=0, mgr_init_pos=starts)
+    hip.set_initial_position(starts)
+    assert hip.launch_config()["waves_per_agent"] == 2
+    oras = []
+    for s in scs:
+        o = oracle.OraclePlanner(s, mgr_init_pos=s["start"])
+        o.set_initial_position(s["start"])
+        oras.append(o)
+    obs = np.stack([s["obstacles"] for s in scs])
+    for t in range(5):
+        bh = hip.tick(obs, scs[0]["dt"], scs[0]["cost_gains"], scs[0]["ws_limits"])
+        bo = [o.tick(obs[i], scs[0]["dt"], scs[0]["cost_gains"], scs[0]["ws_limits"]) for i, o in enumerate(oras)]
+        np.testing.assert_array_equal(bh, bo)
+        obs = np.stack([scenes.advance_live_obstacles(o) if i % 2 == 1 else o for i, o in enumerate(obs)])
+    hip.stop()
+    ph, nh = hip.paths()
+    for i, o in enumerate(oras):
+        po, no = o.paths()
+        np.testing.assert_array_equal(nh[i], no)
+        assert np.array_equal(ph[i], po, equal_nan=True)
+        np.testing.assert_array_equal(hip.rot_vecs()[i], o.rot_vecs())
+        np.testing.assert_array_equal(hip.known()[i], o.known())
+    hip.close()

@@ -32,6 +32,8 @@ misc)
   ;;
 soak)   # stability of the C2 tick loop: 240 s timed, block times
   python bench.py --only-headline --min-seconds 240 --steps 2000 --cpu-seconds 0 --flop-ticks 0 > $O/bench_c2_soak_240s.json 2>> $O/bench.err
+  # (the split kernel: one s_barrier per step and wave -- 120 s of C3 ticks)
+  python bench.py --config C3 --only-headline --min-seconds 120 --steps 500 --cpu-seconds 0 --flop-ticks 0 > $O/bench_c3_soak_120s.json 2>> $O/bench.err
   ;;
 asan)   # (build first, here: bash tools/asan.sh build -- lib_asan/ and lib_bounds/ travel with the snapshot)
   bash tools/asan.sh run > /dev/null 2>&1; cp gpurun_out/r4_asan.txt $O/asan.txt

@@ -125,3 +125,45 @@ def test_batched_populations_on_split_blocks(pmaf, oracle, scenes):
         np.testing.assert_array_equal(hip.rot_vecs()[i], o.rot_vecs())
         np.testing.assert_array_equal(hip.known()[i], o.known())
     hip.close()
+
+
+@pytest.mark.parametrize("cfg", ["C3", "M200_dynamic"])
+def test_split_and_one_wave_kernels_agree_over_a_long_closed_loop(pmaf, scenes, monkeypatch, cfg):
+    """size-independent check at full size: 150 closed-loop ticks (episode restarts every 50, as the bench does) through
+    k_rollout_mw and, with PMAF_MW=0, through the one-wave kernels -- identical best-index sequences, set-points, paths,
+    rotation vectors and costs, bit for bit (the oracle comparison at this size runs for a few ticks only)"""
+    if cfg == "C3":
+        sc, dyn = scenes.config_scene("C3"), False
+    else:
+        sc, dyn = scenes.synthetic_scene(96, 300, 200, 8, 21, dynamic=True), True
+
+    def run(env):
+        if env is None:
+            monkeypatch.delenv("PMAF_MW", raising=False)
+        else:
+            monkeypatch.setenv("PMAF_MW", env)
+        hip = pmaf.PmafPlanner(sc, device=0, mgr_init_pos=sc["start"])
+        hip.set_initial_position(sc["start"])
+        waves = hip.launch_config()["waves_per_agent"]
+        obs = sc["obstacles"].copy()
+        best, setp = [], []
+        for t in range(150):
+            if t % 50 == 0 and t:
+                hip.set_initial_position(sc["start"])
+                obs = sc["obstacles"].copy()
+            best.append(hip.tick(obs, sc["dt"], sc["cost_gains"], sc["ws_limits"]))
+            setp.append(np.concatenate([hip.last_next_pos.ravel(), hip.last_next_vel.ravel()]))
+            if dyn:
+                obs = scenes.advance_live_obstacles(obs)
+        hip.stop()
+        out = (waves, np.array(best), np.array(setp), hip.paths(), hip.costs(), hip.rot_vecs(), hip.known(), hip.min_obs_dist())
+        hip.close()
+        return out
+
+    a, b = run(None), run("0")
+    assert a[0] >= 2 and b[0] == 1
+    np.testing.assert_array_equal(a[1], b[1])
+    assert np.array_equal(a[2], b[2], equal_nan=True)
+    assert np.array_equal(a[3][0], b[3][0], equal_nan=True) and np.array_equal(a[3][1], b[3][1])
+    for x, y in zip(a[4:], b[4:]):
+        assert np.array_equal(np.asarray(x), np.asarray(y), equal_nan=True)

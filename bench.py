@@ -120,7 +120,7 @@ def cpu_baseline(config, budget_s):
 def kernel_name_of(cfg, n_obs, math=2):
     """math: the arithmetic policy's template argument (2 = strict default, 3 = contracted)"""
     tiles = (n_obs - 1 + 63) // 64
-    if 62 <= n_obs - 1 <= 64:
+    if 61 <= n_obs - 1 <= 64:
         tiles = 2
     generic = os.environ.get("PMAF_FORCE_GENERIC") == "1"
     plain = os.environ.get("PMAF_PLAIN_STEP", "1")[:1] != "0"

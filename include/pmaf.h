@@ -160,7 +160,7 @@ int pmaf_reset_agents(pmaf_planner *h, const double *pos, const double *vel,
  * the reference's prediction threads. obstacles may be NULL (= unchanged).
  * A list that differs from the previous one in a field obstacle (compared bit for
  * bit) and is at rest makes the next reset recompute the Obstacle / GoalObstacle
- * heuristics' closest-other table (populations of more than 61 field obstacles on
+ * heuristics' closest-other table (populations of more than 60 field obstacles on
  * the wave-per-agent kernels; M distances per obstacle, once): passing the same
  * static list every tick, as the reference's node does, costs nothing.
  */
@@ -463,7 +463,7 @@ int pmaf_reset_kernel_stats(pmaf_planner *h);
 /* chosen lanes-per-agent and grid of the rollout kernel */
 int pmaf_get_launch_config(pmaf_planner *h, int32_t *lanes_per_agent,
                            int32_t *n_blocks, int32_t *lds_bytes);
-/* Wave-per-agent handles with 62..256 field obstacles: how many waves share an agent's rollout (csrc/pmaf_k_mw.hip:
+/* Wave-per-agent handles with 61..256 field obstacles: how many waves share an agent's rollout (csrc/pmaf_k_mw.hip:
  * one block of 2..4 waves per agent, <= 64 obstacles per wave, one LDS hand-off per step) and how many obstacles each
  * wave holds; waves_per_agent = 1: the one-wave kernels (2 / 4 obstacle slots per lane; always with
  * PMAF_FLAG_IEEE_SEQUENCES). Chosen at pmaf_create while

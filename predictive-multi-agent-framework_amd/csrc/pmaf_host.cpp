@@ -61,7 +61,7 @@ struct pmaf_planner {
   bool plain_step = false;     // every k_attr != 0 and unit mass: the wave-per-agent kernels' PLAIN step (pmaf_k_w64.hip)
   bool blocking_wait = false;  // PMAF_FLAG_BLOCKING_WAIT: pmaf_tick sleeps on an event instead of spinning on the mailbox
   bool dpp_sum = true;         // w64 kernels: ordered force sum by the DPP chain (M > 20) or LDS batches
-  // W waves per agent (pmaf_k_mw.hip; 0: the wave-per-agent kernels): 62..244 field obstacles, default or contracted
+  // W waves per agent (pmaf_k_mw.hip; 0: the wave-per-agent kernels): 61..256 field obstacles, every policy but the compiler-IEEE one
   // arithmetic, and every wave of the launch with a SIMD to itself (pick_mw)
   int mw_waves = 0, mw_per = 0, mw_lds_kb = 0;
   int n_blocks = 0;
@@ -106,7 +106,7 @@ struct pmaf_planner {
   // (an external kernel -- pmaf_debug_external_rollout -- is the product kernel's own code and reads the table too)
   bool uses_closest_table() const {
     const int M = D.n_obs - 1;
-    const int tiles64 = (M >= 62 && M <= 64) ? 2 : (M + 63) / 64;
+    const int tiles64 = (M >= 61 && M <= 64) ? 2 : (M + 63) / 64;
     return lpa == 64 && tiles64 >= 2 && tiles64 <= 4 && !force_generic;
   }
   // host-side clock of the last pmaf_tick calls (pmaf_get_tick_times_us): entry -> both launches enqueued, entry ->
@@ -322,7 +322,7 @@ static int pick_lpa(int N, int P, int M) {
 static void pick_mw(pmaf_planner *h, int N, int P, int M) {
   h->mw_waves = 0; h->mw_per = 0;
   if (h->lpa != 64 || h->force_generic || h->math == MATH_IEEE) return;
-  if (M < 62 || M > 4 * 64) return;
+  if (M < 61 || M > 4 * 64) return;
   // as few waves as hold the obstacles at 64 per wave (every wave more costs ~0.24 us per step: profiles/r4_ab_mw.txt);
   // at <= 61 per wave lanes 61..63 stay free for the tail's riders and the sweep's norms ride along (pmaf_k_mw.hip)
   int waves = (M + 63) / 64;
@@ -378,9 +378,10 @@ static void launch_rollout(pmaf_planner *h) {
   // with a communicator attached the rollout writes the OTHER path buffer: the exchange of the selection just made
   // may still be packing the path it scored (the getters follow D.paths)
   if (h->x.c) h->D.paths = (h->D.paths == h->x.paths_a) ? h->x.paths_b : h->x.paths_a;
-  // (the one-slot kernel keeps lanes 61-63 for the goal and the two speed limits: 62-64 obstacles go to the two-slot kernel)
+  // (the one-slot kernel keeps lanes 61-63 for the goal and the two speed limits and lane 60 for the repulsive obstacle:
+  // 61-64 obstacles go to the split / two-slot kernels)
   const int M = h->D.n_obs - 1;
-  const int tiles64 = (M >= 62 && M <= 64) ? 2 : (M + 63) / 64;
+  const int tiles64 = (M >= 61 && M <= 64) ? 2 : (M + 63) / 64;
   bool ok;
   if (h->ext_fn) {
     // measurement tooling (tools/slackprof): the same launch with a kernel out of an external code object -- the

@@ -2,7 +2,7 @@
 // 256 agents x 500 steps x 128 obstacles) and its launcher. Compiled per arithmetic policy (-DPMAF_MW_MATH=1|2|3,
 // csrc/build.sh; 3 with -ffp-contract=fast); each object defines pmaf_k_launch_mw_m<policy>.
 //
-// Why: with 62..256 field obstacles the wave-per-agent kernel holds 2 or 4 obstacle slots per lane and its lone wave
+// Why: with 61..256 field obstacles the wave-per-agent kernel holds 2 or 4 obstacle slots per lane and its lone wave
 // issues the per-obstacle instructions of every slot (C3: 769 instructions per step against the one-slot kernel's 447,
 // profiles/r4_c3_strict_steploop.txt) while three quarters of the chip's 1024 SIMDs idle. Here an agent is a BLOCK of
 // W = ceil(M / 64) waves on W SIMDs of one CU and every wave runs the ONE-slot step on its own <= 64 obstacles (<= 61:

@@ -114,7 +114,7 @@ __device__ __forceinline__ void rollout_w64_body(const DevView &D, const CostPar
   double zv = sqn(v);
   double z_init = sqn(p - init_pos);
   V3 gn = (dg > 0.0) ? MT::div3(g, dg) : g;  // goal_vec.normalized()
-  // One slot per lane (M <= 61; the host sends 62..64 obstacles to the two-slot kernel): the sweep's |ro| /
+  // One slot per lane (M <= 60; the host sends 61..64 obstacles to the split / two-slot kernels): the sweep's |ro| /
   // ro.normalized() of the NEXT step are computed at the end of this step, and the lanes that have no obstacle carry
   // the tail's other norms through the same instructions -- lane 63 the goal (distance and direction), lane 62 the
   // speed clamp, lane 61 attractorForce's speed limit -- instead of three more sqrt / reciprocal / divide sequences.
@@ -131,8 +131,19 @@ __device__ __forceinline__ void rollout_w64_body(const DevView &D, const CostPar
     // it would turn into +0.0, and the goal direction read back from lane 63 also feeds the latch, calc_rot_vec_pre)
     const double nz = (C.dt < 0.0) ? 0.0 : -0.0;
     if (lane == 63 || lane == 61) { O.p[0] = goal; O.v[0] = mk(nz, nz, nz); }
+#ifndef PMAF_SENT_RIDER
+#define PMAF_SENT_RIDER 1
+#endif
+    // Round 4 (last session): the loop that carries code for the repulsive obstacle keeps that obstacle in lane 60 like a
+    // field obstacle (advanced with the others by predictObstacles' p + v dt), so that |p - sent_pos| and the direction
+    // to it -- repelForce's square root, reciprocal and three divisions -- ride in the tail's ONE sequence like the goal
+    // and the two speed limits (the one-slot kernel therefore takes at most 60 field obstacles; the host sends 61..64
+    // to the other kernels). C4, where the obstacle is the other arm: 280.0 -> 270.5 us per launch
+    // (profiles/r4_ab_w64.txt item 8).
+    if (PMAF_SENT_RIDER && SENT == 1 && lane == 60) { O.p[0] = sent_p; O.v[0] = sent_v; }
     MT::norm_unit(O.p[0] - p, s_pre, ron_pre);
   }
+  constexpr bool SRIDE = PMAF_SENT_RIDER && PRE && SENT == 1;
   V3 verr = attractor_velocity_error<MATH>(v, g, C, k_attr, k_damp);
   const double zsent_lt = D.zsent_lt[pop];
   const bool sent_reachable = (SENT == 2) ? sentinel_reachable(p, sent_p, sent_v, zsent_lt, C, D.cap) : (SENT == 1);
@@ -258,6 +269,24 @@ __device__ __forceinline__ void rollout_w64_body(const DevView &D, const CostPar
       dg = readlane_d(s, 63);
       gn = readlane_v3(u, 63);
       verr = vel_des * smin(1.0, f_des) - v;
+      if (SRIDE) {
+        // repelForce (:159-181) of the coming step from lane 60's norm and direction: z = |sent_pos - p|^2 is the squared
+        // norm of dist_vec (same components up to sign), otr = normalized(p - sent_pos) = -(ro / |ro|) (a zero component's
+        // sign differs: F + (0 + repel) below does not see it)
+        const double z60 = readlane_d(zvec, 60);
+        repel = mk(0.0, 0.0, 0.0);
+        if (z60 < zsent_lt) {
+          const double s60 = readlane_d(s, 60);
+          const V3 u60 = readlane_v3(u, 60);
+          double d = s60 - (C.rad + sent_r);
+          d = smax(d, 1e-5);
+          const V3 otr = -u60;
+          const double t = MT::div_pos(1.0, d) - inv_shell;
+          const double dd = d * d;
+          const V3 num2 = (k_repel * otr) * t;
+          repel = MT::div3_n_pos(num2, dd, MT::rcp_for(dd));
+        }
+      }
     }
     zv = sqn(v);
     z_init = sqn(p - init_pos);
@@ -274,7 +303,8 @@ __device__ __forceinline__ void rollout_w64_body(const DevView &D, const CostPar
     }
     // (decided at run time in the multi-slot kernels: out of line there -- in the shipped scenes the obstacle sits 170 m
     // away, and a block that is skipped costs a taken branch per step)
-    if ((SENT == 2) ? PMAF_RARE(sent_reachable) : sent_reachable) {  // the only masked block of the step for the repulsive obstacle: advance it, next step's repelForce
+    if (SRIDE) {
+    } else if ((SENT == 2) ? PMAF_RARE(sent_reachable) : sent_reachable) {  // the only masked block of the step for the repulsive obstacle: advance it, next step's repelForce
       sent_p = sent_p + sent_v * C.dt;
       repel = sentinel_repel_m<MATH>(p, C, k_repel, sent_p, sent_r, zsent_lt, inv_shell);
     }

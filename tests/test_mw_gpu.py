@@ -16,7 +16,7 @@ def _expected_split(m):
 
 
 @pytest.mark.parametrize("dynamic", [False, True])
-@pytest.mark.parametrize("m", [62, 64, 100, 122, 123, 128, 129, 183, 184, 192, 200, 244, 245, 256])
+@pytest.mark.parametrize("m", [61, 62, 64, 100, 122, 123, 128, 129, 183, 184, 192, 200, 244, 245, 256])
 def test_every_split_matches_the_oracle(pmaf, oracle, scenes, m, dynamic):
     """obstacle counts on both sides of every boundary of the split: 2 / 3 / 4 waves, <= 61 obstacles per wave (riders in
     lanes 61..63, the sweep's norms in the tail's sequence) and 62..64 (the sweep takes its own); every heuristic type

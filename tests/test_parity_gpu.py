@@ -939,8 +939,9 @@ def test_signed_zero_coordinates_of_obstacles_at_rest(pmaf, oracle, scenes, lpa)
 def test_idle_lane_riders_at_the_obstacle_count_boundary(pmaf, oracle, scenes, m, dynamic, monkeypatch, one_wave):
     """the one-slot wave-per-agent kernel runs the goal distance / direction, the
     speed clamp and the attractor speed limit in lanes 63 / 62 / 61 of the sweep's
-    norm sequence, so it takes at most 61 field obstacles; 62...64 go to the
-    two-slot kernel (which packs the three riders into a sequence of their own)"""
+    norm sequence (and a reachable repulsive obstacle in lane 60), so it takes at
+    most 60 field obstacles; 61...64 go to the split / two-slot kernels (which pack
+    the three riders into a sequence of their own)"""
     if one_wave:   # the one-wave kernels (2 / 4 obstacle slots per lane) instead of k_rollout_mw
         monkeypatch.setenv("PMAF_MW", "0")
     sc = scenes.synthetic_scene(12, 90, m, 6, 100 + m, dynamic=dynamic)
@@ -983,6 +984,41 @@ def test_repulsive_obstacle_moving_into_range(pmaf, oracle, scenes):
         sc["obstacles"][-1] = [0.0, 2.0, 0.7, 0.0, -1.2, 0.0, 0.1]
         hip, ora = run_both(pmaf, oracle, scenes, sc, 3, dynamic=True, lanes_per_agent=lpa)
         hip.close()
+
+
+@pytest.mark.parametrize("m", [32, 59, 60, 61, 62])
+@pytest.mark.parametrize("case", ["flying_in", "resting_on_the_path", "on_an_axis", "fast", "ieee"])
+def test_repulsive_obstacle_rides_in_lane_60(pmaf, oracle, scenes, m, case):
+    """the one-slot kernel's loop for a reachable repulsive obstacle keeps it in lane 60 like a field obstacle (advanced by
+    the same p + v dt) and takes |p - sent_pos| and the direction from the tail's norm sequence, so it holds at most 60
+    field obstacles -- 61 and more go to the split / two-slot kernels, which evaluate repelForce on their own. Around
+    that boundary: the obstacle flying in (out of range, in range, out again), resting right next to the path (in range
+    from the first step), centred on a coordinate axis of the start (zero components of the direction: their sign
+    differs from the reference's normalized(p - sent_pos) and F + (0 + repel) must not see it), and the other
+    arithmetic policies' kernels"""
+    sc = scenes.synthetic_scene(9, 160, m, 9, 300 + m, dynamic=(case == "flying_in"))
+    if case == "flying_in":
+        sc["obstacles"][-1] = [0.0, 2.0, 0.7, 0.0, -1.2, 0.0, 0.1]
+    elif case == "on_an_axis":
+        sc["obstacles"][-1] = [sc["start"][0], sc["start"][1] + 0.3, sc["start"][2], 0.0, 0.0, 0.0, 0.08]
+    else:
+        sc["obstacles"][-1] = [-0.2, 0.12, 0.72, 0.0, 0.0, 0.0, 0.1]
+    kw = {"fast_math": True} if case == "fast" else {"ieee_sequences": True} if case == "ieee" else {}
+    if case == "fast":
+        # (1-2 ulp arithmetic: tolerance parity as in test_fast_math_within_north_star_tolerance, selected trajectory)
+        hip, ora = make_pair(pmaf, oracle, sc, **kw)
+        for _ in range(3):
+            b = ora.tick(sc["obstacles"], sc["dt"], sc["cost_gains"], sc["ws_limits"])
+            assert hip.tick(sc["obstacles"], sc["dt"], sc["cost_gains"], sc["ws_limits"]) == b
+        hip.stop()
+        (ph, nh), (po, no) = hip.paths(), ora.paths()
+        assert nh[b] == no[b] and np.abs(ph[b, :no[b]] - po[b, :no[b]]).max() <= LIBM_TOL
+        hip.close()
+        return
+    hip, _ = run_both(pmaf, oracle, scenes, sc, 3, dynamic=(case == "flying_in"), **kw)
+    cfg = hip.launch_config()
+    assert (cfg["waves_per_agent"] == 1) == (m <= 60 or case == "ieee")
+    hip.close()
 
 
 @pytest.mark.parametrize("lpa,force_generic,ieee", [(0, False, False), (0, True, False), (0, False, True)])

@@ -23,7 +23,7 @@ BASE = ("--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-
 
 # (tag, source, extra flags as in csrc/build.sh, {label: mangled kernel})
 UNITS = [
-    ("c1c2_strict", "pmaf_k_w64.hip", ["-DPMAF_W64_MATH=2", "-DPMAF_W64_PART=1"],
+    ("c1c2_strict", "pmaf_k_w64.hip", ["-DPMAF_W64_MATH=2", "-DPMAF_W64_PART=1", "-falign-loops=32"],
      {"C2 / C4 k_rollout_w64<1,2,dpp,plain>": "_Z13k_rollout_w64ILi1ELi2ELb1ELb1EEv7DevView10CostParams"}),
     ("c3_strict", "pmaf_k_w64.hip", ["-DPMAF_W64_MATH=2", "-DPMAF_W64_PART=2", "-mllvm", "-misched-prera-direction=topdown",
                                      "-mllvm", "-align-all-nofallthru-blocks=6"],

@@ -80,3 +80,21 @@ def test_plan_is_the_same_code_path_for_every_world_size():
     # the default flags (no --steps / --warmup): still minutes, not more
     ns2 = dict(ns, steps=2000, warmup=100)
     assert bench.plan_budget_s(argparse.Namespace(**ns2), 1)[0] < 180.0
+
+
+def test_kernel_names_follow_the_librarys_routing():
+    """bench.py names the rollout kernel of a launch from the handle's launch configuration (the rocprofv3 summary of the
+    same command must show that kernel): one-slot up to 60 field obstacles, the split kernel where the library reports
+    waves_per_agent > 1, the two- / four-slot kernels otherwise, the lane-group kernels by lanes per agent"""
+    sys.path.insert(0, ROOT)
+    import bench
+    one = dict(lanes_per_agent=64, waves_per_agent=1, obstacles_per_wave=32)
+    assert bench.kernel_name_of(one, 33) == "k_rollout_w64<1, 2, true, true>"
+    assert bench.kernel_name_of(one, 61) == "k_rollout_w64<1, 2, true, true>"          # 60 field obstacles
+    assert bench.kernel_name_of(one, 62) == "k_rollout_w64<2, 2, true, true>"          # 61: lane 60 is the repulsive obstacle's
+    assert bench.kernel_name_of(one, 129, 3) == "k_rollout_w64<2, 3, true, true>"
+    assert bench.kernel_name_of(one, 201) == "k_rollout_w64<4, 2, true, true>"
+    split = dict(lanes_per_agent=64, waves_per_agent=2, obstacles_per_wave=64)
+    assert bench.kernel_name_of(split, 129) == "k_rollout_mw<2, 2, true, false>"
+    assert bench.kernel_name_of(dict(split, obstacles_per_wave=50), 101, 3) == "k_rollout_mw<2, 3, true, true>"
+    assert bench.kernel_name_of(dict(lanes_per_agent=16), 33) == "k_rollout_grp<16, 2, 2>"

@@ -15,7 +15,7 @@ only = int(sys.argv[3]) if len(sys.argv) > 3 else -1
 bad = 0
 t0 = time.time()
 for trial in range(n_trials):
-    N = int(rng.integers(1, 40)); M = int(rng.choice([0, 1, 2, 5, 9, 17, 32, 33, 62, 63, 64, 65, 100, 122, 123, 128, 129, 150, 192, 200, 256]))
+    N = int(rng.integers(1, 40)); M = int(rng.choice([0, 1, 2, 5, 9, 17, 32, 33, 58, 59, 60, 61, 62, 63, 64, 65, 100, 122, 123, 128, 129, 150, 192, 200, 256]))
     H = int(rng.integers(5, 160)); dyn = bool(rng.integers(0, 2))
     if rng.integers(0, 25) == 0:   # a large population (multi-block launches of the group kernels), short horizon
         N = int(rng.integers(200, 1500)); H = int(rng.integers(5, 30)); M = int(rng.choice([3, 17, 32, 40]))

@@ -31,7 +31,9 @@ __device__ __forceinline__ auto w64_exp_consts(double *tab, int lane) {
     return exp_consts_in_vgprs();
   }
 }
-template <int TILES, int TYPE, int MATH, int SENT = 2, bool DPPSUM = false, bool PLAIN = false>
+// STATICV (one slot per lane): every field obstacle of the population is at rest with +0.0 velocities and the lane the
+// rel_vel rider needs is idle -- decided per block by the kernel (pmaf_rollout_w64.hpp, NVL)
+template <int TILES, int TYPE, int MATH, int SENT = 2, bool DPPSUM = false, bool PLAIN = false, bool STATICV = false>
 __device__ __forceinline__ void rollout_w64_body(const DevView &D, const CostParams &CP, const int lane,
                                                  const int pop, const int a) {
   extern __shared__ double smem[];
@@ -191,7 +193,7 @@ __device__ __forceinline__ void rollout_w64_body(const DevView &D, const CostPar
 #else
     if (PRE || gate)
 #endif
-      circ_and_scale_w64<TILES, TYPE, MATH, PRE, DPPSUM, decltype(EK)>(lane, p, v, zv, goal, g, dg, gn, C, k_circ, n_obs, rot_g, known_bits,
+      circ_and_scale_w64<TILES, TYPE, MATH, PRE, DPPSUM, decltype(EK), (STATICV ? (SENT == 1 ? 59 : 60) : -1)>(lane, p, v, zv, goal, g, dg, gn, C, k_circ, n_obs, rot_g, known_bits,
                                                  O, clist, lane_min, F, scale, ST, EK, D.ablate, 0, s_pre, ron_pre,
                                                  gate_m, cidx);
     PMAF_SEC(ST, 5);
@@ -370,8 +372,22 @@ __global__ __launch_bounds__(64) void k_rollout_w64(DevView D, CostParams CP) {
     const V3 p0 = mk(D.start_pos[pop * 3], D.start_pos[pop * 3 + 1], D.start_pos[pop * 3 + 2]);
     const PopConst C0 = D.C;
     const bool reach = sentinel_reachable(p0, sp, sv, D.zsent_lt[pop], C0, D.cap);
+    // field obstacles at rest with +0.0 velocities (bit patterns: v - (-0.0) would turn a -0.0 component of v into +0.0),
+    // and the rider's lane idle (lane 60; 59 when lane 60 holds the repulsive obstacle): the loops with one
+    // normalisation sequence less per step
+    bool rest = true;
+    for (int i = lane; i < M; i += 64) {
+      const unsigned long long bx = (unsigned long long)__double_as_longlong(src[3 * n_obs + i]),
+                               by = (unsigned long long)__double_as_longlong(src[4 * n_obs + i]),
+                               bz = (unsigned long long)__double_as_longlong(src[5 * n_obs + i]);
+      rest = rest && ((bx | by | bz) == 0ull);
+    }
+    const bool st = !wave_any(!rest) && (M <= 59 || !reach);
 #define PMAF_BODY(T) \
-    if (!reach) rollout_w64_body<TILES, T, MATH, 0, DPPSUM, PLAIN>(D, CP, lane, pop, a); \
+    if (st) { \
+      if (!reach) rollout_w64_body<TILES, T, MATH, 0, DPPSUM, PLAIN, true>(D, CP, lane, pop, a); \
+      else rollout_w64_body<TILES, T, MATH, 1, DPPSUM, PLAIN, true>(D, CP, lane, pop, a); \
+    } else if (!reach) rollout_w64_body<TILES, T, MATH, 0, DPPSUM, PLAIN>(D, CP, lane, pop, a); \
     else rollout_w64_body<TILES, T, MATH, 1, DPPSUM, PLAIN>(D, CP, lane, pop, a)
     switch (D.types[a]) {
       case T_GOAL: PMAF_BODY(T_GOAL); break;

@@ -326,7 +326,32 @@ __device__ __forceinline__ V3 closest_from_table_w64(const int32_t *cidx, int t,
 // ds_read per 16 entries, one dependent add per entry for all three components). Measured crossover at M ~ 20
 // field obstacles (tools/msweep.py, 64 agents x 200 steps): M = 16 274 vs 282 us, M = 32 301 vs 287 us, M = 61 353 vs
 // 326 us; C3 (M = 128, ~57 terms per step) 1603 -> 1322 us. The host picks per launch (pmaf_host.cpp).
-template <int TILES, int TYPE, int MATH, bool PRE = false, bool DPPSUM = false, class KT = ExpK>
+// currentVector's closing `if (cur.norm() < 1e-10) cur = (0,0,1); return cur.normalized()` of the Goal / Velocity branches
+// exactly as current_vector<MATH, true> evaluates it (pmaf_device.hpp), with the quotient handed out as well and `keep`
+// lanes that take it whatever the norm (a rider of the sequence, see NVL below)
+template <int MATH>
+__device__ __forceinline__ V3 cv_close_threshold(const V3 cur, const bool keep, V3 &quot) {
+  typedef Mth<MATH> M;
+  if constexpr (MATH == MATH_XACT) {
+    const double z = sqn(cur);
+    const double s = M::sqrt_pos(z);
+    quot = M::div3_n_pos(cur, s, M::rcp_refined(s));
+    const bool tiny = (z < 0x1.79ca10c924223p-67) && !keep;
+    return mk(tiny ? 0.0 : quot.x, tiny ? 0.0 : quot.y, tiny ? 1.0 : quot.z);
+  } else {
+    double s;
+    M::template norm_unit<true>(cur, s, quot);
+    const bool tiny = (s < 1e-10) && !keep;
+    return mk(tiny ? 0.0 : quot.x, tiny ? 0.0 : quot.y, tiny ? 1.0 : quot.z);
+  }
+}
+
+// NVL (one slot per lane, rollout kernels only; -1: none): the field obstacles are at rest with +0.0 velocities, so
+// rel_vel = v - (+0.0) = v EXACTLY in every lane and its normalisation -- one of the step's per-lane sqrt / reciprocal /
+// divide sequences -- is the same 32 instructions in all 64 lanes. It rides in idle lane NVL of the current vector's own
+// normalisation instead (v goes in for the lane's vector, the quotient is read back): same operations on the same
+// operand, one sequence less per step (round 4, last session: C2's Random agents 202.0 -> 190.8 us per rollout).
+template <int TILES, int TYPE, int MATH, bool PRE = false, bool DPPSUM = false, class KT = ExpK, int NVL = -1>
 __device__ __forceinline__ void circ_and_scale_w64(int lane, V3 p, V3 v, double zv, V3 goal, V3 g, double dg, V3 gn,
                                                    const PopConst &C, double k_circ,
                                                    int n_obs, double *rot_g, unsigned &known_bits,
@@ -450,11 +475,39 @@ __device__ __forceinline__ void circ_and_scale_w64(int lane, V3 p, V3 v, double 
     const V3 rot = mk(O.rx[t], O.ry[t], O.rz[t]);
     const V3 rv = rv_t[t];
     // |rv| is only divided by, and compared with 0: sqrt(z) != 0 <=> z != 0 (for z == 0 the term is discarded, has_c)
-    const double zrv = sqn(rv);
-    double vn, rvn;
-    MT::norm_rcp_zpos(zrv, vn, rvn);   // (zrv == 0: garbage that goes to the lane's scratch entry, has_c below)
-    const V3 nv = MT::div3_n_pos(rv, vn, rvn);
-    const V3 cur = current_vector<MATH, true>(type, rv, g, ron_t[t], rot);   // (normalized() by a select on the divisor: 4 instructions less)
+    constexpr bool NVR = (NVL >= 0) && PRE && TILES == 1 && TYPE != T_REAL;
+    double zrv;
+    V3 nv, cur;
+    if constexpr (NVR) {
+      // (zrv == 0: the quotient is garbage in every lane and every term goes to a scratch entry, has_c below)
+      zrv = zv;   // sqn(v): the caller's -- the same expression on the same operand
+      const bool rl = (lane == NVL);
+      const V3 to_obs = ron_t[t];
+      if constexpr (TYPE == T_VEL) {
+        // the Velocity heuristic normalises rel_vel itself (nvel): that IS the term's direction, no rider needed
+        const V3 nvel = MT::template normalized<true>(rv);
+        nv = nvel;
+        V3 q;
+        cur = cv_close_threshold<MATH>(nvel - to_obs * dot(nvel, to_obs), false, q);
+      } else if constexpr (TYPE == T_GOAL) {
+        V3 raw = g - to_obs * dot(to_obs, g);
+        raw.x = rl ? v.x : raw.x; raw.y = rl ? v.y : raw.y; raw.z = rl ? v.z : raw.z;
+        V3 q;
+        cur = cv_close_threshold<MATH>(raw, rl, q);
+        nv = readlane_v3(q, NVL);
+      } else {
+        V3 raw = cross(to_obs, rot);
+        raw.x = rl ? v.x : raw.x; raw.y = rl ? v.y : raw.y; raw.z = rl ? v.z : raw.z;
+        cur = MT::template normalized<true>(raw);
+        nv = readlane_v3(cur, NVL);
+      }
+    } else {
+      zrv = sqn(rv);
+      double vn, rvn;
+      MT::norm_rcp_zpos(zrv, vn, rvn);   // (zrv == 0: garbage that goes to the lane's scratch entry, has_c below)
+      nv = MT::div3_n_pos(rv, vn, rvn);
+      cur = current_vector<MATH, true>(type, rv, g, ron_t[t], rot);   // (normalized() by a select on the divisor: 4 instructions less)
+    }
     // (round 4) multi-slot kernels: the wave minimum's read-back is pinned HERE -- between the last slot's normalisations and
     // its cross products (a scheduling barrier: nothing moves across) -- so that its LDS round trip runs under ~30
     // instructions of arithmetic instead of in front of the closest-obstacle selection (the listing showed ds_read /

@@ -74,7 +74,11 @@ class CfManager {
   std::vector<std::vector<Vector3d>> paths_cache_;
   bool paths_cached_ = false;
   pmaf_comm *comm_ = nullptr;             // attached communicator (not owned)
-  bool throw_on_numeric_fault_ = true;    // planTick: std::runtime_error on a non-finite set-point / force
+  // planTick: std::runtime_error on a non-finite set-point / force. OFF by default, like the reference, which publishes
+  // the NaN (its consumer logs it, B/src/costp_controller.cpp:317-319): the device state has already advanced to NaN when
+  // the throw comes, so every later tick throws too and an uncaught exception ends a 100 Hz node. Opt in with
+  // setThrowOnNumericFault(true) and re-init() after catching; getHealth() reports the same bits without throwing.
+  bool throw_on_numeric_fault_ = false;
   bool selected_path_on_ = false;         // enableSelectedPath survives a re-init
   void touch() { paths_cached_ = false; }
 
@@ -198,7 +202,13 @@ class CfManager {
       std::uniform_real_distribution<double> dis(-1.0, 1.0);
       for (size_t k = 0; k < (size_t)n_agents_ * n_obs_; ++k) {
         double x = dis(gen), y = dis(gen), z = dis(gen);
+        // (makeRandomVector's normalized(), B/src/helper_functions.cpp:7-13: Eigen's squaredNorm in the association the
+        // product library was built for -- compile the node with -DPMAF_DOT_RIGHT_ASSOC when it links the rassoc variant)
+#ifdef PMAF_DOT_RIGHT_ASSOC
+        double zz = x * x + (y * y + z * z);
+#else
         double zz = (x * x + y * y) + z * z;
+#endif
         if (zz > 0) { double s = std::sqrt(zz); x = x / s; y = y / s; z = z / s; }
         random_vecs_[k * 3] = x; random_vecs_[k * 3 + 1] = y; random_vecs_[k * 3 + 2] = z;
       }
@@ -424,9 +434,9 @@ class CfManager {
     double np[3];
     check(pmaf_tick(h_, obs.data(), delta_t, gains, ws, &best, np, nullptr), "planTick");
     if (next_position) *next_position = Vector3d(np[0], np[1], np[2]);
-    // failure detection (pmaf.h, PMAF_HEALTH_*): a NaN / infinite set-point must not reach the controller silently --
-    // the reference's consumer only logs it (B/src/costp_controller.cpp:317-319). The individual calls of the
-    // reference's surface (moveRealEEAgent ...) keep its behaviour; getHealth() reports for them too.
+    // failure detection (pmaf.h, PMAF_HEALTH_*), opt-in (setThrowOnNumericFault): a NaN / infinite set-point reported as
+    // an exception instead of being published like the reference does. getHealth() reports it either way, also for the
+    // individual calls of the reference's surface (moveRealEEAgent ...).
     if (throw_on_numeric_fault_ && (getHealth() & (PMAF_HEALTH_SETPOINT_NAN | PMAF_HEALTH_FORCE_NAN)))
       throw std::runtime_error("CfManager::planTick: the real agent's set-point / force is not finite (getHealth())");
     return best;

@@ -22,11 +22,15 @@ def build():
     alt = os.environ.get("PMAF_ORACLE_LIB")  # a differently configured build (tests/test_oracle_sensitivity.py)
     if alt:
         return alt
-    so = os.path.join(_HERE, "libpmaf_oracle.so")
+    # PMAF_VARIANT=rassoc: the oracle with the other dot-product association (-DPMAF_DOT_RIGHT_ASSOC), the checker of
+    # the product library built with the same switch (predictive-multi-agent-framework_amd/lib_rassoc/)
+    variant = os.environ.get("PMAF_VARIANT", "")
+    name = "libpmaf_oracle_%s.so" % variant if variant else "libpmaf_oracle.so"
+    so = os.path.join(_HERE, name)
     srcs = [os.path.join(_HERE, f) for f in ("pmaf_oracle.c", "pmaf_oracle.h", "Makefile")]
     if os.path.exists(so) and all(os.path.getmtime(so) >= os.path.getmtime(s) for s in srcs):
         return so
-    subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "libpmaf_oracle.so"])
+    subprocess.check_call(["make", "-C", _HERE, "-s", "-B", name])
     return so
 
 
@@ -146,6 +150,13 @@ def portable_exp(x):
 def _d(a):
     a = np.ascontiguousarray(a, dtype=np.float64)
     return a, a.ctypes.data_as(_dp)
+
+
+def eval_order():
+    """0: (a0 b0 + a1 b1) + a2 b2, 1: a0 b0 + (a1 b1 + a2 b2) -- must equal the product library's pmaf_eval_order()"""
+    L = lib()
+    L.orc_eval_order.restype = C.c_int
+    return int(L.orc_eval_order())
 
 
 class OraclePlanner:

@@ -45,6 +45,16 @@ static inline double vdot(v3 a, v3 b) {
   return (a.x * b.x + a.y * b.y) + a.z * b.z;
 #endif
 }
+/* which association this build uses: 0 = (a0 b0 + a1 b1) + a2 b2, 1 = a0 b0 + (a1 b1 + a2 b2) -- the values of
+ * include/pmaf.h's PMAF_EVAL_ORDER_DOT_LEFT / _RIGHT; the parity suite refuses to compare a library with an oracle of
+ * the other order (tests/conftest.py) */
+int orc_eval_order(void) {
+#ifdef PMAF_DOT_RIGHT_ASSOC
+  return 1;
+#else
+  return 0;
+#endif
+}
 static inline double vsqn(v3 a) { return vdot(a, a); }
 static inline double vnorm(v3 a) { return sqrt(vsqn(a)); }
 static inline v3 vnormalized(v3 a) {

@@ -69,6 +69,8 @@ void orc_destroy(orc_planner *p);
 
 /* CfManager::setInitialPosition, B/src/cf_manager.cpp:226-236 */
 void orc_set_initial_position(orc_planner *p, const double *pos);
+/* 3-vector dot-product association of this build (0 left, 1 right: -DPMAF_DOT_RIGHT_ASSOC), pmaf_oracle.c header */
+int orc_eval_order(void);
 /* CfManager::setRealEEAgentPosition, B/src/cf_manager.cpp:216-218 */
 void orc_set_real_position(orc_planner *p, const double *pos);
 

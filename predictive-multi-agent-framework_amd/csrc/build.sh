@@ -23,6 +23,18 @@ cd "$(dirname "$0")"
 ROCM=${ROCM_PATH:-/opt/rocm}
 HIPCC=${HIPCC:-$ROCM/bin/hipcc}
 CXX=${CXX:-g++}
+# PMAF_VARIANT: a second product library with another EVALUATION-ORDER policy, built into ../lib_<variant>/ --
+#   rassoc   3-vector dot products / squared norms associate as a0 b0 + (a1 b1 + a2 b2): Eigen 3.3's NON-vectorised
+#            redux (EIGEN_DONT_VECTORIZE, targets without a double-precision packet type) instead of the default
+#            (a0 b0 + a1 b1) + a2 b2 of its SSE2 / NEON packet path (Redux.h: predux of the first packet, then the
+#            remaining coefficient). -DPMAF_DOT_RIGHT_ASSOC on kernels AND host; the oracle has the same switch
+#            (oracle/pmaf_oracle.c) and the 0-tolerance suite runs against either pair (tests/test_build_variants.py).
+#            pmaf_eval_order() reports which one a library was built with.
+case "${PMAF_VARIANT:-}" in
+  "") ;;
+  rassoc) PMAF_OUT=${PMAF_OUT:-../lib_rassoc}; PMAF_EXTRA_FLAGS="$PMAF_EXTRA_FLAGS -DPMAF_DOT_RIGHT_ASSOC" ;;
+  *) echo "build.sh: unknown PMAF_VARIANT '$PMAF_VARIANT' (known: rassoc)" >&2; exit 2 ;;
+esac
 OUT=${PMAF_OUT:-../lib}   # PMAF_OUT: another output directory (variant / timer builds under tools/dbg)
 OBJ=$OUT/obj
 mkdir -p "$OBJ"
@@ -36,6 +48,10 @@ KFLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-m
 HFLAGS="-O2 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function -D__HIP_PLATFORM_AMD__ -I$ROCM/include ${PMAF_EXTRA_FLAGS} ${PMAF_EXTRA_HFLAGS}"
 
 DEPS_K="pmaf_types.hpp pmaf_device.hpp pmaf_rollout_w64.hpp pmaf_rollout_grp.hpp"
+# the objects of an output directory belong to ONE set of flags: a directory built with other flags is rebuilt
+STAMP="$KFLAGS | $HFLAGS | $PMAF_EXTRA_LDFLAGS"
+FLAGS_CHANGED=0
+[ "$(cat "$OBJ/flags.txt" 2>/dev/null)" = "$STAMP" ] || FLAGS_CHANGED=1
 pids=()
 names=()
 kcompile() {  # kcompile <object stem> <source> [defines...]
@@ -44,8 +60,7 @@ kcompile() {  # kcompile <object stem> <source> [defines...]
   local stale=0
   [ -f "$o" ] || stale=1
   for d in $src $DEPS_K build.sh; do [ "$d" -nt "$o" ] && stale=1; done
-  [ -n "$PMAF_EXTRA_FLAGS$PMAF_EXTRA_KFLAGS" ] && stale=1
-  [ "$OUT" != "../lib" ] && [ ! -f "$o" ] && stale=1
+  [ "$FLAGS_CHANGED" = 1 ] && stale=1
   [ "$stale" = 0 ] && return 0
   ( $HIPCC $KFLAGS "$@" -c "$src" -o "$o" 2> "$OBJ/$stem.log" ) &
   pids+=($!); names+=("$stem")
@@ -80,6 +95,7 @@ for i in "${!pids[@]}"; do
   if ! wait "${pids[$i]}"; then echo "compile failed: ${names[$i]}" >&2; cat "$OBJ/${names[$i]}.log" >&2; fail=1; fi
 done
 [ "$fail" = 0 ] || exit 1
+printf '%s' "$STAMP" > "$OBJ/flags.txt"
 for n in "${names[@]}"; do grep -E -A3 "warning:|error:" "$OBJ/$n.log" >&2 || true; done
 $HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT/libpmaf_hip.so" \
   "$OBJ"/k_w64_m2_t1.o "$OBJ"/k_w64_m2_tn.o "$OBJ"/k_w64_m0.o "$OBJ"/k_w64_m1.o "$OBJ"/k_grp_m2.o "$OBJ"/k_grp_m0.o "$OBJ"/k_w64_m3.o "$OBJ"/k_grp_m3.o "$OBJ"/k_mw_m1.o "$OBJ"/k_mw_m2.o "$OBJ"/k_mw_m3.o "$OBJ"/k_misc.o \

@@ -125,6 +125,15 @@ struct pmaf_planner {
   double *h_stage[kStage] = {nullptr, nullptr, nullptr, nullptr};  // pinned staging ring for obstacle SoA uploads
   hipEvent_t ev_stage[kStage] = {nullptr, nullptr, nullptr, nullptr};
   double *h_zc = nullptr, *d_zc = nullptr;  // mapped pinned obstacle buffer read by k_manager in pmaf_tick
+  // closed loop: pmaf_set_real_position leaves the measured position [P][3] in mapped pinned memory and the NEXT manager
+  // launch reads it from there (ManagerArgs::real_pos_src) -- the call neither waits for the running rollout nor puts a
+  // copy command in front of the tick. One buffer is enough: every entry point that launches the manager kernel returns
+  // only after that kernel has read its inputs.
+  double *h_rp = nullptr, *d_rp = nullptr;
+  bool real_pos_pending = false;
+  // pmaf_tick gave up on its time limit with its launches still queued / running (they still read h_zc / h_rp and write
+  // the mailbox): no further tick until the stream has been drained (pmaf_stop)
+  bool tick_abandoned = false;
   int stage_next = 0;
   // ---- winner-record exchange of sharded runs (pmaf_attach_comm) ----
   // Two exchange slots used alternately: the selection of tick k sends from slot k & 1, so its manager kernel only has
@@ -392,18 +401,22 @@ static void launch_rollout(pmaf_planner *h) {
                                     h->stream, args, nullptr));
     if (e1) HIP_CHECK(hipEventRecord(e1, h->stream));
     ok = true;
-  } else if (h->mw_waves)
-    ok = pmaf_k_launch_mw(h->D, h->cp, h->mw_waves, h->mw_per, h->math, h->plain_step, h->mw_lds_kb, h->stream, e0, e1);
-  else if (h->lpa == 64 && tiles64 <= 4 && !h->force_generic)
+  } else if (h->mw_waves &&
+             pmaf_k_launch_mw(h->D, h->cp, h->mw_waves, h->mw_per, h->math, h->plain_step, h->mw_lds_kb, h->stream, e0, e1))
+    ok = true;
+  else if (h->lpa == 64 && tiles64 <= 4 && !h->force_generic) {
+    // (the split kernel refused the launch -- its 72 / 96 KB LDS opt-in failed on this device, or a bad PMAF_MW_LDS_KB:
+    // the one-wave kernels serve every such population, bit for bit the same; pmaf_get_waves_per_agent reports 1 from now on)
+    if (h->mw_waves) { (void)hipGetLastError(); h->mw_waves = 0; h->mw_per = 0; }
     // ordered force sum: the DPP chain (h->dpp_sum, see pmaf_create), LDS batches on request (pmaf_rollout_w64.hpp)
     ok = pmaf_k_launch_w64(h->D, h->cp, tiles64, h->math, h->dpp_sum, h->plain_step, h->lds_rollout, h->stream, e0, e1);
-  else if (!h->force_generic && (h->lpa == 32 || h->lpa == 16 || h->lpa == 8) && (M + h->lpa - 1) / h->lpa <= 4)
+  } else if (!h->force_generic && (h->lpa == 32 || h->lpa == 16 || h->lpa == 8) && (M + h->lpa - 1) / h->lpa <= 4)
     // (policy 1, the plain fast arithmetic, exists for the w64 kernels only)
     ok = pmaf_k_launch_grp(h->D, h->cp, h->lpa, (M + h->lpa - 1) / h->lpa, h->math == MATH_FAST ? MATH_XACT : h->math,
                            h->n_blocks, h->lds_rollout, h->stream, e0, e1);
   else
     ok = pmaf_k_launch_generic(h->D, h->cp, h->lpa, h->n_blocks, h->lds_rollout, h->stream, e0, e1);
-  if (!ok) fail(PMAF_ERR_INVALID, "bad lanes_per_agent");
+  if (!ok) fail(PMAF_ERR_INVALID, "no rollout kernel for this lanes_per_agent / obstacle count in this build");
   HIP_CHECK(hipGetLastError());
   h->launches++;
   h->paths_gen++;
@@ -471,8 +484,18 @@ static const double *stage_live_obstacles_zero_copy(pmaf_planner *h, const doubl
   return h->d_zc;
 }
 
+// a pending closed-loop position into D.real_pos the slow way (stream sync + copy), for the consumers of D.real_pos
+// that are not manager launches (winner-record packing, the state blob)
+static void flush_real_position(pmaf_planner *h) {
+  if (!h->real_pos_pending) return;
+  sync(h);
+  h->upload(h->D.real_pos, h->real_pos_h.data(), (size_t)h->D.P * 3);
+  h->real_pos_pending = false;
+}
+
 static void launch_manager(pmaf_planner *h, const ManagerArgs &A0, hipEvent_t done = nullptr) {
   ManagerArgs A = A0;
+  if (h->real_pos_pending) { A.real_pos_src = h->d_rp; h->real_pos_pending = false; }
   if (A.do_reset) h->paths_gen++;
   if (A.do_reset && h->uses_closest_table()) { A.compute_closest = h->closest_dirty ? 1 : 0; h->closest_dirty = false; }
   A.tuned_real_step = (h->math == MATH_XACT && !h->force_generic) ? 1 : 0;
@@ -521,9 +544,16 @@ static void wait_mailbox(pmaf_planner *h, double seq) {
       if ((++spins & 0x3fffu) == 0 || (h->blocking_wait && (spins & 0x3fffu) < 0x400)) {
         const auto now = std::chrono::steady_clock::now();
         if (!timing) { timing = true; t_start = now; }
-        else if (std::chrono::duration<double>(now - t_start).count() > h->tick_timeout_s)
-          fail(PMAF_ERR_DEVICE, "pmaf_tick: no result from the manager kernel within the time limit (PMAF_TICK_TIMEOUT_S): "
-                                "device hung, or the previous rollout still running");
+        else if (std::chrono::duration<double>(now - t_start).count() > h->tick_timeout_s) {
+          // the two launches of this tick are still queued or running: they will read the zero-copy buffers and write
+          // the mailbox later, so the handle takes no further tick until the stream has been drained (pmaf_stop)
+          h->tick_abandoned = true;
+          char msg[384];
+          snprintf(msg, sizeof msg, "pmaf_tick: no result from the manager kernel within the time limit (PMAF_TICK_TIMEOUT_S = %g s): "
+                   "device hung, the previous rollout still running%s; call pmaf_stop() before the next tick", h->tick_timeout_s,
+                   h->peer.on ? ", or a coupled peer's header outstanding (the in-kernel wait is bounded by PMAF_PEER_TIMEOUT_S)" : "");
+          fail(PMAF_ERR_DEVICE, msg);
+        }
         hipError_t e = hipStreamQuery(h->stream);
         if (e == hipErrorNotReady) continue;
         if (e != hipSuccess) throw HipError{e, "hipStreamQuery (mailbox wait)", __LINE__};
@@ -688,7 +718,7 @@ static void pci_id_of(int device, int32_t out[3]) {
   (void)hipGetLastError();
 }
 static_assert(sizeof(PeerHandleBlob) == PMAF_PEER_HANDLE_BYTES, "pmaf.h: PMAF_PEER_HANDLE_BYTES");
-static const uint64_t kPeerMagic = 0x504d41465f505231ull;  // "PMAF_PR1"
+static const uint64_t kPeerMagic = 0x504d41465f505232ull;  // "PMAF_PR2" (the blob of ABI 5 changed layout: pad -> fine, pci[3])
 
 static size_t peer_inbox_doubles(int world, int P) { return (size_t)2 * world * P * PMAF_PEER_SLOT; }
 
@@ -756,6 +786,13 @@ extern "C" {
 
 const char *pmaf_last_error(void) { return g_err.c_str(); }
 int pmaf_abi_version(void) { return PMAF_ABI_VERSION; }
+int pmaf_eval_order(void) {
+#ifdef PMAF_DOT_RIGHT_ASSOC
+  return PMAF_EVAL_ORDER_DOT_RIGHT;
+#else
+  return PMAF_EVAL_ORDER_DOT_LEFT;
+#endif
+}
 
 int pmaf_create(const pmaf_params *prm, pmaf_planner **out) {
   pmaf_planner *h = nullptr;
@@ -885,6 +922,8 @@ int pmaf_create(const pmaf_params *prm, pmaf_planner **out) {
     HIP_CHECK(hipHostGetDevicePointer((void **)&h->d_out, h->h_out, 0));
     HIP_CHECK(hipHostMalloc((void **)&h->h_zc, sizeof(double) * (size_t)P * 7 * n_obs, hipHostMallocMapped));
     HIP_CHECK(hipHostGetDevicePointer((void **)&h->d_zc, h->h_zc, 0));
+    HIP_CHECK(hipHostMalloc((void **)&h->h_rp, sizeof(double) * (size_t)P * 3, hipHostMallocMapped));
+    HIP_CHECK(hipHostGetDevicePointer((void **)&h->d_rp, h->h_rp, 0));
     for (int i = 0; i < pmaf_planner::kStage; i++) {
       HIP_CHECK(hipHostMalloc((void **)&h->h_stage[i], sizeof(double) * (size_t)P * 7 * n_obs, hipHostMallocDefault));
       HIP_CHECK(hipEventCreateWithFlags(&h->ev_stage[i], hipEventDisableTiming));
@@ -983,6 +1022,7 @@ int pmaf_destroy(pmaf_planner *h) {
   for (void *p : h->scratch) (void)hipFree(p);
   if (h->h_out) (void)hipHostFree(h->h_out);
   if (h->h_zc) (void)hipHostFree(h->h_zc);
+  if (h->h_rp) (void)hipHostFree(h->h_rp);
   if (h->h_wp) (void)hipHostFree(h->h_wp);
   if (h->h_wph) (void)hipHostFree(h->h_wph);
   if (h->h_paths) (void)hipHostFree(h->h_paths);
@@ -1012,6 +1052,7 @@ int pmaf_set_initial_position(pmaf_planner *h, const double *pos) {
     h->upload(D.agent_init_pos, pos, P * 3);
     h->upload(D.real_init_pos, pos, P * 3);
     h->upload(D.real_pos, pos, P * 3);
+    h->real_pos_pending = false;   // (a closed-loop position handed over before this call is superseded)
     h->upload(D.start_pos, pos, P * 3);
     // CfAgent::setPosition = clear + push_back for every predicted agent
     h->paths_gen++;
@@ -1031,9 +1072,12 @@ int pmaf_set_real_position(pmaf_planner *h, const double *pos) {
   return guarded([&] {
     REQUIRE(h && pos, "pmaf_set_real_position: NULL argument");
     check_range(pos, (size_t)h->D.P * 3, "pmaf_set_real_position");
-    h->use_device();
-    sync(h);
-    h->upload(h->D.real_pos, pos, h->D.P * 3);
+    // RealCfAgent::setPosition = push_back (B/src/cf_agent.cpp:44-46): the measured position becomes the real agent's
+    // latest one. Handed to the next manager launch through mapped pinned memory -- no wait for the running rollout,
+    // no copy command (the node calls this in front of every tick when open_loop is false,
+    // B/src/panda_bimanual_control.cpp:333-335)
+    std::memcpy(h->h_rp, pos, sizeof(double) * (size_t)h->D.P * 3);
+    h->real_pos_pending = true;
     h->real_pos_h.assign(pos, pos + h->D.P * 3);
     for (int p = 0; p < h->D.P; p++)
       h->real_path[p].insert(h->real_path[p].end(), {pos[p * 3], pos[p * 3 + 1], pos[p * 3 + 2]});
@@ -1067,6 +1111,7 @@ int pmaf_stop(pmaf_planner *h) {
     REQUIRE(h, "pmaf_stop: NULL handle");
     h->use_device();
     sync(h);
+    h->tick_abandoned = false;   // the stream is empty: an abandoned tick's kernels are through
   });
 }
 
@@ -1156,6 +1201,15 @@ int pmaf_tick(pmaf_planner *h, const double *obstacles, double dt, const double 
     REQUIRE(h && cost_gains && ws, "pmaf_tick: NULL argument");
     const auto t_entry = std::chrono::steady_clock::now();
     h->use_device();
+    if (h->tick_abandoned)
+      fail(PMAF_ERR_STATE, "pmaf_tick: the previous tick ran into its time limit with its kernels still queued; drain the "
+                           "stream with pmaf_stop() (or recreate the handle) before the next tick");
+    // whatever fails between here and the manager kernel's result: the list handed over with this call may not have
+    // reached D.obs_live, so it must not count as resident (a retry with the same list has to hand it over again)
+    struct ResidentGuard {
+      pmaf_planner *h; bool armed = true;
+      ~ResidentGuard() { if (armed) { h->live_resident.clear(); h->last_live.clear(); h->closest_dirty = true; } }
+    } resident_guard{h};
     set_cost_params(h, cost_gains, ws);
     ensure_scores(h);
     ManagerArgs A{};
@@ -1194,6 +1248,7 @@ int pmaf_tick(pmaf_planner *h, const double *obstacles, double dt, const double 
       h->tick_head = (h->tick_head + 1) % pmaf_planner::TICK_RING;
       if (h->tick_count < pmaf_planner::TICK_RING) h->tick_count++;
     }
+    resident_guard.armed = false;   // the manager kernel has read the list and published its result
     const int peer_late = h->peer.on ? peer_book_tick(h) : 0;
     if (h->x.c) begin_exchange(h, scored);  // pack + all-gather on the exchange stream, beside the rollout
     refresh_real_cache(h);
@@ -1572,6 +1627,7 @@ int pmaf_write_winner_records(pmaf_planner *h, void *dst_device, size_t bytes) {
     REQUIRE(h && dst_device, "pmaf_write_winner_records: NULL argument");
     REQUIRE(bytes >= sizeof(double) * pmaf_winner_record_doubles(h) * h->D.P, "pmaf_write_winner_records: buffer too small");
     h->use_device();
+    flush_real_position(h);
     pmaf_k_launch_winner(h->D, (double *)dst_device, h->stream);
     HIP_CHECK(hipGetLastError());
   });
@@ -1584,6 +1640,7 @@ int pmaf_allgather_winners(pmaf_planner *h, pmaf_comm *c, void *recv_device, siz
     REQUIRE(bytes >= sizeof(double) * n_local * (size_t)c->world, "pmaf_allgather_winners: receive buffer too small");
     h->use_device();
     if (!h->d_send1) HIP_CHECK(hipMalloc((void **)&h->d_send1, sizeof(double) * n_local));
+    flush_real_position(h);
     pmaf_k_launch_winner(h->D, h->d_send1, h->stream);
     HIP_CHECK(hipGetLastError());
     if (c->rccl) {
@@ -1794,6 +1851,9 @@ int pmaf_peer_connect(pmaf_planner *h, int32_t world, int32_t rank, const void *
     pr.us_per_tick = 1e3 / (double)khz;
     double timeout_s = 2.0;
     { const char *to = getenv("PMAF_PEER_TIMEOUT_S"); if (to && atof(to) > 0.0) timeout_s = atof(to); }
+    // the in-kernel wait for a peer's header must end before the host's wait for the tick does (PMAF_TICK_TIMEOUT_S):
+    // otherwise a late peer is reported as a hung device and the tick is abandoned with its kernel still waiting
+    if (timeout_s > 0.5 * h->tick_timeout_s) timeout_s = 0.5 * h->tick_timeout_s;
     PeerView v{};
     v.world = world; v.rank = rank; v.P = P;
     v.inbox = pr.inbox;
@@ -2026,6 +2086,7 @@ int pmaf_save_state(pmaf_planner *h, void *blob, size_t bytes) {
     h->use_device();
     sync(h);
     normalise_path_buffer(h);
+    flush_real_position(h);   // (closed loop: a measured position not yet consumed by a manager launch)
     char *w = static_cast<char *>(blob);
     StateHeader hd{};
     hd.magic = kStateMagic; hd.abi = PMAF_ABI_VERSION;
@@ -2099,6 +2160,7 @@ int pmaf_load_state(pmaf_planner *h, const void *blob, size_t bytes) {
     h->scores_valid = hd.scores_valid != 0;
     h->rollout_pending = hd.rollout_pending != 0;
     h->stepped = hd.stepped != 0;
+    h->real_pos_pending = false;
     h->closest_dirty = true;   // (the blob's table matches its obs_start; recompute at the next reset all the same)
     h->last_live.clear();
     h->live_resident.clear();

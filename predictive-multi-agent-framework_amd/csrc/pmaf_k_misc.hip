@@ -260,7 +260,12 @@ __global__ __launch_bounds__(64) void k_manager(DevView D, CostParams CP, Manage
   const int had_best = D.has_best[pop];
   const int old_best_id = D.best_id[pop];
   int htype = D.best_type[pop];
-  V3 rp = mk(D.real_pos[pop * 3], D.real_pos[pop * 3 + 1], D.real_pos[pop * 3 + 2]);
+  // (closed loop: the measured position handed over by pmaf_set_real_position since the last manager launch)
+  const double *rp_src = A.real_pos_src ? A.real_pos_src : D.real_pos;
+  V3 rp = mk(rp_src[pop * 3], rp_src[pop * 3 + 1], rp_src[pop * 3 + 2]);
+  if (A.real_pos_src && !A.do_move && lane == 0) {   // no step in this launch: keep it for the launches that follow
+    D.real_pos[pop * 3] = rp.x; D.real_pos[pop * 3 + 1] = rp.y; D.real_pos[pop * 3 + 2] = rp.z;
+  }
   V3 rv = mk(D.real_vel[pop * 3], D.real_vel[pop * 3 + 1], D.real_vel[pop * 3 + 2]);
   V3 rf = mk(D.real_force[pop * 3], D.real_force[pop * 3 + 1], D.real_force[pop * 3 + 2]);
   const V3 init_pos = mk(D.real_init_pos[pop * 3], D.real_init_pos[pop * 3 + 1], D.real_init_pos[pop * 3 + 2]);

@@ -141,6 +141,10 @@ struct ManagerArgs {
   // number (= seq, written last behind a system-scope fence)}; NULL: off
   double *wp_out;
   double *wp_hdr;
+  // closed loop (pmaf_set_real_position = CfManager::setRealEEAgentPosition, B/src/cf_manager.cpp:216-218): the measured
+  // position [P][3] in mapped pinned HOST memory replaces the real agent's latest position before anything else of this
+  // launch reads it (no sync, no copy command in front of the tick); NULL: D.real_pos holds it
+  const double *real_pos_src;
 };
 
 // synchronous stepping (CfAgent::cfPlanner, B/src/cf_agent.cpp:278-300): k_plan_steps

@@ -13,7 +13,10 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # PMAF_LIB_PATH: load an alternative build of the same library (debug / timer builds)
-LIB_PATH = os.environ.get("PMAF_LIB_PATH") or os.path.join(_HERE, "lib", "libpmaf_hip.so")
+# PMAF_VARIANT=rassoc: the library built with the other evaluation-order policy (csrc/build.sh, include/pmaf.h
+# pmaf_eval_order) out of lib_rassoc/ -- the oracle binding (oracle/orc.py) follows the same variable
+VARIANT = os.environ.get("PMAF_VARIANT", "")
+LIB_PATH = os.environ.get("PMAF_LIB_PATH") or os.path.join(_HERE, "lib_" + VARIANT if VARIANT else "lib", "libpmaf_hip.so")
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int32)
@@ -45,6 +48,7 @@ SYMBOLS = {
     "pmaf_destroy": (C.c_int, [_V]),
     "pmaf_last_error": (C.c_char_p, []),
     "pmaf_abi_version": (C.c_int, []),
+    "pmaf_eval_order": (C.c_int, []),
     "pmaf_set_initial_position": (C.c_int, [_V, _dp]),
     "pmaf_set_real_position": (C.c_int, [_V, _dp]),
     "pmaf_start": (C.c_int, [_V]),

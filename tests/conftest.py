@@ -37,10 +37,27 @@ def scenes(pmaf):
 
 
 @pytest.fixture(scope="session")
-def oracle():
+def oracle(pmaf):
+    """the CPU oracle (checker). PMAF_VARIANT selects the evaluation-order pair: the library out of lib_<variant>/ and the
+    oracle built with the same switch -- a 0-tolerance comparison across the two orders would be meaningless, so it is
+    refused here"""
     from oracle import orc
     orc.build()
+    try:
+        L = pmaf.load_library()
+    except OSError:
+        L = None
+    if L is not None:
+        assert L.pmaf_eval_order() == orc.eval_order(), "library and oracle were built with different dot-product associations"
     return orc
+
+
+def binary_env(pmaf):
+    """environment for the C++ test drivers (tools/plan_task, tests/cpp/facade_tick): their RUNPATH points at lib/, so
+    the directory of the library under test goes in front of it (PMAF_VARIANT / PMAF_LIB_PATH builds)"""
+    d = os.path.dirname(os.path.abspath(pmaf.LIB_PATH))
+    old = os.environ.get("LD_LIBRARY_PATH", "")
+    return dict(os.environ, LD_LIBRARY_PATH=d + (":" + old if old else ""))
 
 
 def has_gpu():

@@ -62,7 +62,8 @@ def test_facade_node_sequence_matches_oracle(pmaf, oracle, scenes, tmp_path, hip
         rvf = tmp_path / "rv.bin"
         np.ascontiguousarray(sc["random_vecs"]).tofile(rvf)
         exe = os.path.join(ROOT, "tests", "cpp", "facade_tick")
-        out = subprocess.run([exe, str(N), str(cap), str(ticks), str(rvf)], capture_output=True, check=True).stdout.decode()
+        out = subprocess.run([exe, str(N), str(cap), str(ticks), str(rvf)], capture_output=True, check=True,
+                             env=conftest.binary_env(pmaf)).stdout.decode()
         ora = oracle.OraclePlanner(sc, mgr_init_pos=sc["start"])
         ora.set_initial_position(sc["start"])
         lines = out.strip().split("\n")

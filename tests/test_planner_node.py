@@ -83,7 +83,7 @@ def test_headless_task_run_matches_oracle(pmaf, oracle, scenes, tmp_path, hip_li
         np.ascontiguousarray(sc["random_vecs"]).tofile(rvf)
         cmd = [EXE, os.path.join(TASKS, task + ".yaml"), "--start"] + [repr(float(x)) for x in sc["start"]] + \
               ["--max-ticks", "1200", "--random-vecs", str(rvf), "--consumer"]
-        r = subprocess.run(cmd, capture_output=True, check=True)
+        r = subprocess.run(cmd, capture_output=True, check=True, env=conftest.binary_env(pmaf))
         lines = [l for l in r.stdout.decode().strip().split("\n")]
         rows = _oracle_node_run(oracle, scenes, sc, 1200)
         data = [l for l in lines if not l.startswith("#") and not l.startswith("C ")]

@@ -7,7 +7,16 @@
 // reference's TrajectoryBuffer + followTrajectory acceptance logic, cycled at 1 kHz until it asks for the next
 // point, like VrepController::targetPoseCallback) and each tick prints a second line
 //   C <tick> <controller cycles> <v_goal> <next_ng> <accepted> <refused> <nan> <too_close> <inconsistent>
-// usage: plan_task <task.yaml> --start x y z [--max-ticks N] [--seed S] [--random-vecs f.bin] [--consumer] [--dump-params]
+// --lag F (closed loop, task files with open_loop: false): the controller does not reach the set-point -- the position it
+//   reports back is  set-point - F * (set-point - previous reported position)  (a deterministic tracking error), which
+//   planCallback hands to CfManager::setRealEEAgentPosition in front of the tick (B/src/panda_bimanual_control.cpp:333-335)
+// --goal-ticks N: leave every plan goal after N ticks even if it is not reached (a goal change mid-run: the best agent of
+//   the running population is carried into the next init, B/src/cf_manager.cpp:344-354)
+// --random-vecs f.bin: explicit Random-agent vectors [N][n_obs][3]; a file with several such blocks gives the k-th plan
+//   goal's init() the k-th block (the reference draws fresh vectors in every init)
+// usage: plan_task <task.yaml> --start x y z [--max-ticks N] [--goal-ticks N] [--lag F] [--seed S] [--random-vecs f.bin]
+//                  [--consumer] [--dump-params]
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -47,13 +56,16 @@ static void dump(const TaskParams &t) {
 int main(int argc, char **argv) {
   if (argc < 2) { fprintf(stderr, "usage: plan_task <task.yaml> --start x y z [--max-ticks N] [--seed S] [--dump-params]\n"); return 2; }
   double start[3] = {0, 0, 0};
-  long max_ticks = 5000;
+  long max_ticks = 5000, goal_ticks = -1;
+  double lag = 0.0;
   unsigned long long seed = 1;
   bool dump_only = false, with_consumer = false;
   const char *rv_file = nullptr;
   for (int i = 2; i < argc; ++i) {
     if (!strcmp(argv[i], "--start") && i + 3 < argc) { for (int c = 0; c < 3; ++c) start[c] = atof(argv[++i]); }
     else if (!strcmp(argv[i], "--max-ticks") && i + 1 < argc) max_ticks = atol(argv[++i]);
+    else if (!strcmp(argv[i], "--goal-ticks") && i + 1 < argc) goal_ticks = atol(argv[++i]);
+    else if (!strcmp(argv[i], "--lag") && i + 1 < argc) lag = atof(argv[++i]);
     else if (!strcmp(argv[i], "--seed") && i + 1 < argc) seed = strtoull(argv[++i], nullptr, 10);
     else if (!strcmp(argv[i], "--dump-params")) dump_only = true;
     else if (!strcmp(argv[i], "--consumer")) with_consumer = true;
@@ -63,19 +75,30 @@ int main(int argc, char **argv) {
     TaskParams task = loadTaskFile(argv[1]);
     if (dump_only) { dump(task); return 0; }
     PlannerNode node(task, seed);
-    if (rv_file) {  // explicit Random-agent vectors [N][n_obs][3] (tests)
-      std::vector<double> rv((size_t)task.num_agents_ee * task.obstacles.size() * 3);
+    std::vector<double> rv_all;   // explicit Random-agent vectors, one [N][n_obs][3] block per plan goal (tests)
+    const size_t rv_block = (size_t)task.num_agents_ee * task.obstacles.size() * 3;
+    if (rv_file) {
       FILE *f = fopen(rv_file, "rb");
-      if (!f || fread(rv.data(), sizeof(double), rv.size(), f) != rv.size()) throw std::runtime_error("cannot read --random-vecs file");
+      if (!f) throw std::runtime_error("cannot read --random-vecs file");
+      std::vector<double> blk(rv_block);
+      while (fread(blk.data(), sizeof(double), rv_block, f) == rv_block) rv_all.insert(rv_all.end(), blk.begin(), blk.end());
       fclose(f);
-      node.manager().setRandomVectors(rv);
+      if (rv_all.empty()) throw std::runtime_error("--random-vecs file holds no complete [N][n_obs][3] block");
     }
+    size_t plan_goal = 0;
     DynamicObstacleSource source(task.obstacles, task.frequency_ros);
     Position position{{start[0], start[1], start[2]}};
     node.planCallback(position, nullptr);              // planning not active: records the initial position
     long tick = 0;
     for (const GoalSpec &goal : task.goals) {
       if (goal.type != "plan") continue;               // key / gesture / goto ...: operator or robot actions
+      if (!rv_all.empty()) {
+        const size_t k = std::min(plan_goal, rv_all.size() / rv_block - 1);
+        node.manager().setRandomVectors(std::vector<double>(rv_all.begin() + k * rv_block, rv_all.begin() + (k + 1) * rv_block));
+      }
+      if (plan_goal > 0) node.planCallback(position, nullptr);   // between goals the controller's position keeps arriving (:364-367)
+      ++plan_goal;
+      const long goal_start = tick;
       Position sp = node.startPlan(goal);
       SetPointConsumer consumer;                         // the controller is reset at the start pose ...
       consumer.reset(Vector3d(start[0], start[1], start[2]));
@@ -98,13 +121,18 @@ int main(int argc, char **argv) {
                  cn.accepted, cn.refused, cn.nan, cn.too_close, cn.inconsistent);
         }
         prev = nv;
-        position = next;                               // echo: the set-point is reached
+        if (lag != 0.0)                                // the controller trails the set-point (closed loop, --lag)
+          for (int c = 0; c < 3; ++c) position.data[c] = next.data[c] - lag * (next.data[c] - position.data[c]);
+        else
+          position = next;                             // echo: the set-point is reached
         node.obstacleCallback(source.step());          // obstacle stream between ticks
         ++tick;
         if (goal.end_condition == "reached" && node.reached()) break;
+        if (goal_ticks >= 0 && tick - goal_start >= goal_ticks) break;
       }
       node.finishGoal();
-      printf("# goal %s after %ld ticks, distance %.6g\n", node.reached() ? "reached" : "not reached", tick, node.goalDistance());
+      printf("# goal %s after %ld ticks, distance %.6g, planned trajectory %zu points\n", node.reached() ? "reached" : "not reached", tick,
+             node.goalDistance(), node.manager().getPlannedTrajectory().size());
     }
   } catch (const std::exception &e) {
     fprintf(stderr, "plan_task: %s\n", e.what());

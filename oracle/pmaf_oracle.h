@@ -14,6 +14,20 @@
  * /root/reference/src/bimanual_planning_ros/) and is additionally checked
  * against the probe numbers recorded in SURVEY.md section 8(c).
  *
+ * HOW TO PIN IT (one command, on a machine that can build the reference:
+ * Eigen3 + the dqrobotics packages installed; NOT possible in this repo's
+ * build container, where the script exits 77 = skipped):
+ *     bash oracle/pin/make_pin.sh /path/to/predictive-multi-agent-framework
+ *     python -m pytest tests/test_reference_pin.py -q -s
+ * The script compiles the reference's cf_agent.cpp + cf_manager.cpp unmodified
+ * with oracle/pin/pin_harness.cpp (it drives CfManager through the planner
+ * node's call sequence, Random vectors from the scenario file, every rollout
+ * run to its guard) and writes tests/golden/ref_*.json; the test holds this
+ * oracle to them BIT FOR BIT under both 3-vector dot-product associations
+ * (PMAF_DOT_RIGHT_ASSOC, orc_eval_order) and names the product library
+ * variant that matches the reference build (include/pmaf.h, pmaf_eval_order).
+ * Once those files are committed this header and DESIGN.md drop "unpinned".
+ *
  * Conventions: all arithmetic IEEE double, compiled with -ffp-contract=off.
  * obstacles are flat [n_obs][7] = px,py,pz,vx,vy,vz,r; the LAST obstacle
  * (index n_obs-1) is the repulsive-only one (B/src/cf_agent.cpp:159-181),

@@ -80,8 +80,19 @@ int pmaf_comm_init_rccl(int32_t world, int32_t rank, const void *id, int32_t dev
   ncclComm_t comm = nullptr;
   ncclResult_t r = ncclCommInitRank(&comm, world, uid, rank);
   if (r != ncclSuccess) return fail(PMAF_ERR_DEVICE, nccl_text("ncclCommInitRank", r));
+  // what RCCL itself says it joined (reported by pmaf_comm_world, bench.py's config.collective_world): a communicator
+  // that came up with another rank count than asked for must not pass as an N-rank run
+  int n_rccl = 0, r_rccl = -1;
+  r = ncclCommCount(comm, &n_rccl);
+  if (r == ncclSuccess) r = ncclCommUserRank(comm, &r_rccl);
+  if (r != ncclSuccess || n_rccl != world || r_rccl != rank) {
+    ncclCommDestroy(comm);
+    if (r != ncclSuccess) return fail(PMAF_ERR_DEVICE, nccl_text("ncclCommCount / ncclCommUserRank", r));
+    return fail(PMAF_ERR_DEVICE, "pmaf_comm_init_rccl: RCCL reports " + std::to_string(n_rccl) + " rank(s), this one as rank " +
+                                     std::to_string(r_rccl) + "; asked for rank " + std::to_string(rank) + " of " + std::to_string(world));
+  }
   pmaf_comm *c = new pmaf_comm();
-  c->world = world; c->rank = rank; c->device = dev;
+  c->world = n_rccl; c->rank = r_rccl; c->device = dev;
   c->rccl = true; c->nccl_comm = comm; c->owns_nccl = true;
   return finish_rccl_comm(c, out);
 }

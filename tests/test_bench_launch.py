@@ -52,7 +52,7 @@ def test_gpus_8_dry_run_and_the_plan_budget():
     assert out["n_gpus"] == 8 and out["collective_world"] == 8
     assert [w[0] for w in out["ranks"]] == list(range(8)) and len({w[2] for w in out["ranks"]}) == 8
     assert out["allgather_of_ranks"] == [float(k) for k in range(8)]
-    assert out["plan"] == ["C1", "C3", "C5_sharded", "C4", "C2_contracted", "C3_contracted", "C5_sharded_contracted"]
+    assert out["plan"] == ["C1", "C3", "C5_sharded", "C4", "task_static1", "C2_contracted", "C3_contracted", "C5_sharded_contracted"]
     assert out["budget_s"] < 60.0, out["budget_rows"]
 
 

@@ -542,6 +542,25 @@ def test_bench_multi_rank_modes_on_one_gpu(args, n_ranks):
     assert out["h_eff"] == out["config"]["horizon"]
 
 
+@pytest.mark.timeout(600)
+def test_bench_c4_couples_through_the_host_when_inboxes_cannot_be_shared():
+    """C4 one arm per rank on a runtime that cannot export fine-grained inboxes (forced here with
+    PMAF_BENCH_C4_HOST_COUPLED=1): NOT a skipped record -- each tick waits for the winner table and takes the other arm's
+    set-point out of it, and the record says so"""
+    import json
+    import subprocess
+    env = dict(os.environ, PMAF_BENCH_BACKEND="gloo", PMAF_BENCH_SINGLE_DEVICE="1", PMAF_BENCH_C4_HOST_COUPLED="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"),
+           "--gpus", "2", "--steps", "12", "--warmup", "3", "--min-seconds", "0.05", "--flop-ticks", "0", "--config", "C4"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=500, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["value"] and out["value"] > 0 and "skipped" not in out
+    assert "THROUGH THE HOST" in out["config"]["workload"] and out["header_exchange_us"] is None
+    assert out["allgather_us"]["n"] >= 12 and out["h_eff"] == out["config"]["horizon"]
+
+
 @pytest.mark.timeout(900)
 def test_bench_self_spawns_its_ranks_and_reports_every_config():
     """`python bench.py --gpus 2` WITHOUT a launcher (two ranks sharing GPU 0 under the test hooks): the script starts
@@ -558,11 +577,19 @@ def test_bench_self_spawns_its_ranks_and_reports_every_config():
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert out["n_gpus"] == 2 and out["config"]["collective_world"] == 2
     cfgs = out["configs"]
-    assert set(cfgs) == {"C1", "C3", "C5_sharded", "C4", "C2_contracted", "C3_contracted", "C5_sharded_contracted"}
+    assert set(cfgs) == {"C1", "C3", "C5_sharded", "C4", "task_static1", "C2_contracted", "C3_contracted", "C5_sharded_contracted"}
     assert all(cfgs[k]["arithmetic_policy"] == ("contracted" if k.endswith("_contracted") else "strict") for k in cfgs)
+    # parity flags: strict = bit-exact; the contracted policy's tolerance contract does not hold on C5
+    assert all(cfgs[k]["parity_met"] for k in cfgs if not k.endswith("_contracted"))
+    assert cfgs["C2_contracted"]["parity_met"] and cfgs["C3_contracted"]["parity_met"] and not cfgs["C5_sharded_contracted"]["parity_met"]
+    ts = cfgs.pop("task_static1")   # the shipped operating point: early stops allowed, no exchange
+    assert ts["agents"] == 10 and ts["horizon"] == 1499 and ts["obstacles"] == 9 and 100 < ts["h_eff"] <= 1499
+    assert ts["regime"]["tick_budget_ms"] == 10.0 and 0 < ts["regime"]["share_of_the_control_period"] < 1
+    assert ts["kernel"] == "k_rollout_w64<1, 2, true, true>"
     for name, c in cfgs.items():
         assert c["rollouts_per_s"] > 0 and c["blocks"] >= 5 and c["h_eff"] == c["horizon"], name
         assert c["allgather_us"]["n"] >= 10 and c["kernel"].startswith("k_rollout")
+    assert cfgs["C4"]["coupling"] == "peer mailboxes"
     assert cfgs["C5_sharded"]["populations_total"] == 8 and cfgs["C5_sharded"]["populations_per_gpu"] == 4
     assert cfgs["C2_contracted"]["kernel"] == "k_rollout_w64<1, 3, true, true>"
     hx = cfgs["C4"]["header_exchange_us"]

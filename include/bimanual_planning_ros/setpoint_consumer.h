@@ -76,7 +76,11 @@ class SetPointConsumer {
   static V sub(V a, V b) { return V{a.x - b.x, a.y - b.y, a.z - b.z}; }
   static V mul(double s, V a) { return V{s * a.x, s * a.y, s * a.z}; }
   static V mulr(V a, double s) { return V{a.x * s, a.y * s, a.z * s}; }
+#ifdef PMAF_DOT_RIGHT_ASSOC   // the evaluation-order policy of the library this is built against (include/pmaf.h, pmaf_eval_order)
+  static double dot(V a, V b) { return a.x * b.x + (a.y * b.y + a.z * b.z); }
+#else
   static double dot(V a, V b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+#endif
   static double norm(V a) { return std::sqrt(dot(a, a)); }
   static V normalized(V a) {
     const double z = dot(a, a);

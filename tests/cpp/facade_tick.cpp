@@ -22,7 +22,8 @@ using namespace ghostplanner::cfplanner;
 // `health` mode (ABI 5): failure detection and the selected path through the facade. One Had-heuristic agent (the
 // reference's layout puts it first, B/src/cf_manager.cpp:70-104) flies straight at an obstacle whose centre lies on the
 // agent-goal line: at first contact the REAL agent's rotation vector is 0 / 0 (B/src/cf_agent.cpp:599-611), its force and
-// set-point turn NaN, and planTick must throw instead of handing the NaN on. Until then every planTick's selected path
+// set-point turn NaN: by default planTick hands the NaN on like the reference (health word set), with
+// setThrowOnNumericFault(true) it throws at that very tick. Until then every planTick's selected path
 // (pmaf_view_winner_path) must be the best agent's predicted path as it was scored.
 static int health_mode() {
   std::vector<Obstacle> obstacles = {Obstacle(Vector3d(0.0, 0.0, 0.7), Vector3d(0, 0, 0), 0.05),
@@ -31,7 +32,27 @@ static int health_mode() {
   Vector6d ws;
   const double wsv[6] = {1.0, -1.0, 0.3, -0.3, 1.1, 0.2};
   for (int i = 0; i < 6; ++i) ws(i) = wsv[i];
+  // DEFAULT behaviour = the reference's: the NaN set-point is published, nothing throws (its consumer logs it,
+  // B/src/costp_controller.cpp:317-319); the health word reports it
+  int t_default = -1;
+  {
+    CfManager d;
+    d.setInitialPosition(start);
+    d.init(goal, 0.01, obstacles, {4.0}, {0.025}, {0.08}, {3.0}, {0.0}, {0.02}, 0.2, 0.25, 0.35, 61, 1);
+    d.setInitialPosition(start);
+    for (int t = 0; t < 400 && t_default < 0; ++t) {
+      Vector3d np(0, 0, 0);
+      try { d.planTick(obstacles, 0.01, 100.0, 10.0, 0.001, 1.0, ws, &np); }
+      catch (const std::exception &e) { fprintf(stderr, "planTick threw without the opt-in: %s\n", e.what()); return 10; }
+      const bool nan = np.x() != np.x() || np.y() != np.y() || np.z() != np.z();
+      const bool bits = (d.getHealth() & (PMAF_HEALTH_FORCE_NAN | PMAF_HEALTH_SETPOINT_NAN)) != 0;
+      if (nan != bits) { fprintf(stderr, "health word and set-point disagree at tick %d\n", t); return 11; }
+      if (nan) t_default = t;
+    }
+    if (t_default < 0) { fprintf(stderr, "the real agent never met the degenerate obstacle (default mode)\n"); return 9; }
+  }
   CfManager m;
+  m.setThrowOnNumericFault(true);   // opt-in: the NaN as an exception
   m.setInitialPosition(start);
   m.init(goal, 0.01, obstacles, {4.0}, {0.025}, {0.08}, {3.0}, {0.0}, {0.02}, 0.2, 0.25, 0.35, 61, 1);
   m.setInitialPosition(start);
@@ -46,6 +67,7 @@ static int health_mode() {
     } catch (const std::runtime_error &e) {
       const int hb = m.getHealth();
       if (!(hb & PMAF_HEALTH_FORCE_NAN) || !(hb & PMAF_HEALTH_SETPOINT_NAN)) { fprintf(stderr, "throw without health bits: %d\n", hb); return 7; }
+      if (t != t_default) { fprintf(stderr, "throw at tick %d, NaN without the opt-in at tick %d\n", t, t_default); return 12; }
       printf("H %d %d\nS %ld\n", t, hb, checked);
       return 0;
     }

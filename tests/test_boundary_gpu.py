@@ -23,7 +23,7 @@ import conftest
 pytestmark = pytest.mark.gpu
 
 ROOT = conftest.ROOT
-EXE = os.path.join(ROOT, "tools", "plan_task")
+EXE = conftest.exe(os.path.join(ROOT, "tools", "plan_task"))
 TASKS = os.path.join(ROOT, "tests", "golden", "tasks")
 LAG = 0.3   # share of the last step the controller has NOT covered when it reports its position
 

@@ -61,7 +61,7 @@ def test_facade_node_sequence_matches_oracle(pmaf, oracle, scenes, tmp_path, hip
         sc = scenes.static1_scene(N, cap - 1)
         rvf = tmp_path / "rv.bin"
         np.ascontiguousarray(sc["random_vecs"]).tofile(rvf)
-        exe = os.path.join(ROOT, "tests", "cpp", "facade_tick")
+        exe = conftest.exe(os.path.join(ROOT, "tests", "cpp", "facade_tick"))
         out = subprocess.run([exe, str(N), str(cap), str(ticks), str(rvf)], capture_output=True, check=True,
                              env=conftest.binary_env(pmaf)).stdout.decode()
         ora = oracle.OraclePlanner(sc, mgr_init_pos=sc["start"])
@@ -134,7 +134,7 @@ def test_node_visualisation_loop_does_not_dominate_the_tick(scenes, tmp_path, hi
     sc = scenes.static1_scene(N, cap - 1)
     rvf = tmp_path / "rv.bin"
     np.ascontiguousarray(sc["random_vecs"]).tofile(rvf)
-    exe = os.path.join(ROOT, "tests", "cpp", "facade_tick")
+    exe = conftest.exe(os.path.join(ROOT, "tests", "cpp", "facade_tick"))
     out = subprocess.run([exe, str(N), str(cap), str(ticks), str(rvf), "viz"], capture_output=True, check=True).stdout.decode()
     v = [l for l in out.strip().split("\n") if l.startswith("V ")][0].split()
     with_viz, plain, visited = float(v[1]), float(v[2]), int(v[3])
@@ -152,7 +152,7 @@ def test_facade_with_an_attached_rccl_communicator(scenes, tmp_path, hip_lib):
     sc = scenes.static1_scene(N, cap - 1)
     rvf = tmp_path / "rv.bin"
     np.ascontiguousarray(sc["random_vecs"]).tofile(rvf)
-    exe = os.path.join(ROOT, "tests", "cpp", "facade_tick")
+    exe = conftest.exe(os.path.join(ROOT, "tests", "cpp", "facade_tick"))
     r = subprocess.run([exe, str(N), str(cap), str(ticks), str(rvf), "comm"], capture_output=True)
     assert r.returncode == 0, r.stderr.decode()[-2000:]
     assert ("W %d" % ticks) in r.stdout.decode()

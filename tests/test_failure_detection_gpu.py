@@ -13,6 +13,8 @@ import time
 import numpy as np
 import pytest
 
+import conftest
+
 pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -140,8 +142,9 @@ def test_winner_path_in_pinned_memory_is_the_scored_path_of_the_best_agent(pmaf,
     hip.close()
 
 
-def test_facade_plantick_throws_on_a_nan_setpoint_and_serves_the_selected_path(hip_lib):
-    exe = os.path.join(ROOT, "tests", "cpp", "facade_tick")
+def test_facade_plantick_reports_a_nan_setpoint_throws_on_opt_in_and_serves_the_selected_path(hip_lib):
+    """default = the reference's behaviour (NaN published, health word set, no throw: ADVICE r4); opt-in throw at the same tick"""
+    exe = conftest.exe(os.path.join(ROOT, "tests", "cpp", "facade_tick"))
     r = subprocess.run([exe, "health"], capture_output=True)
     assert r.returncode == 0, r.stderr.decode()[-2000:]
     out = r.stdout.decode().split()

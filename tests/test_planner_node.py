@@ -12,7 +12,7 @@ import pytest
 import conftest
 
 ROOT = conftest.ROOT
-EXE = os.path.join(ROOT, "tools", "plan_task")
+EXE = conftest.exe(os.path.join(ROOT, "tools", "plan_task"))
 TASKS = os.path.join(ROOT, "tests", "golden", "tasks")
 
 

@@ -20,8 +20,10 @@ ROOT = conftest.ROOT
 @pytest.fixture(scope="module")
 def consumer_exe(tmp_path_factory):
     exe = str(tmp_path_factory.mktemp("consumer") / "consumer_check")
-    subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-Werror", "-ffp-contract=off",
-                           "-I" + os.path.join(ROOT, "include"),
+    # (the consumer's 3-vector arithmetic follows the evaluation-order policy of the pair under test)
+    defs = ["-DPMAF_DOT_RIGHT_ASSOC"] if os.environ.get("PMAF_VARIANT") == "rassoc" else []
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-Werror", "-ffp-contract=off"] + defs +
+                          ["-I" + os.path.join(ROOT, "include"),
                            os.path.join(ROOT, "tests", "cpp", "consumer_check.cpp"), "-o", exe])
     return exe
 

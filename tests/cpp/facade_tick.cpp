@@ -88,8 +88,62 @@ static int health_mode() {
   return 9;
 }
 
+// `lat` mode: what one planCallback costs at the C++ boundary on an idle stream (the previous rollout has finished, as in a
+// 100 Hz loop), no interpreter in the way: planTick open loop, setRealEEAgentPosition + planTick closed loop
+// (B/src/panda_bimanual_control.cpp:333-335: the measured position trails the set-point), and the node's five individual
+// calls. usage: facade_tick lat <n_agents> <max_prediction_steps> <n_samples>
+static int lat_mode(int N, int cap, int n) {
+  std::vector<Obstacle> obstacles;
+  const double xs[3] = {0.125, 0.125, -0.35}, zs[3] = {1.0, 0.7, 0.6}, ys[3] = {0.0, 0.125, -0.125};
+  for (int g = 0; g < 3; ++g)
+    for (int k = 0; k < 3; ++k) obstacles.push_back(Obstacle(Vector3d(xs[g], ys[k], zs[g]), Vector3d(0, 0, 0), 0.1));
+  obstacles.push_back(Obstacle(Vector3d(100.0, 100.0, 100.0), Vector3d(0, 0, 0), 0.1));
+  const Vector3d start(-0.6, 0.0, 0.75), goal(0.5, 0.0, 0.7);
+  Vector6d ws;
+  const double wsv[6] = {1.0, -1.0, 0.3, -0.3, 1.1, 0.2};
+  for (int i = 0; i < 6; ++i) ws(i) = wsv[i];
+  auto stats = [](std::vector<double> v, const char *what) {
+    std::sort(v.begin(), v.end());
+    printf("L %-44s median %7.2f  p90 %7.2f  p99 %7.2f  max %7.2f us  (%zu samples)\n", what, v[v.size() / 2], v[v.size() * 9 / 10],
+           v[v.size() * 99 / 100], v.back(), v.size());
+  };
+  for (int mode = 0; mode < 3; ++mode) {
+    CfManager m;
+    m.setRandomSeed(7);
+    m.setInitialPosition(start);
+    m.init(goal, 0.01, obstacles, std::vector<double>(N, 4.0), std::vector<double>(N, 0.025), std::vector<double>(N, 0.08),
+           std::vector<double>(N, 3.0), std::vector<double>(N, 0.0), std::vector<double>(1, 0.02), 0.2, 0.25, 0.35, cap, 1);
+    m.setInitialPosition(start);
+    Vector3d measured = start;
+    std::vector<double> us;
+    for (int t = 0; t < n + 20; ++t) {
+      if (t % 100 == 0) { m.setInitialPosition(start); measured = start; }   // stay near the start: full-length rollouts
+      m.stopPrediction();                                                   // idle stream
+      const auto t0 = std::chrono::steady_clock::now();
+      Vector3d next;
+      if (mode == 2) {
+        m.stopPrediction();
+        const int best = m.evaluateAgents(obstacles, 100.0, 10.0, 0.001, 1.0, ws);
+        m.moveRealEEAgent(obstacles, 0.01, 1, best);
+        m.resetEEAgents(m.getNextPosition(), m.getNextVelocity(), obstacles);
+        m.startPrediction();
+        next = m.getNextPosition();
+      } else {
+        if (mode == 1) m.setRealEEAgentPosition(measured);
+        m.planTick(obstacles, 0.01, 100.0, 10.0, 0.001, 1.0, ws, &next);
+      }
+      const double dt_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+      if (t >= 20) us.push_back(dt_us);
+      for (int c = 0; c < 3; ++c) measured[c] = next[c] - 0.3 * (next[c] - measured[c]);
+    }
+    stats(us, mode == 0 ? "planTick, open loop" : mode == 1 ? "setRealEEAgentPosition + planTick, closed loop" : "the node's five calls (stop ... start)");
+  }
+  return 0;
+}
+
 int main(int argc, char **argv) {
   if (argc > 1 && !strcmp(argv[1], "health")) return health_mode();
+  if (argc > 4 && !strcmp(argv[1], "lat")) return lat_mode(atoi(argv[2]), atoi(argv[3]), atoi(argv[4]));
   if (argc < 5) return 2;
   const int N = atoi(argv[1]), cap = atoi(argv[2]), ticks = atoi(argv[3]);
   // static1 scene: 9 spheres + repulsive sentinel (values as in pmaf scenes.static1_obstacles)

@@ -97,6 +97,11 @@ def test_tick_time_limit_when_the_sequence_number_never_arrives(pmaf, scenes, mo
     assert ei.value.code == -2 and "time limit" in str(ei.value), str(ei.value)
     assert waited < 0.012, "gave up only after %.1f ms (limit 2 ms, rollout ~15 ms)" % (waited * 1e3)
     hip.debug_withhold_mailbox(False)
+    # the abandoned tick's kernels are still queued (they read the call's staging buffers and write the mailbox later):
+    # no further tick until the stream has been drained
+    with pytest.raises(pmaf.PmafError) as ei2:
+        hip.tick(sc["obstacles"], sc["dt"], sc["cost_gains"], sc["ws_limits"])
+    assert ei2.value.code == -3 and "pmaf_stop" in str(ei2.value), str(ei2.value)
     hip.stop()
     b = hip.tick(sc["obstacles"], sc["dt"], sc["cost_gains"], sc["ws_limits"])
     assert 0 <= b < 512

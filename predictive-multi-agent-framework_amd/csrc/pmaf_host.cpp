@@ -325,8 +325,8 @@ static int pick_lpa(int N, int P, int M) {
 }
 
 // W waves per agent with <= 61 obstacles each (pmaf_k_mw.hip) instead of 2 / 4 obstacle slots per lane of ONE wave:
-// the per-obstacle part of the step runs on W SIMDs at once. Only while the launch leaves every wave a SIMD of its own
-// (N P W <= SIMDs of the device) -- beyond that the multi-slot kernels' single wave per agent wins back.
+// the per-obstacle part of the step runs on W SIMDs at once. Only while the launch leaves every BLOCK a CU of its own
+// (N P <= CUs of the device) -- beyond that the multi-slot kernels' single wave per agent wins back.
 // PMAF_MW=0 / 2 / 3 / 4: off / that many waves (tests, timing); PMAF_MW_PER: obstacles per wave (default: even split).
 static void pick_mw(pmaf_planner *h, int N, int P, int M) {
   h->mw_waves = 0; h->mw_per = 0;
@@ -342,9 +342,14 @@ static void pick_mw(pmaf_planner *h, int N, int P, int M) {
     if (f == 0) return;
     if (f >= waves && f <= 4) waves = f;
   }
-  // (a CU holds 4 / waves blocks: pmaf_k_mw.hip's launcher enforces it through the LDS request)
-  const long cus = h->D.n_simds / 4, per_cu = 4 / waves;
-  if ((long)N * P > cus * per_cu) return;
+  // ONE block per CU (pmaf_k_mw.hip's launcher enforces it through the LDS request). Rounds 4's rule let two two-wave
+  // blocks share a CU (N P <= 2 CUs); measured in round 5 (profiles/r5_mw_rule_sweep.txt, 300 steps, kernel us per launch):
+  //   128 obstacles: 256 agents split 536 / one-wave 578, 288 ... 512 agents split 710 ... 716 / one-wave 601
+  //   100 obstacles: 256 agents 492 / 550, 384 ... 512 agents 649 ... 652 / 574;   64 obstacles: 445 / 515, 616 ... 621 / 540
+  // -- as soon as ONE CU holds two blocks (their four waves contend for the CU's LDS pipe at the per-step hand-off) the
+  // launch is 18 % slower than the two-slot one-wave kernel, so the split kernel is kept to launches with a CU per block.
+  const long cus = h->D.n_simds / 4;
+  if ((long)N * P > cus) return;
   { const char *lk = getenv("PMAF_MW_LDS_KB"); h->mw_lds_kb = lk ? atoi(lk) : 0; }   // timing experiments
   int per = (M + waves - 1) / waves;
   const char *pe = getenv("PMAF_MW_PER");

@@ -536,13 +536,13 @@ bool PMAF_MW_LAUNCH(const DevView &D, const CostParams &cp, int waves, int per, 
   const int mpd = ((M + 63) & ~63) + 64;
   const size_t lds = sizeof(double) * ((size_t)(2 * waves * 4 + 8) + (size_t)waves * 2 * MW_REGION + 6 * (size_t)mpd +
                                        (size_t)(mpd / 2 + 8));
-  // Placement: the W waves of a block want a SIMD each, so a CU (4 SIMDs, 160 KB of LDS) should hold 4 / W blocks and no
-  // more; the LDS request enforces it whatever the dispatcher would do by itself: 72 KB (two blocks fit, three do not)
-  // for two waves, 96 KB (one block) for three and four. (tools/mwplace.hip: on an otherwise idle GPU the
-  // dispatcher spreads 256 blocks over 256 CUs and a block's waves over distinct SIMDs without it, too.)
+  // Placement: ONE block per CU (the W waves on W of its 4 SIMDs). The LDS request enforces it whatever the dispatcher
+  // would do by itself: 96 KB of the CU's 160 KB, so a second block does not fit. Round 4 let two two-wave blocks share
+  // a CU (72 KB); round 5 measured that such a launch is 18 % slower than the one-wave two-slot kernel
+  // (profiles/r5_mw_rule_sweep.txt) and the host no longer asks for it (pmaf_host.cpp, pick_mw).
   // `lds_kb`: the caller's override (0: this rule; timing experiments).
   size_t need = lds;
-  { const size_t want = (size_t)(lds_kb > 0 ? lds_kb : (waves == 2 ? 72 : 96)) * 1024; if (want > need) need = want; }
+  { const size_t want = (size_t)(lds_kb > 0 ? lds_kb : 96) * 1024; if (want > need) need = want; }
   const dim3 grid((unsigned)D.N, (unsigned)D.P);
   // (the opt-in to more than 64 KB of dynamic LDS is per function AND device: remembered per device of the calling thread)
   int dev = 0;

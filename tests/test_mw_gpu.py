@@ -39,9 +39,13 @@ def test_more_waves_than_needed(pmaf, oracle, scenes, monkeypatch, waves):
 
 
 def test_one_wave_kernels_on_request_and_beyond_one_wave_per_simd(pmaf, oracle, scenes, monkeypatch):
-    """PMAF_MW=0 keeps the one-wave kernels; so does a launch that could not give every wave a SIMD of its own
-    (two-wave blocks: 2 per CU -> more than 512 agents at 128 obstacles)"""
-    sc = scenes.synthetic_scene(600, 40, 128, 7, 3)
+    """PMAF_MW=0 keeps the one-wave kernels; so does a launch that could not give every block a CU of its own
+    (more than 256 agents: round 5's rule, profiles/r5_mw_rule_sweep.txt)"""
+    sc = scenes.synthetic_scene(256, 20, 128, 7, 3)
+    hip = pmaf.PmafPlanner(sc, device=0, mgr_init_pos=sc["start"])
+    assert hip.launch_config()["waves_per_agent"] == 2     # a CU per block: the split kernel
+    hip.close()
+    sc = scenes.synthetic_scene(300, 40, 128, 7, 3)
     hip, ora = make_pair(pmaf, oracle, sc)
     assert hip.launch_config()["waves_per_agent"] == 1
     for _ in range(2):

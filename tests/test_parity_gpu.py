@@ -19,6 +19,7 @@ import os
 import numpy as np
 import pytest
 
+import conftest
 from conftest import drive
 
 pytestmark = pytest.mark.gpu

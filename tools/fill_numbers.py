@@ -86,13 +86,23 @@ try:
     m_closed = re.search(r"closed loop\s+\| around the calls median ([0-9.]+) p99 ([0-9.]+) us \| pmaf_tick alone \(library clock\) set-point median ([0-9.]+)", tl)
     m_plain = re.search(r"events False obstacles False winner path False \| enqueue median [0-9.]+ p99 [0-9.]+ \| set-point median ([0-9.]+) p99 ([0-9.]+)", tl)
     if m_open and m_closed:
-        lat_extra = (" **Closed loop** (`pmaf_set_real_position` + `pmaf_tick`, the measured position read by the manager kernel out of pinned "
-                     "memory — no stream sync, no copy command): %s µs median / %s p99 around the two calls against %s / %s for the open-loop "
-                     "tick on the same (interpreter's) clock; `pmaf_tick` alone on the library clock %s vs %s µs (`profiles/%s_ticklat.txt`)."
-                     % (m_closed.group(1), m_closed.group(2), m_open.group(1), m_open.group(2), m_closed.group(3), m_open.group(3), R))
+        lat_extra = (" **Closed loop** (`pmaf_set_real_position` leaves the measured position in pinned memory, the manager kernel reads it: "
+                     "no stream sync, no copy command): `pmaf_tick` on the library clock %s µs median against %s open loop "
+                     "(`profiles/%s_ticklat.txt`)." % (m_closed.group(3), m_open.group(3), R))
     if m_plain:
         lat_extra += " Without event timing of the launches the set-point takes %s µs median / %s p99." % (m_plain.group(1), m_plain.group(2))
 except OSError:
+    pass
+try:   # the same question at the C++ boundary, no interpreter (tests/cpp/facade_tick lat)
+    fl = open(os.path.join(P, "%s_facade_latency.txt" % R)).read()
+    sec = fl.split("## agents, max_prediction_steps: 64 201")[1]
+    g_ = lambda what: re.search(re.escape(what) + r"\s+median\s+([0-9.]+)\s+p90\s+[0-9.]+\s+p99\s+([0-9.]+)", sec).groups()
+    o_, c_, f_ = g_("planTick, open loop"), g_("setRealEEAgentPosition + planTick, closed loop"), g_("the node's five calls (stop ... start)")
+    lat_extra += (" **At the C++ boundary** (`tests/cpp/facade_tick lat`, one `planCallback` through the facade, 64 agents, 1000 samples, "
+                  "`profiles/%s_facade_latency.txt`): `planTick` %s µs median / %s p99 open loop, **%s / %s closed loop** (`setRealEEAgentPosition` "
+                  "costs nothing extra since ABI 6; it was a stream sync + copy), the node's five individual calls %s / %s µs (each one synchronises)."
+                  % (R, o_[0], o_[1], c_[0], c_[1], f_[0], f_[1]))
+except (OSError, IndexError, AttributeError):
     pass
 out.append("**Tick latency** on an idle stream, library clock. SURVEY §8(d)'s tick — host call → best index, set-point AND the selected "
            "agent's scored path on the host (`pmaf_enable_winner_path`, %d B at C2), %d ticks — **median %.1f µs, p90 %.1f, p99 %.1f, max %.1f**. "
@@ -148,7 +158,7 @@ out.append("")
 try:
     rg = json.load(open(os.path.join(P, "%s_regime.json" % R)))
     out.append("**The regime** (`tools/regime.py` → `profiles/%s_regime.json`; full-horizon rollouts, H = %d, %s): a rollout is ONE dependent chain; "
-               "more lanes do not shorten it. Per step of a chain the MI355X wave is SLOWER than one x86 core; it wins by running thousands of chains at once." % (R, rg["horizon"], rg["cpu_model"]))
+               "more lanes do not shorten it. Per step of a chain the MI355X wave is SLOWER than one x86 core up to a few dozen obstacles (at 128 the two-wave split kernel draws level); the GPU wins by running thousands of chains at once." % (R, rg["horizon"], rg["cpu_model"]))
     out.append("")
     out.append("| field obstacles M | one CPU core, ns per agent-step | GPU, ns per step of a chain (64 agents) | GPU ÷ CPU per chain | agents from which one MI355X beats a 64-core host (one agent per core) | aggregate agent-steps/µs at 8 192 agents: GPU vs 64 cores |\n|---|---|---|---|---|---|")
     for r_ in rg["rows"]:

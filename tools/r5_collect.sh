@@ -16,7 +16,7 @@ bench)
   for f in $O/bench_*.json; do [ -s "$f" ] && cp "$f" profiles/r5_$(basename $f); done
   ;;
 misc)
-  for f in regime.json regime.txt ticklat.txt facade_latency.txt agent_times.txt fuzz_campaign.txt tolerance_report.jsonl gpu_tests.log gpu_tests_rassoc.log variant_kernel_times.txt cpu_bench_c2_run1.json cpu_bench_c2_run2.json; do
+  for f in regime.json regime.txt ticklat.txt facade_latency.txt mw_rule_sweep.txt agent_times.txt fuzz_campaign.txt tolerance_report.jsonl gpu_tests.log gpu_tests_rassoc.log variant_kernel_times.txt cpu_bench_c2_run1.json cpu_bench_c2_run2.json; do
     [ -s $O/$f ] && cp $O/$f profiles/r5_$f
   done
   ;;

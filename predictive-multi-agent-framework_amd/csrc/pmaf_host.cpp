@@ -314,11 +314,17 @@ static int pick_lpa(int N, int P, int M) {
     long waves = ((long)N * lpa + 63) / 64 * P;
     if (waves > 2048) lpa /= 2; else break;
   }
-  // 129..256 obstacles: the lane-group kernels hold at most 4 slots per lane (M <= 128 at 32 lanes), so a narrower
-  // mapping would fall to the generic LDS-table kernel -- the four-slot wave-per-agent kernel is 2.7-3.7x faster
-  // even with several rounds of waves (measured, tools/m200time.py: 2048 agents x 300 steps, M = 200: 2.95 ms
-  // against 8.08 ms; M = 256: 3.36 ms against 12.5 ms; 4096 agents x 200 steps: 3.8 / 4.1 ms against 8.3 / 10.2 ms)
-  if (lpa < 64 && M > 128 && M <= 256) lpa = 64;
+  // Never more than TWO obstacle slots per lane in a narrower mapping (round 5, tools/lpasweep.py, profiles/r5_lpa_rule.txt;
+  // kernel us per launch, 200 steps, old choice -> the mapping with <= 2 slots):
+  //   128 obstacles: 2304 agents 1674 -> 876, 4096 agents 1882 -> 1149, 8192 agents 4143 -> 2154 (32 / 16 lanes -> wave per agent)
+  //   70 obstacles: 4096 agents 1509 -> 1105;  64 obstacles, 8192 agents 1606 -> 1301 (16 -> 32 lanes);  40 obstacles,
+  //   12288 agents 2519 -> 1862 (8 -> 32);  32 obstacles, 16384 agents 1744 -> 1317 (8 -> 16);  20 obstacles: 1509 -> 1204
+  // -- the group kernels' three- and four-slot bodies (and the generic kernel beyond them) cost more per agent-step than
+  // another round of waves of a mapping that holds the obstacles in <= 2 slots; with <= 2 slots the wave-count rule above
+  // stands (64 obstacles x 4096 agents: 32 lanes 688 against 1089 us for the wave per agent; C5: 16 lanes).
+  // (This subsumes rounds 2-4's rule for 129..256 obstacles: those always take the four-slot wave-per-agent kernel, 2.7-3.7 x
+  // faster than the generic LDS-table kernel a narrower mapping would fall to.)
+  while (lpa < 64 && (M + lpa - 1) / lpa > 2) lpa *= 2;
   // known-flag bitmask holds 64 tiles per lane
   while ((M + lpa - 1) / lpa > 64 && lpa < 64) lpa *= 2;
   return lpa;

@@ -1219,6 +1219,24 @@ def test_synchronous_stepping_api_matches_oracle(pmaf, oracle, scenes, lpa):
     hip.close()
 
 
+@pytest.mark.parametrize("n,m,want", [(2304, 128, 64), (2304, 70, 64), (4400, 64, 32), (4400, 33, 32), (2304, 64, 32),
+                                      (4400, 32, 16), (8400, 20, 16), (8400, 16, 8)])
+def test_narrower_mappings_hold_at_most_two_slots_per_lane(pmaf, oracle, scenes, n, m, want):
+    """pick_lpa (round 5, profiles/r5_lpa_rule.txt): more agents than 2048 waves narrow the mapping, but never to more
+    than two obstacle slots per lane -- the three- / four-slot group bodies cost more than another round of waves
+    (128 obstacles x 2304 agents: 1674 -> 876 us). Parity of the populations whose mapping changed, and of their
+    neighbours whose mapping stayed."""
+    sc = scenes.synthetic_scene(n, 12, m, 6, 9)
+    hip, ora = make_pair(pmaf, oracle, sc)
+    assert hip.launch_config()["lanes_per_agent"] == want
+    for t in range(2):
+        assert hip.tick(sc["obstacles"], sc["dt"], sc["cost_gains"], sc["ws_limits"]) == \
+            ora.tick(sc["obstacles"], sc["dt"], sc["cost_gains"], sc["ws_limits"])
+    hip.stop()
+    assert_state_equal(hip, ora)
+    hip.close()
+
+
 def test_many_agents_with_200_obstacles_stay_on_the_four_slot_kernel(pmaf, oracle, scenes):
     """N x P > 1024 waves with 129..256 obstacles: the launch keeps the
     wave-per-agent mapping (k_rollout_w64<4>, several rounds of waves) instead of

@@ -495,6 +495,7 @@ def run_workload(ctx, spec, args, full):
         # control loop): host call -> best index and next set-point on the host. Outside the timed region.
         idle = np.zeros(0)
         idle_lib = (np.zeros(0), np.zeros(0))
+        closed_sp = np.zeros(0)
         if full and not ((coupled or host_coupled) and n_part > 1):
             idle = np.zeros(500)
             planner.tick_times_us()          # (clears the library's own record of the timed ticks)
@@ -508,6 +509,23 @@ def run_workload(ctx, spec, args, full):
             # the same calls on the library's own clock (pmaf_get_tick_times_us): without this script's ctypes / numpy
             # / interpreter time, which is where the tail of the figure above comes from
             idle_lib = planner.tick_times_us(idle.size)
+            # closed loop (open_loop: false in the task file, B/src/panda_bimanual_control.cpp:333-335): the measured position
+            # -- trailing the set-point by 30 % of the last step -- handed over in front of every tick; library clock of the tick
+            closed_sp = np.zeros(0)
+            if not coupled and not host_coupled:
+                meas = np.asarray(planner.real_state()[0], dtype=np.float64).reshape(P, 3).copy()
+                for k in range(300):
+                    if episode and tick_no[0] % episode == 0:
+                        planner.set_initial_position(starts)
+                        meas = starts.copy()
+                    planner.stop()
+                    planner.set_real_position(meas)
+                    one_tick(obs)
+                    spn = np.asarray(planner.real_state()[0], dtype=np.float64).reshape(P, 3)
+                    meas = spn - 0.3 * (spn - meas)
+                planner.stop()
+                closed_sp = planner.tick_times_us(300)[1]
+                planner.set_initial_position(starts)
             # the tick SURVEY.md 8(d) defines: host call -> costs + best index + the WINNING TRAJECTORY on the host (what the
             # reference's planCallback hands out, B/src/panda_bimanual_control.cpp:340-347). The manager kernel writes the
             # selected agent's scored path into mapped pinned memory behind the set-point (pmaf_enable_winner_path);
@@ -618,6 +636,7 @@ def run_workload(ctx, spec, args, full):
         rec["_wp"] = (wp_lib, wp_wall) if (full and part and not ((coupled or host_coupled) and n_part > 1)) else (np.zeros(0), np.zeros(0))
         rec["_idle"] = idle
         rec["_idle_lib"] = idle_lib
+        rec["_closed_sp"] = closed_sp if (part and not ((coupled or host_coupled) and n_part > 1)) else np.zeros(0)
         rec["_scene"] = sc
         rec["_P"] = P
         rec["_transport"] = transport
@@ -773,6 +792,7 @@ def main():
         idle, sc, P = head.pop("_idle"), head.pop("_scene"), head.pop("_P")
         wp_lib, wp_wall = head.pop("_wp")
         idle_enq, idle_sp = head.pop("_idle_lib")
+        closed_sp = head.pop("_closed_sp")
         transport, has_comm = head.pop("_transport"), head.pop("_has_comm")
         N, H, n_obs = head["agents"], head["horizon"], head["obstacles"] + 1
         kernel_name, avg_kernel_s = head["kernel"], head["avg_kernel_us"] * 1e-6
@@ -833,6 +853,11 @@ def main():
                     "enqueue_median": float(np.median(idle_enq)), "enqueue_p99": float(np.percentile(idle_enq, 99)),
                     "note": "the same calls on the library's own clock (pmaf_get_tick_times_us): entry of pmaf_tick -> "
                             "set-point on the host; enqueue = both launches handed to the stream"},
+                "closed_loop_in_library": None if not closed_sp.size else {
+                    "median": float(np.median(closed_sp)), "p90": float(np.percentile(closed_sp, 90)),
+                    "p99": float(np.percentile(closed_sp, 99)), "n": int(closed_sp.size),
+                    "note": "pmaf_set_real_position(measured) in front of every pmaf_tick (the node with open_loop: false): the "
+                            "position rides in pinned memory into the manager kernel -- no stream sync, no copy command"},
                 "note": "tick issued on an idle stream: host call -> best index + next set-point "
                         "on the host (the new rollout then runs asynchronously); measured around the ctypes call"},
             "tick_with_winner_path_us": None if not wp_lib.size else {

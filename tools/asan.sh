@@ -14,7 +14,7 @@ if [ "${1:-build}" = build ]; then
 fi
 cd "$R"
 mkdir -p gpurun_out
-OUT=gpurun_out/r4_asan.txt
+OUT=gpurun_out/r5_asan.txt
 ASAN_SO=$(g++ -print-file-name=libasan.so)
 UBSAN_SO=$(g++ -print-file-name=libubsan.so)
 rm -f /tmp/asan_log.* /tmp/ubsan_log.*
@@ -29,12 +29,12 @@ export UBSAN_OPTIONS=print_stacktrace=1:log_path=/tmp/ubsan_log
   echo "== torch fails with 'Error in dlopen: libcaffe2_nvrtc.so' -- the one failure of profiles/r3_asan.txt; test_no_kernel_touches_scratch_memory"
   echo "== inspects the product build's object files, not this library; the facade driver is linked against the product library)"
   PMAF_LIB_PATH=$R/predictive-multi-agent-framework_amd/lib_asan/libpmaf_hip.so LD_PRELOAD="$ASAN_SO $UBSAN_SO" \
-    python -m pytest tests/test_abi.py tests/test_peer_gpu.py tests/test_shard_gpu.py tests/test_parity_gpu.py tests/test_failure_detection_gpu.py \
-    -v -rfEs -p no:cacheprovider --deselect tests/test_failure_detection_gpu.py::test_facade_plantick_throws_on_a_nan_setpoint_and_serves_the_selected_path \
+    python -m pytest tests/test_abi.py tests/test_peer_gpu.py tests/test_shard_gpu.py tests/test_parity_gpu.py tests/test_failure_detection_gpu.py tests/test_boundary_gpu.py \
+    -v -rfEs -p no:cacheprovider --deselect tests/test_failure_detection_gpu.py::test_facade_plantick_reports_a_nan_setpoint_throws_on_opt_in_and_serves_the_selected_path \
     --deselect tests/test_abi.py::test_no_kernel_touches_scratch_memory \
     --deselect tests/test_shard_gpu.py::test_exchange_lifecycle_does_not_leak \
     --deselect tests/test_parity_gpu.py::test_handle_lifecycle_does_not_leak_device_memory \
-    -k "abi or symbol or validation or error_reporting or checkpoint or stepping or attached or peer_mailbox_couples or peer_mailbox_two_handles or one_way or missing_header or step_api or health or time_limit or winner_path or set_agent or lifecycle or range" 2>&1 \
+    -k "abi or symbol or validation or error_reporting or checkpoint or stepping or attached or peer_mailbox_couples or peer_mailbox_two_handles or one_way or missing_header or step_api or health or time_limit or winner_path or set_agent or lifecycle or range or closed_loop or prediction_freq or new_goal" 2>&1 \
     | grep -E "PASSED|FAILED|ERROR|SKIPPED|passed|failed|^E  " | sed -e "s#$R/##" | tail -80
   echo "== tools/fuzz_api.py 1000 trials"
   PMAF_LIB_PATH=$R/predictive-multi-agent-framework_amd/lib_asan/libpmaf_hip.so LD_PRELOAD="$ASAN_SO $UBSAN_SO" \
@@ -43,6 +43,6 @@ export UBSAN_OPTIONS=print_stacktrace=1:log_path=/tmp/ubsan_log
   ls /tmp/asan_log.* /tmp/ubsan_log.* 2>/dev/null | wc -l
   cat /tmp/asan_log.* /tmp/ubsan_log.* 2>/dev/null | grep -E "ERROR|runtime error|SUMMARY" | sort | uniq -c | head -20
   echo "# kernels with -DPMAF_DEBUG_BOUNDS (lib_bounds/): the GPU parity suite"
-  PMAF_LIB_PATH=$R/predictive-multi-agent-framework_amd/lib_bounds/libpmaf_hip.so python -m pytest tests/test_parity_gpu.py tests/test_mw_gpu.py tests/test_tolerance_gpu.py -q -rfE -p no:cacheprovider 2>&1 | tail -6
+  PMAF_LIB_PATH=$R/predictive-multi-agent-framework_amd/lib_bounds/libpmaf_hip.so python -m pytest tests/test_parity_gpu.py tests/test_mw_gpu.py tests/test_tolerance_gpu.py tests/test_boundary_gpu.py -q -rfE -p no:cacheprovider 2>&1 | tail -6
 } > $OUT 2>&1
 cat $OUT

@@ -76,11 +76,17 @@ def normalise(raw, order):
     return raw / s[..., None]
 
 
-def replay(scn, ref):
-    from oracle import orc
-    orc.build()
-    orc.set_exp_mode(0)
-    order = orc.eval_order()
+def replay(scn, ref, make=None, tol=0.0, selected_only=False, order=None):
+    """make(scene, mgr_init_pos) -> planner with the OraclePlanner / PmafPlanner method surface (default: the CPU oracle in
+    its libm-exp mode, compared bit for bit). tests/test_reference_pin.py also runs the HIP planner through it with
+    tol = 1e-5 m and selected_only = True (its exp is portable_exp, not the reference's libm: the north star's contract
+    is the selected trajectory / set-point sequence and the best-index sequence)."""
+    if make is None:
+        from oracle import orc
+        orc.build()
+        orc.set_exp_mode(0)
+        order = orc.eval_order()
+        make = lambda sc, ip: orc.OraclePlanner(sc, mgr_init_pos=ip)
     N, n_obs = scn["n_agents"], scn["obstacles"].shape[0]
     base = dict(n_agents=N, max_prediction_steps=scn["max_prediction_steps"], dt=scn["freq_multiple"] * scn["dt"],
                 velocity_max=scn["velocity_max"], approach_dist=scn["approach_dist"], detect_shell_rad=scn["detect_shell_rad"],
@@ -92,7 +98,8 @@ def replay(scn, ref):
         got = np.asarray(got, dtype=np.float64).ravel()
         want = np.array([float.fromhex(x) for x in np.asarray(want_hex).ravel()])
         assert got.shape == want.shape, (what, tick, got.shape, want.shape)
-        bad = ~((got == want) | (np.isnan(got) & np.isnan(want)))
+        with np.errstate(invalid="ignore"):
+            bad = ~((got == want) | (np.isnan(got) & np.isnan(want)) | (np.abs(got - want) <= tol))
         stats["compared"] += int(got.size)
         if bad.any():
             stats["mismatches"] += int(bad.sum())
@@ -124,14 +131,14 @@ def replay(scn, ref):
             rv[5:] = normalise(scn["random"][rg["random_first"]:rg["random_first"] + per_init].reshape(N - 5, n_obs, 3), order)
         sc = dict(base, goal=goal, obstacles=obs.copy(), random_vecs=rv)
         if ora is None:
-            new = orc.OraclePlanner(sc, mgr_init_pos=mgr_init)
+            new = make(sc, mgr_init)
             cur = scn["start"].copy()
         else:
             ora.set_initial_position(position)          # the position message while planning is inactive
             mgr_init = position.copy()
             cur = np.asarray(ora.real_state()[0]).copy()
             bid, btype = ora.best_id(), ora.best_type()
-            new = orc.OraclePlanner(sc, mgr_init_pos=mgr_init)
+            new = make(sc, mgr_init)
             if bid > 0:
                 new.set_best(bid, btype, old_rv[bid - 1])
             ora.close()
@@ -147,22 +154,34 @@ def replay(scn, ref):
             rt = rg["ticks"][t]
             if scn.get("closed_loop"):
                 ora.set_real_position(position)
+            scored = None
             if "n" in rt:   # what the selection of this tick scores
+                if hasattr(ora, "stop"):
+                    ora.stop()
                 paths, n = ora.paths()
-                cmpi("n_steps", t, n, rt["n"])
-                cmp("path lengths", t, ora.path_lengths(), rt["len"])
-                cmpi("reached", t, ora.success(), rt["reached"])
-                cmp("last points", t, np.stack([paths[i, n[i] - 1] for i in range(N)]), rt["last"])
-                if "paths" in rt and np.array_equal(n, rt["n"]):
-                    for i in range(N):
-                        cmp("path of agent %d" % i, t, paths[i, :n[i]], rt["paths"][i])
+                scored = (paths, n)
+                if not selected_only:
+                    cmpi("n_steps", t, n, rt["n"])
+                    cmp("path lengths", t, ora.path_lengths(), rt["len"])
+                    cmpi("reached", t, ora.success(), rt["reached"])
+                    cmp("last points", t, np.stack([paths[i, n[i] - 1] for i in range(N)]), rt["last"])
+                    if "paths" in rt and np.array_equal(n, rt["n"]):
+                        for i in range(N):
+                            cmp("path of agent %d" % i, t, paths[i, :n[i]], rt["paths"][i])
             b = ora.tick(obs, scn["dt"], scn["cost_gains"], scn["ws_limits"])
+            if selected_only and scored is not None and b == rt["best"]:   # the selected agent's scored trajectory
+                paths, n = scored
+                cmpi("n_steps of the selected agent", t, [n[b]], [rt["n"][b]])
+                cmp("last point of the selected agent", t, paths[b, n[b] - 1], rt["last"][b])
+                if "paths" in rt and n[b] == rt["n"][b]:
+                    cmp("path of the selected agent", t, paths[b, :n[b]], rt["paths"][b])
             cmpi("best index", t, [b], [rt["best"]])
             cmpi("best type", t, [ora.best_type()], [rt["type"]])
             pos, vel, force = ora.real_state()
             cmp("set-point", t, pos, rt["pos"])
             cmp("velocity", t, vel, rt["vel"])
-            cmp("force", t, force, rt["force"])
+            if not selected_only:
+                cmp("force", t, force, rt["force"])
             cmp("goal distance", t, [ora.dist_from_goal()], [rt["dist"]])
             nxt = np.asarray(pos).copy()
             position = nxt - scn["lag"] * (nxt - position) if scn.get("closed_loop") else nxt

@@ -80,3 +80,71 @@ def test_oracle_is_held_to_the_reference_fixtures():
     print("the reference build evaluates the %s association -> use %s" % (
         "RIGHT (a0 b0 + (a1 b1 + a2 b2))" if "rassoc" in common and "" not in common else "LEFT ((a0 b0 + a1 b1) + a2 b2)",
         "lib_rassoc/libpmaf_hip.so (PMAF_VARIANT=rassoc)" if "rassoc" in common and "" not in common else "lib/libpmaf_hip.so (the default)"))
+
+
+class LockStep:
+    """drives the HIP planner and the oracle (portable-exp mode: the kernels' own exp) through the same calls and requires
+    every value they hand back to be bit-identical; returns the HIP planner's"""
+
+    def __init__(self, hip, ora):
+        self.hip, self.ora = hip, ora
+
+    @staticmethod
+    def _same(a, b):
+        if isinstance(a, (tuple, list)):
+            return len(a) == len(b) and all(LockStep._same(x, y) for x, y in zip(a, b))
+        if a is None or b is None:
+            return a is None and b is None
+        import numpy as np
+        a, b = np.asarray(a), np.asarray(b)
+        return a.shape == b.shape and bool(np.all((a == b) | ((a != a) & (b != b))))
+
+    def __getattr__(self, name):
+        fh, fo = getattr(self.hip, name), getattr(self.ora, name)
+
+        def call(*args, **kw):
+            rh, ro = fh(*args, **kw), fo(*args, **kw)
+            assert LockStep._same(rh, ro), "HIP and oracle differ in %s()" % name
+            return rh
+        return call
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not REFS, reason="no tests/golden/ref_*.json yet (see test_oracle_is_held_to_the_reference_fixtures)")
+def test_hip_path_is_held_to_the_reference_fixtures(pmaf, oracle):
+    """The north star itself, once the fixtures exist -- the HIP planner (through the C-ABI) against the REFERENCE's own
+    record, for the library variant whose evaluation order is the reference build's (the oracle of that order must
+    reproduce the fixture bit for bit, else this variant is skipped). Per scenario:
+      1. HIP == the oracle in its portable-exp mode, bit for bit, on every call (LockStep);
+      2. both against the reference's record: same best-index sequence, set-points and the selected agent's scored
+         trajectory within 1e-5 m. The one difference left between the two sides is exp's last bit (kernels: portable_exp,
+         reference: its libm): scenarios where THAT alone is amplified past 1e-5 m -- the flow check (NOTES, round 5) found
+         the second leg of dyn1_two_goals and the lagged closed loop on static1 -- are reported, not failed: no
+         implementation with another exp can do better there, and the deviation is a property of the scene."""
+    sys.path.insert(0, PIN)
+    import replay
+    order = pmaf.load_library().pmaf_eval_order()
+    sensitive = []
+    for ref_path in REFS:
+        name = os.path.basename(ref_path)[4:-5]
+        scn = replay.load_scenario(os.path.join(PIN, "scenarios", name + ".txt"))
+        ref = json.load(open(ref_path))
+        exact = replay.replay(scn, ref)                      # the oracle of THIS variant with libm exp, bit for bit
+        if not exact["match"]:
+            pytest.skip("evaluation order %d is not the reference build's (oracle differs on %s: %s) -- run with the other PMAF_VARIANT"
+                        % (order, name, exact["first"]))
+        oracle.set_exp_mode(1)
+        try:
+            res = replay.replay(scn, ref, tol=1e-5, selected_only=True, order=order,
+                                make=lambda sc, ip: LockStep(pmaf.PmafPlanner(sc, device=0, mgr_init_pos=ip),
+                                                             oracle.OraclePlanner(sc, mgr_init_pos=ip)))
+        finally:
+            oracle.set_exp_mode(0)
+        print("%-28s HIP == oracle (portable exp) on every call; vs the reference: %d values over %d ticks, %d beyond 1e-5 m (max %.3g)%s" % (
+            name, res["compared"], res["ticks"], res["mismatches"], res["max_abs_diff"],
+            "" if res["match"] else "  <- exp's last bit amplified by this scene: " + str(res["first"])))
+        if not res["match"]:
+            sensitive.append(name)
+    assert len(sensitive) < len(REFS), "every scenario deviates from the reference: not an exp effect"
+    # the well-conditioned core must hold: BASELINE C1 / C2, the shipped static1 / dyn1 / trap tasks
+    assert not {"c1_static1_n16_h100", "c2_64x200x32", "static1_shipped", "dyn1_shipped", "trap_shipped"} & set(sensitive), sensitive

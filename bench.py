@@ -769,6 +769,13 @@ def main():
             print(json.dumps({"dry_run": True, "n_gpus": world, "ranks": who, "devices_visible": ctx.n_devices,
                               "plan": [n for n, _ in build_plan(args, world)[1]], "plan_skipped": sorted(build_plan(args, world)[2]),
                               "headline": build_plan(args, world)[0],
+                              # how C4's arms will be coupled on this launch (run_workload, mode "c4"): decided at run time from
+                              # pmaf_peer_info of every rank -- never a skipped record while an exchange communicator exists
+                              "c4_coupling": ("one handle: the handle's own inbox" if world == 1 else
+                                              "host, winner records (forced: PMAF_BENCH_C4_HOST_COUPLED=1)"
+                                              if os.environ.get("PMAF_BENCH_C4_HOST_COUPLED") == "1" else
+                                              "peer mailboxes between ranks 0 / 1; host-coupled through the winner records if an "
+                                              "inbox is not fine-grained device memory"),
                               "budget_s": budget, "budget_rows": rows,
                               "transport": transport if got is not None else None,
                               "collective_world": collective_world if got is not None else None,

@@ -506,12 +506,14 @@ static void flush_real_position(pmaf_planner *h) {
 
 static void launch_manager(pmaf_planner *h, const ManagerArgs &A0, hipEvent_t done = nullptr) {
   ManagerArgs A = A0;
-  if (h->real_pos_pending) { A.real_pos_src = h->d_rp; h->real_pos_pending = false; }
+  const bool hand_over_position = h->real_pos_pending;
+  if (hand_over_position) A.real_pos_src = h->d_rp;
   if (A.do_reset) h->paths_gen++;
   if (A.do_reset && h->uses_closest_table()) { A.compute_closest = h->closest_dirty ? 1 : 0; h->closest_dirty = false; }
   A.tuned_real_step = (h->math == MATH_XACT && !h->force_generic) ? 1 : 0;
   pmaf_k_launch_manager(h->D, h->cp, A, h->lds_manager, h->stream, done);
   HIP_CHECK(hipGetLastError());
+  if (hand_over_position) h->real_pos_pending = false;   // (only once the launch that reads it is in the stream)
 }
 
 // copy the mailbox into the host-side real-agent state (call after the
@@ -1083,6 +1085,8 @@ int pmaf_set_real_position(pmaf_planner *h, const double *pos) {
   return guarded([&] {
     REQUIRE(h && pos, "pmaf_set_real_position: NULL argument");
     check_range(pos, (size_t)h->D.P * 3, "pmaf_set_real_position");
+    if (h->tick_abandoned)   // (its manager kernel may not have read the staging buffer yet)
+      fail(PMAF_ERR_STATE, "pmaf_set_real_position: the previous tick ran into its time limit; call pmaf_stop() first");
     // RealCfAgent::setPosition = push_back (B/src/cf_agent.cpp:44-46): the measured position becomes the real agent's
     // latest one. Handed to the next manager launch through mapped pinned memory -- no wait for the running rollout,
     // no copy command (the node calls this in front of every tick when open_loop is false,

@@ -507,7 +507,14 @@ static void flush_real_position(pmaf_planner *h) {
 static void launch_manager(pmaf_planner *h, const ManagerArgs &A0, hipEvent_t done = nullptr) {
   ManagerArgs A = A0;
   const bool hand_over_position = h->real_pos_pending;
-  if (hand_over_position) A.real_pos_src = h->d_rp;
+  if (hand_over_position) {
+    if (h->D.P <= PMAF_RP_INLINE) {   // by value in the kernel arguments (no PCIe read in front of the real step)
+      A.real_pos_inline = 1;
+      std::memcpy(A.real_pos_val, h->h_rp, sizeof(double) * 3 * (size_t)h->D.P);
+    } else {
+      A.real_pos_src = h->d_rp;
+    }
+  }
   if (A.do_reset) h->paths_gen++;
   if (A.do_reset && h->uses_closest_table()) { A.compute_closest = h->closest_dirty ? 1 : 0; h->closest_dirty = false; }
   A.tuned_real_step = (h->math == MATH_XACT && !h->force_generic) ? 1 : 0;

@@ -262,8 +262,10 @@ __global__ __launch_bounds__(64) void k_manager(DevView D, CostParams CP, Manage
   int htype = D.best_type[pop];
   // (closed loop: the measured position handed over by pmaf_set_real_position since the last manager launch)
   const double *rp_src = A.real_pos_src ? A.real_pos_src : D.real_pos;
-  V3 rp = mk(rp_src[pop * 3], rp_src[pop * 3 + 1], rp_src[pop * 3 + 2]);
-  if (A.real_pos_src && !A.do_move && lane == 0) {   // no step in this launch: keep it for the launches that follow
+  V3 rp;
+  if (A.real_pos_inline) rp = mk(A.real_pos_val[pop * 3], A.real_pos_val[pop * 3 + 1], A.real_pos_val[pop * 3 + 2]);   // (kernel arguments)
+  else rp = mk(rp_src[pop * 3], rp_src[pop * 3 + 1], rp_src[pop * 3 + 2]);
+  if ((A.real_pos_src || A.real_pos_inline) && !A.do_move && lane == 0) {   // no step in this launch: keep it for the launches that follow
     D.real_pos[pop * 3] = rp.x; D.real_pos[pop * 3 + 1] = rp.y; D.real_pos[pop * 3 + 2] = rp.z;
   }
   V3 rv = mk(D.real_vel[pop * 3], D.real_vel[pop * 3 + 1], D.real_vel[pop * 3 + 2]);

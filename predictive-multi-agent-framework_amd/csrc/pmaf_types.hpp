@@ -145,7 +145,13 @@ struct ManagerArgs {
   // position [P][3] in mapped pinned HOST memory replaces the real agent's latest position before anything else of this
   // launch reads it (no sync, no copy command in front of the tick); NULL: D.real_pos holds it
   const double *real_pos_src;
+  // ... and for handles of at most PMAF_RP_INLINE populations (the node's single manager) BY VALUE in the kernel arguments:
+  // the position arrives with the dispatch packet instead of through a PCIe read on the real step's critical path
+  // (closed-loop set-point latency 15.8 -> 14.4 us at C2, the open-loop figure). real_pos_inline = 1: use real_pos_val.
+  int real_pos_inline;
+  double real_pos_val[3 * 4];
 };
+#define PMAF_RP_INLINE 4
 
 // synchronous stepping (CfAgent::cfPlanner, B/src/cf_agent.cpp:278-300): k_plan_steps
 struct PlanArgs {

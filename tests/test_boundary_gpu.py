@@ -117,6 +117,51 @@ def test_closed_loop_dyn1_until_reached(pmaf, oracle, scenes, style):
     assert 745 < n < 2500, n
 
 
+@pytest.mark.parametrize("P", [2, 6])
+def test_closed_loop_batched_populations(pmaf, oracle, scenes, P):
+    """P populations in one handle, each with its own measured position: up to four populations the positions travel by
+    value in the manager kernel's arguments, beyond that through the pinned staging buffer (ManagerArgs)"""
+    scs = [scenes.synthetic_scene(24, 80, 20, 5, 60 + sid, dynamic=(sid % 2 == 1)) for sid in range(P)]
+    starts = np.stack([s["start"] for s in scs])
+    hip = pmaf.PmafPlanner(scs, device=0, mgr_init_pos=starts)
+    hip.set_initial_position(starts)
+    oras = []
+    for s in scs:
+        o = oracle.OraclePlanner(s, mgr_init_pos=s["start"])
+        o.set_initial_position(s["start"])
+        oras.append(o)
+    obs = np.stack([s["obstacles"] for s in scs])
+    measured = starts.copy()
+    sc = scs[0]
+    for t in range(12):
+        hip.set_real_position(measured)
+        for p, o in enumerate(oras):
+            o.set_real_position(measured[p])
+        if t % 2:
+            bh = hip.tick(obs, sc["dt"], sc["cost_gains"], sc["ws_limits"])
+        else:   # the individual calls: the position is consumed by the evaluate (a launch without a step)
+            hip.stop()
+            bh = hip.evaluate(sc["cost_gains"], sc["ws_limits"])
+            hip.move_real(obs, sc["dt"], 1, bh)
+            pos, vel, _ = hip.real_state()
+            hip.reset_agents(pos, vel, obs)
+            hip.start()
+        bo = [o.tick(obs[p], sc["dt"], sc["cost_gains"], sc["ws_limits"]) for p, o in enumerate(oras)]
+        _same(bh, bo)
+        sp = np.stack([o.real_state()[0] for o in oras])
+        _same(hip.real_state()[0], sp)
+        measured = sp - LAG * (sp - measured)
+        obs = np.stack([scenes.advance_live_obstacles(o) if p % 2 == 1 else o for p, o in enumerate(obs)])
+    hip.stop()
+    ph, nh = hip.paths()
+    for p, o in enumerate(oras):
+        po, no = o.paths()
+        _same(nh[p], no)
+        _same(ph[p], po)
+        _same(hip.real_path(p), o.real_path())
+    hip.close()
+
+
 def test_closed_loop_position_survives_evaluate_and_checkpoint(pmaf, oracle, scenes):
     """the measured position is handed to the NEXT manager launch through pinned memory: an evaluate alone (no step),
     a state blob taken in between and the winner-record packing must all see it"""

@@ -77,7 +77,6 @@ struct pmaf_planner {
   double *h_wp = nullptr, *d_wp = nullptr, *h_wph = nullptr, *d_wph = nullptr;
   std::vector<int32_t> wp_np, wp_agent;
   double wp_seq = 0.0;          // sequence number the last selection published its path under (0: none yet)
-  double wp_counter = 0.0;      // sequence numbers of the selections that are not pmaf_ticks (pmaf_evaluate): negative
   std::chrono::steady_clock::time_point last_tick_entry{};
   bool wp_timed = true;         // the last pmaf_tick's path latency has been booked (or there was no tick)
   std::vector<double> wp_us;
@@ -121,9 +120,6 @@ struct pmaf_planner {
   // getEEForce / getDistFromGoal must not wait for the running rollout)
   std::vector<double> real_pos_h, real_vel_h, real_force_h;
   double *d_out = nullptr;      // device alias of h_out
-  static constexpr int kStage = 4;
-  double *h_stage[kStage] = {nullptr, nullptr, nullptr, nullptr};  // pinned staging ring for obstacle SoA uploads
-  hipEvent_t ev_stage[kStage] = {nullptr, nullptr, nullptr, nullptr};
   double *h_zc = nullptr, *d_zc = nullptr;  // mapped pinned obstacle buffer read by k_manager in pmaf_tick
   // closed loop: pmaf_set_real_position leaves the measured position [P][3] in mapped pinned memory and the NEXT manager
   // launch reads it from there (ManagerArgs::real_pos_src) -- the call neither waits for the running rollout nor puts a
@@ -131,10 +127,13 @@ struct pmaf_planner {
   // only after that kernel has read its inputs.
   double *h_rp = nullptr, *d_rp = nullptr;
   bool real_pos_pending = false;
+  // pop 0's D.has_best as the host knows it (pmaf_move_real's precondition without a device round trip): 1 after any
+  // completed selection, 0 on a fresh handle, -1 unknown (after pmaf_load_state / pmaf_set_best with id 0: read back once)
+  int has_best_h = 0;
+  double call_seq = 0.0;        // mailbox sequence numbers of the manager launches that are not pmaf_ticks: -1, -2, ...
   // pmaf_tick gave up on its time limit with its launches still queued / running (they still read h_zc / h_rp and write
   // the mailbox): no further tick until the stream has been drained (pmaf_stop)
   bool tick_abandoned = false;
-  int stage_next = 0;
   // ---- winner-record exchange of sharded runs (pmaf_attach_comm) ----
   // Two exchange slots used alternately: the selection of tick k sends from slot k & 1, so its manager kernel only has
   // to wait for the exchange of tick k-2 (long through) -- never for the collective of the tick before, which a slower
@@ -464,23 +463,9 @@ static void ensure_scores(pmaf_planner *h) {
   h->scores_valid = true;
 }
 
-static void upload_live_obstacles(pmaf_planner *h, const double *obstacles) {
-  if (!obstacles) return;
-  check_range(obstacles, (size_t)h->D.P * h->D.n_obs * 7, "obstacles");
-  h->note_live_obstacles(obstacles);
-  h->live_resident.assign(obstacles, obstacles + (size_t)h->D.P * h->D.n_obs * 7);
-  // ring of pinned staging buffers: wait only for the copy that last used this slot
-  int s = h->stage_next;
-  h->stage_next = (s + 1) % pmaf_planner::kStage;
-  HIP_CHECK(hipEventSynchronize(h->ev_stage[s]));
-  aos_to_soa(obstacles, h->h_stage[s], h->D.P, h->D.n_obs);
-  HIP_CHECK(hipMemcpyAsync(h->D.obs_live, h->h_stage[s], sizeof(double) * (size_t)h->D.P * 7 * h->D.n_obs,
-                           hipMemcpyHostToDevice, h->stream));
-  HIP_CHECK(hipEventRecord(h->ev_stage[s], h->stream));
-}
-
-// pmaf_tick's obstacles: converted into the mapped pinned buffer k_manager reads directly. One buffer is enough:
-// pmaf_tick returns only after the manager kernel that read it has published its result.
+// The caller's obstacle list (pmaf_tick, pmaf_move_real, pmaf_reset_agents): converted into the mapped pinned buffer
+// k_manager reads directly. One buffer is enough: each of these calls returns only after the manager kernel that read it
+// has published its result.
 static const double *stage_live_obstacles_zero_copy(pmaf_planner *h, const double *obstacles) {
   if (!obstacles) return nullptr;
   const size_t n = (size_t)h->D.P * h->D.n_obs * 7;
@@ -944,10 +929,6 @@ int pmaf_create(const pmaf_params *prm, pmaf_planner **out) {
     HIP_CHECK(hipHostGetDevicePointer((void **)&h->d_zc, h->h_zc, 0));
     HIP_CHECK(hipHostMalloc((void **)&h->h_rp, sizeof(double) * (size_t)P * 3, hipHostMallocMapped));
     HIP_CHECK(hipHostGetDevicePointer((void **)&h->d_rp, h->h_rp, 0));
-    for (int i = 0; i < pmaf_planner::kStage; i++) {
-      HIP_CHECK(hipHostMalloc((void **)&h->h_stage[i], sizeof(double) * (size_t)P * 7 * n_obs, hipHostMallocDefault));
-      HIP_CHECK(hipEventCreateWithFlags(&h->ev_stage[i], hipEventDisableTiming));
-    }
     std::memset(h->h_out, 0, sizeof(double) * P * PMAF_MBOX);
 
     // ---- initial state = freshly constructed agents (cf_agent.h:69-97) ----
@@ -1049,10 +1030,6 @@ int pmaf_destroy(pmaf_planner *h) {
   if (h->h_np) (void)hipHostFree(h->h_np);
   if (h->d_link) (void)hipFree(h->d_link);
   if (h->h_link) (void)hipHostFree(h->h_link);
-  for (int i = 0; i < pmaf_planner::kStage; i++) {
-    if (h->h_stage[i]) (void)hipHostFree(h->h_stage[i]);
-    if (h->ev_stage[i]) (void)hipEventDestroy(h->ev_stage[i]);
-  }
   for (auto &e : h->ev_free) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   for (auto &e : h->ev_inflight) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   if (h->ev_mgr) (void)hipEventDestroy(h->ev_mgr);
@@ -1150,16 +1127,19 @@ int pmaf_evaluate(pmaf_planner *h, const double *cost_gains, const double *ws, i
       A.winner_hdr = claim_exchange_slot(h).d_send;  // (its exchange of two selections ago is through)
       A.winner_stride = (int)winner_rec(h);
     }
-    if (h->h_wp) {   // the winner path of this selection (sequence numbers of non-tick selections count down from -1)
+    // (sequence numbers of the manager launches that are not ticks count down from -1; the host waits for the mailbox,
+    // as pmaf_tick does, instead of for the stream: the result is on the host when the selection is published)
+    A.seq = (h->call_seq -= 1.0);
+    if (h->h_wp) {   // the winner path of this selection
       A.wp_out = h->d_wp; A.wp_hdr = h->d_wph;
-      A.seq = (h->wp_counter -= 1.0);
       h->wp_seq = A.seq;
       h->wp_timed = true;
     }
     launch_manager(h, A);
-    HIP_CHECK(hipStreamSynchronize(h->stream));
+    wait_mailbox(h, A.seq);
+    h->has_best_h = 1;
     if (h->x.c) begin_exchange(h, h->D.paths);
-    if (!h->ev_inflight.empty()) drain_events(h, true);
+    if (!h->ev_inflight.empty()) drain_events(h, false);
     refresh_real_cache(h);
     if (best_idx)
       for (int p = 0; p < h->D.P; p++) best_idx[p] = (int32_t)h->h_out[p * PMAF_MBOX];
@@ -1171,21 +1151,31 @@ int pmaf_move_real(pmaf_planner *h, const double *obstacles, double dt, int32_t 
     REQUIRE(h && agent_id, "pmaf_move_real: NULL argument");
     REQUIRE(steps >= 0, "pmaf_move_real: steps must be >= 0");
     h->use_device();
-    sync(h);
-    int32_t hb = 0;
-    h->download(&hb, h->D.has_best, 1);
-    if (!hb) fail(PMAF_ERR_STATE, "pmaf_move_real: no best agent yet (call pmaf_evaluate first; the reference dereferences a null best_agent_ here)");
+    if (h->has_best_h < 0) {   // unknown (restored / set from outside): read it back once
+      sync(h);
+      int32_t hb = 0;
+      h->download(&hb, h->D.has_best, 1);
+      h->has_best_h = hb ? 1 : 0;
+    }
+    if (!h->has_best_h) fail(PMAF_ERR_STATE, "pmaf_move_real: no best agent yet (call pmaf_evaluate first; the reference dereferences a null best_agent_ here)");
     for (int p = 0; p < h->D.P; p++) REQUIRE(agent_id[p] >= 0 && agent_id[p] < h->D.N, "pmaf_move_real: agent_id out of range");
-    upload_live_obstacles(h, obstacles);
-    h->upload(h->d_agent_id, agent_id, h->D.P);
+    // the call's small inputs travel like pmaf_tick's: the obstacle list through the mapped pinned buffer (not at all when
+    // it is the resident one), the agent indices by value in the kernel arguments (<= 4 populations), the result through
+    // the mailbox -- no copy command and no stream synchronisation (round 5; the node's five calls 106 -> ~45 us)
+    const double *live = stage_live_obstacles_zero_copy(h, obstacles);
+    const bool inl = h->D.P <= PMAF_RP_INLINE;
+    if (!inl) h->upload(h->d_agent_id, agent_id, h->D.P);
     for (int s = 0; s < steps; s++) {
       ManagerArgs A{};
       A.do_move = 1;
       A.dt_real = dt;
-      A.agent_id = h->d_agent_id;
+      if (inl) { A.agent_id_inline = 1; for (int p = 0; p < h->D.P; p++) A.agent_id_val[p] = agent_id[p]; }
+      else A.agent_id = h->d_agent_id;
+      A.live_src = (s == 0) ? live : nullptr;
       A.out = h->d_out;
-      launch_manager(h, A);
-      sync(h);
+      A.seq = (h->call_seq -= 1.0);
+      try { launch_manager(h, A); wait_mailbox(h, A.seq); }
+      catch (...) { h->live_resident.clear(); h->last_live.clear(); h->closest_dirty = true; throw; }
       refresh_real_cache(h);
       append_real_path(h);
     }
@@ -1198,18 +1188,31 @@ int pmaf_reset_agents(pmaf_planner *h, const double *pos, const double *vel, con
     check_range(pos, (size_t)h->D.P * 3, "pmaf_reset_agents: pos");
     check_range(vel, (size_t)h->D.P * 3, "pmaf_reset_agents: vel");
     h->use_device();
-    sync(h);
-    upload_live_obstacles(h, obstacles);
-    std::vector<double> in(h->D.P * 6);
-    for (int p = 0; p < h->D.P; p++)
-      for (int c = 0; c < 3; c++) { in[p * 6 + c] = pos[p * 3 + c]; in[p * 6 + 3 + c] = vel[p * 3 + c]; }
-    h->upload(h->d_reset_in, in.data(), in.size());
+    // an exchange in flight still reads the scored path buffer until its pack kernel is through (the reset rewrites the
+    // paths' first points); everything else is ordered by the stream
+    for (auto &sl : h->x.slot)
+      if (sl.pack_pending) { HIP_CHECK(hipEventSynchronize(sl.ev_pack)); sl.pack_pending = false; }
+    const double *live = stage_live_obstacles_zero_copy(h, obstacles);
     ManagerArgs A{};
     A.do_reset = 1;
+    if (h->D.P <= PMAF_RP_INLINE) {
+      A.reset_in_inline = 1;
+      for (int p = 0; p < h->D.P; p++)
+        for (int c = 0; c < 3; c++) { A.reset_in_val[p * 6 + c] = pos[p * 3 + c]; A.reset_in_val[p * 6 + 3 + c] = vel[p * 3 + c]; }
+    } else {
+      std::vector<double> in(h->D.P * 6);
+      for (int p = 0; p < h->D.P; p++)
+        for (int c = 0; c < 3; c++) { in[p * 6 + c] = pos[p * 3 + c]; in[p * 6 + 3 + c] = vel[p * 3 + c]; }
+      h->upload(h->d_reset_in, in.data(), in.size());
+    }
     A.reset_in = h->d_reset_in;
+    A.live_src = live;
     A.out = h->d_out;
-    launch_manager(h, A);
-    sync(h);
+    A.seq = (h->call_seq -= 1.0);
+    // (the mailbox is published once the kernel has read its inputs -- the staging buffer is free again -- and before
+    // its reset stores, which the stream orders in front of whatever is launched next)
+    try { launch_manager(h, A); wait_mailbox(h, A.seq); }
+    catch (...) { h->live_resident.clear(); h->last_live.clear(); h->closest_dirty = true; throw; }
     refresh_real_cache(h);
     h->scores_valid = false;
     h->rollout_pending = true;
@@ -1271,6 +1274,7 @@ int pmaf_tick(pmaf_planner *h, const double *obstacles, double dt, const double 
       if (h->tick_count < pmaf_planner::TICK_RING) h->tick_count++;
     }
     resident_guard.armed = false;   // the manager kernel has read the list and published its result
+    h->has_best_h = 1;
     const int peer_late = h->peer.on ? peer_book_tick(h) : 0;
     if (h->x.c) begin_exchange(h, scored);  // pack + all-gather on the exchange stream, beside the rollout
     refresh_real_cache(h);
@@ -1626,6 +1630,7 @@ int pmaf_set_best(pmaf_planner *h, const int32_t *id, const int32_t *type, const
       REQUIRE(id[p] == 0 || (type[p] >= PMAF_GOAL_HEURISTIC && type[p] <= PMAF_HAD_HEURISTIC),
               "pmaf_set_best: type must be one of the six heuristics when id > 0");
       hb[p] = id[p] > 0;
+      if (p == 0) h->has_best_h = hb[p] ? 1 : 0;
     }
     h->upload(D.has_best, hb.data(), D.P);
     h->upload(D.best_id, id, D.P);
@@ -2183,6 +2188,7 @@ int pmaf_load_state(pmaf_planner *h, const void *blob, size_t bytes) {
     h->rollout_pending = hd.rollout_pending != 0;
     h->stepped = hd.stepped != 0;
     h->real_pos_pending = false;
+    h->has_best_h = -1;        // (the blob's: read back when pmaf_move_real asks)
     h->closest_dirty = true;   // (the blob's table matches its obs_start; recompute at the next reset all the same)
     h->last_live.clear();
     h->live_resident.clear();

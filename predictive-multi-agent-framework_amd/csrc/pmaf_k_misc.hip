@@ -404,7 +404,7 @@ __global__ __launch_bounds__(64) void k_manager(DevView D, CostParams CP, Manage
   PMAF_MSEC();   // 2: selection
   if (A.do_move) {
     // RealCfAgent::cfPlanner one step, B/src/cf_agent.cpp:343-366
-    int gid = A.agent_id ? A.agent_id[pop] : best;
+    int gid = A.agent_id_inline ? A.agent_id_val[pop] : (A.agent_id ? A.agent_id[pop] : best);
     size_t pg = (size_t)pop * N + gid;
     double k_attr = D.k_attr[pg], k_circ = D.k_circ[pg], k_repel = D.k_repel[pg], k_damp = D.k_damp[pg];
     wave_lds_fence();  // obstacle table + known flags in LDS
@@ -548,7 +548,10 @@ __global__ __launch_bounds__(64) void k_manager(DevView D, CostParams CP, Manage
     // resetEEAgents, B/src/cf_manager.cpp:246-255
     V3 sp, sv;
     if (A.reset_from_real) { sp = rp; sv = rv; }
-    else {
+    else if (A.reset_in_inline) {
+      sp = mk(A.reset_in_val[pop * 6], A.reset_in_val[pop * 6 + 1], A.reset_in_val[pop * 6 + 2]);
+      sv = mk(A.reset_in_val[pop * 6 + 3], A.reset_in_val[pop * 6 + 4], A.reset_in_val[pop * 6 + 5]);
+    } else {
       const double *in = A.reset_in + pop * 6;
       sp = mk(in[0], in[1], in[2]);
       sv = mk(in[3], in[4], in[5]);

@@ -150,6 +150,12 @@ struct ManagerArgs {
   // (closed-loop set-point latency 15.8 -> 14.4 us at C2, the open-loop figure). real_pos_inline = 1: use real_pos_val.
   int real_pos_inline;
   double real_pos_val[3 * 4];
+  // the individual calls of the node's sequence (pmaf_move_real / pmaf_reset_agents) hand their small inputs over the same
+  // way for <= PMAF_RP_INLINE populations instead of through a synchronous copy each (round 5: the five calls 106 -> ~45 us)
+  int agent_id_inline;          // 1: agent_id_val[pop] is the gains index of the real step
+  int32_t agent_id_val[4];
+  int reset_in_inline;          // 1: reset_in_val[pop][6] = pos, vel
+  double reset_in_val[6 * 4];
 };
 #define PMAF_RP_INLINE 4
 

@@ -130,6 +130,30 @@ def cpu_baseline(config, budget_s, episode=None):
     return out
 
 
+def cxx_boundary_latency(n_agents=64, cap=201, samples=400):
+    """One planCallback through the C++ facade (tests/cpp/facade_tick lat, built by __graft_entry__.build()) on an idle
+    stream, no interpreter in the way: CfManager::planTick open loop, setRealEEAgentPosition + planTick closed loop, and
+    the UNCHANGED node's five individual calls (B/src/panda_bimanual_control.cpp:333-352). static1 scene."""
+    import re
+    v = os.environ.get("PMAF_VARIANT", "")
+    exe = os.path.join(ROOT, "tests", "cpp", "facade_tick" + ("_" + v if v else ""))
+    if not os.path.exists(exe):
+        return None
+    try:
+        r = subprocess.run([exe, "lat", str(n_agents), str(cap), str(samples)], capture_output=True, text=True, timeout=120)
+    except (OSError, subprocess.TimeoutExpired) as e:
+        return {"error": str(e)}
+    if r.returncode != 0:
+        return {"error": r.stderr[-300:]}
+    out = {"agents": n_agents, "max_prediction_steps": cap, "samples": samples, "scene": "static1 (9 + 1 obstacles)"}
+    for key, what in (("plan_tick_open_loop", "planTick, open loop"), ("plan_tick_closed_loop", "setRealEEAgentPosition + planTick, closed loop"),
+                      ("five_calls", "the node's five calls (stop ... start)")):
+        m = re.search(re.escape(what) + r"\s+median\s+([0-9.]+)\s+p90\s+([0-9.]+)\s+p99\s+([0-9.]+)\s+max\s+([0-9.]+)", r.stdout)
+        if m:
+            out[key] = {"median": float(m.group(1)), "p90": float(m.group(2)), "p99": float(m.group(3)), "max": float(m.group(4))}
+    return out
+
+
 def kernel_name_of(cfg, n_obs, math=2):
     """math: the arithmetic policy's template argument (2 = strict default, 3 = contracted)"""
     tiles = (n_obs - 1 + 63) // 64
@@ -895,6 +919,9 @@ def main():
         }
         if subs:
             out["configs"] = subs
+        if world == 1 and not args.only_headline:
+            # tick latency where the reference's node would see it: through the C++ facade, open / closed loop / five calls
+            out["cxx_boundary_latency_us"] = cxx_boundary_latency()
         if args.cpu_seconds > 0 and world == 1:  # reported at N = 1 only
             out["cpu_baseline"] = cpu_baseline(args.config if args.config in ("C1", "C2", "C3", "C5") else "C2", args.cpu_seconds)
             ts = subs.get("task_static1")

@@ -141,14 +141,14 @@ for nme in ("%s_cpu_bench_c2_run1.json" % R, "%s_cpu_bench_c2_run2.json" % R):
         pass
 bests = [cb["best"], d2["cpu_baseline"]["best"]] + runs
 out.append("**CPU baseline** (`cpu_baseline`, kind `port`: `oracle/cpu_bench.py`, the oracle in a process of its own on the box's host: %s, "
-           "%d logical CPUs, %s allowed to this process → **%d physical cores used, one pinned OpenMP thread each** (`GOMP_CPU_AFFINITY`), never "
+           "%d logical CPUs, %s in the affinity mask, cgroup CPU quota %s → **%d physical cores used, one pinned OpenMP thread each** (`GOMP_CPU_AFFINITY`), never "
            "more threads than agents; ≥ 3 s warm-up; `-O2` and `-O3 -march=native`, bit-identical results). At C2: best repetition **%s**, median %s "
            "rollouts/s on %d threads, %.0f %% of the repetitions within 10 %% of the best; one core: best %s. Reproducibility of `best` on this box: "
            "%s rollouts/s over %d runs (the two bench lines and two stand-alone runs back to back; spread %.0f %%). The driver's earlier records of "
            "the un-pinned measurement: 254 k (r03, 64 threads) and 60 k (r04, 32 threads, repetitions from 50 k to 177 k). **GPU / CPU at C2 = "
            "%.2f × the port's best, %.2f × its median, %.0f × one core**; C3 %.0f ×, C5 × 8 %.0f × (best). C2 is 64 independent 200-step chains — the "
            "shape where a GPU has the least to offer; the claim here is parity and an issue-bound step, not the ratio."
-           % (cb["cpu_model"], cb["host_cpus"], cb["affinity_cpus"], cb["physical_cores_allowed"], k(cb["best"]), k(cb["value"]), cb["cores"],
+           % (cb["cpu_model"], cb["host_cpus"], cb["affinity_cpus"], cb["cgroup_cpu_quota"], cb["physical_cores_allowed"], k(cb["best"]), k(cb["value"]), cb["cores"],
               100 * cb["share_of_repetitions_within_10pct_of_best"], k(cb["best_1core"]),
               " / ".join(k(b) for b in bests), len(bests), 100.0 * (max(bests) - min(bests)) / max(bests),
               d["value"] / cb["best"], d["value"] / cb["value"], d["value"] / cb["best_1core"],
@@ -202,9 +202,9 @@ tab = ["| BASELINE config | rollouts/s | tick | rollout kernel | CPU port: best 
 r = re.sub(r"(<!-- headline:begin -->\n).*?(<!-- headline:end -->)", lambda m: m.group(1) + "\n".join(tab) + "\n" + m.group(2), r, flags=re.S)
 r = re.sub(r"(<!-- ratio:begin -->).*?(<!-- ratio:end -->)", lambda m: m.group(1) + (
     "%.2f × the best repetition (%.2f × the median) of the multi-threaded CPU port of the same algorithm on the box's %s with one pinned thread per "
-    "allowed physical core (`best` reproduces within %.0f %% over %d runs on that box; the un-pinned measurement of rounds 3 / 4 ranged from 60 k to "
+    "allowed physical core -- %d of them: the cgroup's CPU quota (`best` reproduces within %.0f %% over %d runs on that box; the un-pinned measurement of rounds 3 / 4 ranged from 60 k to "
     "254 k rollouts/s between driver runs) — and %.0f × one core"
-    % (d["value"] / cb["best"], d["value"] / cb["value"], cb["cpu_model"], 100.0 * (max(bests) - min(bests)) / max(bests), len(bests),
+    % (d["value"] / cb["best"], d["value"] / cb["value"], cb["cpu_model"], cb["physical_cores_allowed"], 100.0 * (max(bests) - min(bests)) / max(bests), len(bests),
        d["value"] / cb["best_1core"])) + m.group(2), r, flags=re.S)
 r = re.sub(r"(<!-- frac:begin -->).*?(<!-- frac:end -->)", lambda m: m.group(1) + "%.2g of 8 TB/s" % rf["frac"] + m.group(2), r, flags=re.S)
 r = re.sub(r"(<!-- target:begin -->).*?(<!-- target:end -->)", lambda m: m.group(1) + "%.1f ×" % (d["value"] / 1e5) + m.group(2), r, flags=re.S)

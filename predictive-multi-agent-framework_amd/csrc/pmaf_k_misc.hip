@@ -277,10 +277,28 @@ __global__ __launch_bounds__(64) void k_manager(DevView D, CostParams CP, Manage
   double *live_dev = D.obs_live + (size_t)pop * 7 * n_obs;
   const double *live = A.live_src ? A.live_src + (size_t)pop * 7 * n_obs : live_dev;
   if (A.do_move || A.do_reset) {
-    for (int i = lane; i < 7 * n_obs; i += 64) {
-      const double x = live[i];
-      smem[i] = x;
-      if (A.live_src) live_dev[i] = x;
+    if (A.live_src) {
+      // a NEW list (moving obstacles streamed at the tick rate): every load is a PCIe read of ~1 us, and a rolled loop
+      // with the stores in between issued them one after the other (33 obstacles: +4.5 us of set-point latency, 129:
+      // +17 us). Batches of eight loads per lane in flight together, stored afterwards: one round trip per 512 values
+      // (round 5, tools/ticklat.py, set-point latency with a new list per tick: C2 17.3 -> 14.9 us, C3's 129 obstacles 33.1 -> 20.0 us;
+      // static lists: 13.4 us).
+      const int total = 7 * n_obs;
+      for (int base = 0; base < total; base += 64 * 8) {
+        double v[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+          const int i = base + k * 64 + lane;
+          v[k] = (i < total) ? __builtin_nontemporal_load(live + i) : 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+          const int i = base + k * 64 + lane;
+          if (i < total) { smem[i] = v[k]; live_dev[i] = v[k]; }
+        }
+      }
+    } else {
+      for (int i = lane; i < 7 * n_obs; i += 64) smem[i] = live[i];
     }
     for (int i = lane; i < n_obs; i += 64) s_known[i] = rk[i];
   }

@@ -55,3 +55,22 @@ for closed in (False, True):
     print("%s %-11s | around the calls median %.2f p99 %.2f us | pmaf_tick alone (library clock) set-point median %.2f p99 %.2f us"
           % (cfg, "closed loop" if closed else "open loop", np.median(wall), np.percentile(wall, 99), np.median(sp), np.percentile(sp, 99)), flush=True)
     h.close()
+
+# ---- a NEW obstacle list on every tick (moving obstacles streamed at the tick rate, as the shipped dyn tasks do): the
+# manager kernel reads the list out of mapped pinned host memory (PCIe) in front of the real step
+for cfgname, dyn_sc in (("C2 moving", pm.scenes.config_scene("C2", scene_id=3, dynamic=True)), ("C3 moving", pm.scenes.config_scene("C3", dynamic=True))):
+    h = pm.PmafPlanner(dyn_sc, device=0, mgr_init_pos=dyn_sc["start"])
+    h.set_initial_position(dyn_sc["start"])
+    o = dyn_sc["obstacles"].copy()
+    for k in range(n + 50):
+        if k == 50: h.tick_times_us()
+        if k % 128 == 0:
+            h.set_initial_position(dyn_sc["start"]); o = dyn_sc["obstacles"].copy()
+        h.stop()
+        h.tick(o, dyn_sc["dt"], dyn_sc["cost_gains"], dyn_sc["ws_limits"])
+        o = pm.scenes.advance_live_obstacles(o)
+    h.stop()
+    enq, sp = h.tick_times_us()
+    print("%s, a new list of %d obstacles on every tick | enqueue median %.2f p99 %.2f | set-point median %.2f p99 %.2f us"
+          % (cfgname, o.shape[0], np.median(enq), np.percentile(enq, 99), np.median(sp), np.percentile(sp, 99)), flush=True)
+    h.close()

@@ -330,6 +330,7 @@ def run_workload(ctx, spec, args, full):
     ranks = list(range(world))
     coupled = False
     host_coupled = False    # C4 across GPUs without fine-grained inboxes: set-points out of the winner table, on the host
+    mailbox_failed = False  # ... or because connecting / proving the peer mailboxes failed on some rank
     scaling = "weak"
     if mode == "c4":
         arms = S.dual_arm_scenes()
@@ -406,11 +407,59 @@ def run_workload(ctx, spec, args, full):
             if no_fine:
                 host_coupled = True
                 coupled = False
-            elif part:
-                planner.peer_connect(n_part, me, [box[r][0] for r in ranks])
+            else:
+                # connect, couple and PROVE the mailboxes with three ticks before anything is timed: whatever a first
+                # multi-GPU box holds in store (an IPC mapping that does not open, a peer store that never becomes
+                # visible -> the in-kernel wait times out after PMAF_PEER_TIMEOUT_S), every rank learns of it in the same
+                # reduction and the arms are coupled through the host instead -- a record, not a dead job
+                bad = 0.0
+                if part:
+                    try:
+                        if os.environ.get("PMAF_BENCH_FAIL_PEER") == "connect":   # test hook
+                            raise pkg.PmafError(-2, "PMAF_BENCH_FAIL_PEER=connect")
+                        planner.peer_connect(n_part, me, [box[r][0] for r in ranks])
+                        pkg.shard.couple_dual_arm_on_device(planner, n_part, me, np.stack([a["start"] for a in S.dual_arm_scenes()]))
+                    except pkg.PmafError as e:
+                        bad = 1.0
+                        sys.stderr.write("rank %d: peer mailboxes could not be connected (%s)\n" % (rank, e))
+                bad = ctx.max_over_ranks(bad)
+                if not bad:
+                    if part:
+                        try:
+                            if os.environ.get("PMAF_BENCH_FAIL_PEER") == "probe":   # test hook
+                                raise pkg.PmafError(-2, "PMAF_BENCH_FAIL_PEER=probe")
+                            planner.tick(obs, dt, cg, ws)
+                            planner.tick(None, dt, cg, ws)
+                            planner.tick(None, dt, cg, ws)
+                            planner.stop()
+                        except pkg.PmafError as e:
+                            bad = 1.0
+                            sys.stderr.write("rank %d: peer mailboxes failed their probe ticks (%s)\n" % (rank, e))
+                    bad = ctx.max_over_ranks(bad)
+                if bad:
+                    if part:
+                        try:
+                            planner.stop()
+                        except pkg.PmafError:
+                            pass
+                    ctx.barrier()                 # nobody unmaps an inbox a peer may still store into
+                    if part:
+                        try:
+                            planner.peer_disconnect()
+                        except pkg.PmafError:
+                            pass
+                    coupled = False
+                    if comm is None:
+                        if part:
+                            planner.close()
+                        return {"skipped": "C4 one arm per GPU: the peer mailboxes failed and there is no exchange communicator "
+                                           "(--no-exchange) to couple the arms through"} if rank == 0 else None
+                    host_coupled = True
+                    mailbox_failed = True
+                if part:
+                    planner.set_initial_position(starts)     # (the probe ticks moved the arms)
         elif part:
             planner.peer_connect(1, 0, [planner.peer_export(1)])
-        if part and coupled:
             pkg.shard.couple_dual_arm_on_device(planner, n_part, me, np.stack([a["start"] for a in S.dual_arm_scenes()]))
     hc = None
     if host_coupled and part:
@@ -623,7 +672,9 @@ def run_workload(ctx, spec, args, full):
             "note": ("device time between the events around ncclAllGather on the exchange stream (includes the "
                      "wait for the slowest rank); off the rollout's critical path") if transport == "rccl" else
                     "host transport: wall time of the all-gather callback (gloo), run when the table is asked for"},
-        "coupling": ("peer mailboxes" if coupled else "host, winner records" if host_coupled else None),
+        "coupling": ("peer mailboxes" if coupled else
+                     ("host, winner records (peer mailboxes failed to connect / their probe ticks failed: see stderr)" if mailbox_failed
+                      else "host, winner records") if host_coupled else None),
         "header_exchange_us": None if not coupled else {
             "wait_median": r0["peer_wait"][0] if r0["peer_wait"] else None,
             "wait_p99": r0["peer_wait"][1] if r0["peer_wait"] else None,

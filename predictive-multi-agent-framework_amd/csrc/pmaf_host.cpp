@@ -527,7 +527,7 @@ static void refresh_real_cache(pmaf_planner *h) {
 // Bounded in wall-clock time (round 4): a hung or wedged GPU must not hang a 100 Hz control loop at 100 % CPU -- after
 // PMAF_TICK_TIMEOUT_S (default 5 s) the call fails with PMAF_ERR_DEVICE (the clock is only read every 2^14 spins / on
 // every poll of the blocking variant).
-static void wait_mailbox(pmaf_planner *h, double seq) {
+static void wait_mailbox(pmaf_planner *h, double seq, const char *who = "pmaf_tick") {
   std::chrono::steady_clock::time_point t_start{};
   bool timing = false;
   for (int p = 0; p < h->D.P; p++) {
@@ -554,15 +554,15 @@ static void wait_mailbox(pmaf_planner *h, double seq) {
           // the mailbox later, so the handle takes no further tick until the stream has been drained (pmaf_stop)
           h->tick_abandoned = true;
           char msg[384];
-          snprintf(msg, sizeof msg, "pmaf_tick: no result from the manager kernel within the time limit (PMAF_TICK_TIMEOUT_S = %g s): "
-                   "device hung, the previous rollout still running%s; call pmaf_stop() before the next tick", h->tick_timeout_s,
+          snprintf(msg, sizeof msg, "%s: no result from the manager kernel within the time limit (PMAF_TICK_TIMEOUT_S = %g s): "
+                   "device hung, the previous rollout still running%s; call pmaf_stop() before the next tick", who, h->tick_timeout_s,
                    h->peer.on ? ", or a coupled peer's header outstanding (the in-kernel wait is bounded by PMAF_PEER_TIMEOUT_S)" : "");
           fail(PMAF_ERR_DEVICE, msg);
         }
         hipError_t e = hipStreamQuery(h->stream);
         if (e == hipErrorNotReady) continue;
         if (e != hipSuccess) throw HipError{e, "hipStreamQuery (mailbox wait)", __LINE__};
-        if (*s != seq) fail(PMAF_ERR_DEVICE, "pmaf_tick: manager kernel finished without publishing its result");
+        if (*s != seq) fail(PMAF_ERR_DEVICE, std::string(who) + ": manager kernel finished without publishing its result");
       }
     }
   }
@@ -1114,10 +1114,18 @@ int pmaf_stop(pmaf_planner *h) {
   });
 }
 
+// a call that ran into the time limit left its kernels queued: they still read the staging buffers and write the mailbox
+static void require_drained(pmaf_planner *h, const char *who) {
+  if (h->tick_abandoned)
+    fail(PMAF_ERR_STATE, std::string(who) + ": a previous call ran into its time limit with its kernels still queued; drain the "
+                         "stream with pmaf_stop() (or recreate the handle) first");
+}
+
 int pmaf_evaluate(pmaf_planner *h, const double *cost_gains, const double *ws, int32_t *best_idx) {
   return guarded([&] {
     REQUIRE(h && cost_gains && ws, "pmaf_evaluate: NULL argument");
     h->use_device();
+    require_drained(h, "pmaf_evaluate");
     set_cost_params(h, cost_gains, ws);
     ensure_scores(h);
     ManagerArgs A{};
@@ -1136,7 +1144,7 @@ int pmaf_evaluate(pmaf_planner *h, const double *cost_gains, const double *ws, i
       h->wp_timed = true;
     }
     launch_manager(h, A);
-    wait_mailbox(h, A.seq);
+    wait_mailbox(h, A.seq, "pmaf_evaluate");
     h->has_best_h = 1;
     if (h->x.c) begin_exchange(h, h->D.paths);
     if (!h->ev_inflight.empty()) drain_events(h, false);
@@ -1151,6 +1159,7 @@ int pmaf_move_real(pmaf_planner *h, const double *obstacles, double dt, int32_t 
     REQUIRE(h && agent_id, "pmaf_move_real: NULL argument");
     REQUIRE(steps >= 0, "pmaf_move_real: steps must be >= 0");
     h->use_device();
+    require_drained(h, "pmaf_move_real");
     if (h->has_best_h < 0) {   // unknown (restored / set from outside): read it back once
       sync(h);
       int32_t hb = 0;
@@ -1174,7 +1183,7 @@ int pmaf_move_real(pmaf_planner *h, const double *obstacles, double dt, int32_t 
       A.live_src = (s == 0) ? live : nullptr;
       A.out = h->d_out;
       A.seq = (h->call_seq -= 1.0);
-      try { launch_manager(h, A); wait_mailbox(h, A.seq); }
+      try { launch_manager(h, A); wait_mailbox(h, A.seq, "pmaf_move_real"); }
       catch (...) { h->live_resident.clear(); h->last_live.clear(); h->closest_dirty = true; throw; }
       refresh_real_cache(h);
       append_real_path(h);
@@ -1188,6 +1197,7 @@ int pmaf_reset_agents(pmaf_planner *h, const double *pos, const double *vel, con
     check_range(pos, (size_t)h->D.P * 3, "pmaf_reset_agents: pos");
     check_range(vel, (size_t)h->D.P * 3, "pmaf_reset_agents: vel");
     h->use_device();
+    require_drained(h, "pmaf_reset_agents");
     // an exchange in flight still reads the scored path buffer until its pack kernel is through (the reset rewrites the
     // paths' first points); everything else is ordered by the stream
     for (auto &sl : h->x.slot)
@@ -1211,7 +1221,7 @@ int pmaf_reset_agents(pmaf_planner *h, const double *pos, const double *vel, con
     A.seq = (h->call_seq -= 1.0);
     // (the mailbox is published once the kernel has read its inputs -- the staging buffer is free again -- and before
     // its reset stores, which the stream orders in front of whatever is launched next)
-    try { launch_manager(h, A); wait_mailbox(h, A.seq); }
+    try { launch_manager(h, A); wait_mailbox(h, A.seq, "pmaf_reset_agents"); }
     catch (...) { h->live_resident.clear(); h->last_live.clear(); h->closest_dirty = true; throw; }
     refresh_real_cache(h);
     h->scores_valid = false;
@@ -1226,9 +1236,7 @@ int pmaf_tick(pmaf_planner *h, const double *obstacles, double dt, const double 
     REQUIRE(h && cost_gains && ws, "pmaf_tick: NULL argument");
     const auto t_entry = std::chrono::steady_clock::now();
     h->use_device();
-    if (h->tick_abandoned)
-      fail(PMAF_ERR_STATE, "pmaf_tick: the previous tick ran into its time limit with its kernels still queued; drain the "
-                           "stream with pmaf_stop() (or recreate the handle) before the next tick");
+    require_drained(h, "pmaf_tick");
     // whatever fails between here and the manager kernel's result: the list handed over with this call may not have
     // reached D.obs_live, so it must not count as resident (a retry with the same list has to hand it over again)
     struct ResidentGuard {

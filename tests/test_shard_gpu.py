@@ -543,13 +543,15 @@ def test_bench_multi_rank_modes_on_one_gpu(args, n_ranks):
 
 
 @pytest.mark.timeout(600)
-def test_bench_c4_couples_through_the_host_when_inboxes_cannot_be_shared():
-    """C4 one arm per rank on a runtime that cannot export fine-grained inboxes (forced here with
-    PMAF_BENCH_C4_HOST_COUPLED=1): NOT a skipped record -- each tick waits for the winner table and takes the other arm's
-    set-point out of it, and the record says so"""
+@pytest.mark.parametrize("hook", [{"PMAF_BENCH_C4_HOST_COUPLED": "1"}, {"PMAF_BENCH_FAIL_PEER": "connect"}, {"PMAF_BENCH_FAIL_PEER": "probe"}])
+def test_bench_c4_couples_through_the_host_when_inboxes_cannot_be_shared(hook):
+    """C4 one arm per rank on a runtime that cannot export fine-grained inboxes (forced with PMAF_BENCH_C4_HOST_COUPLED=1),
+    or whose peer mailboxes fail to connect / fail their three probe ticks on some rank (PMAF_BENCH_FAIL_PEER): NOT a
+    skipped record and not a dead job -- every rank learns of it in one reduction, each tick then waits for the winner
+    table and takes the other arm's set-point out of it, and the record says so"""
     import json
     import subprocess
-    env = dict(os.environ, PMAF_BENCH_BACKEND="gloo", PMAF_BENCH_SINGLE_DEVICE="1", PMAF_BENCH_C4_HOST_COUPLED="1")
+    env = dict(os.environ, PMAF_BENCH_BACKEND="gloo", PMAF_BENCH_SINGLE_DEVICE="1", **hook)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"),
            "--gpus", "2", "--steps", "12", "--warmup", "3", "--min-seconds", "0.05", "--flop-ticks", "0", "--config", "C4"]
@@ -558,6 +560,8 @@ def test_bench_c4_couples_through_the_host_when_inboxes_cannot_be_shared():
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert out["value"] and out["value"] > 0 and "skipped" not in out
     assert "THROUGH THE HOST" in out["config"]["workload"] and out["header_exchange_us"] is None
+    if "PMAF_BENCH_FAIL_PEER" in hook:
+        assert "peer mailboxes" in r.stderr and ("could not be connected" in r.stderr or "probe ticks" in r.stderr)
     assert out["allgather_us"]["n"] >= 12 and out["h_eff"] == out["config"]["horizon"]
 
 

@@ -67,39 +67,63 @@ static inline v3 vcross(v3 a, v3 b) {
 }
 /*
  * exp(): the reference calls std::exp (B/src/cf_agent.cpp:220), i.e. the
- * platform libm, whose last bit differs between libms (glibc vs numpy vs ROCm
- * OCML disagree on 4-6 % of arguments). Mode 0 (default) keeps libm exp: the
- * reference-faithful restatement. Mode 1 uses pmaf_portable_exp below, a
- * table-free argument reduction + polynomial (error < 1 ulp) written with
- * correctly rounded IEEE operations only (* rint fma ldexp), so it
- * gives the same bits on every IEEE platform; the HIP kernels use the same
- * function (csrc/pmaf_device.hpp), which makes kernel-vs-oracle comparisons
- * bit-exact in mode 1.
+ * platform libm, whose last bit is not the same in every libm. Mode 0 (default)
+ * keeps the host's libm exp: the reference-faithful restatement. Mode 1 uses
+ * pmaf_portable_exp below, a restatement of glibc >= 2.28's exp in correctly
+ * rounded IEEE operations only (fma, *, +, integer bit operations, a table of
+ * 2^(k/128)), so it gives the same bits on every IEEE platform; the HIP kernels
+ * evaluate the same function (csrc/pmaf_device.hpp), which makes
+ * kernel-vs-oracle comparisons bit-exact in mode 1 -- and on a host whose libm
+ * IS that algorithm (any x86-64 glibc >= 2.28 on a CPU with FMA) mode 1 and
+ * mode 0 are the same function.
  */
 static int g_exp_mode = 0;
 void orc_set_exp_mode(int mode) { g_exp_mode = mode; }
 int orc_get_exp_mode(void) { return g_exp_mode; }
 
+#ifdef PMAF_FLOPCOUNT
+/* the operation-counting build (flopcount.cpp) counts in exp mode 0, where exp() is ONE operation */
+double pmaf_portable_exp(double x) { return exp(x); }
+#else
+#include "pmaf_exp_table.h"
+/* The exp() the reference calls (std::exp, B/src/cf_agent.cpp:220 = glibc's libm), RESTATED so that host and gfx950
+ * evaluate the same operations: glibc >= 2.28's algorithm (sysdeps/ieee754/dbl-64/e_exp.c; the variant compiled with FMA
+ * contraction, which the ifunc selects on every x86-64 CPU with FMA) -- N = 128 table of 2^(k/N), degree-5 polynomial,
+ * operation order as in tools/gen_exp_table.py's header. Every operation is a correctly rounded IEEE one (fma() is
+ * exact-then-rounded with or without hardware FMA), so the bits equal csrc/pmaf_device.hpp:portable_exp on gfx950 AND the
+ * host libm's exp() wherever that libm is this algorithm (tests/test_oracle_properties.py checks it on the machine it runs
+ * on: 2e8 arguments without a mismatch on the build image, glibc 2.35). Error 0.511 ulp.
+ * Range: x is clamped to >= -500 -- below -512 glibc leaves this path for its subnormal-safe one (an unfused last step),
+ * and the only caller forms 1 - exp(x), which is 1.0 for every exp(x) < 2^-54 (x < -37.4): the clamp changes no result
+ * of the planner and keeps ONE straight-line sequence on the device; x above 709.78 -> +inf like exp(). */
 double pmaf_portable_exp(double x) {
-  /* Cody-Waite reduction by two FMAs, degree-11 Horner polynomial on FMAs (coefficients: oracle/exp_poly.py),
-   * scaling by ldexp; every operation is correctly rounded IEEE (fma() is exact-then-rounded with or without
-   * hardware FMA), so the bits equal csrc/pmaf_device.hpp:portable_exp on gfx950. Worst error 0.81 ulp. */
-  const double ln2HI = 6.93147180369123816490e-01, ln2LO = 1.90821492927058770002e-10,
-               invln2 = 1.44269504088896338700e+00,
-               c3 = 0x1.5555555555555p-3, c4 = 0x1.5555555554cb8p-5, c5 = 0x1.1111111110e6bp-7,
-               c6 = 0x1.6c16c1738ed26p-10, c7 = 0x1.a01a01a4b26ffp-13, c8 = 0x1.a019c9ab128cfp-16,
-               c9 = 0x1.71de17e78d069p-19, c10 = 0x1.2880393b27194p-22, c11 = 0x1.af2360fb197fap-26;
-  if (x != x) return x;                                   /* NaN */
-  const double xs = fmin(fmax(x, -708.0), 710.0);         /* outside: >= 3.3e-308 / +inf (ldexp overflow) */
-  const double kf = rint(xs * invln2);                    /* round to nearest even (default rounding mode) */
-  double r = fma(-kf, ln2HI, xs);
-  r = fma(-kf, ln2LO, r);
-  double p = c11;
-  p = fma(p, r, c10); p = fma(p, r, c9); p = fma(p, r, c8); p = fma(p, r, c7); p = fma(p, r, c6);
-  p = fma(p, r, c5); p = fma(p, r, c4); p = fma(p, r, c3); p = fma(p, r, 0.5); p = fma(p, r, 1.0);
-  p = fma(p, r, 1.0);
-  return ldexp(p, (int)kf);
+  double kd, r, tail, scale;
+  uint64_t ki, sbits, u;
+  const double *K = (const double *)(const void *)PMAF_EXP_DATA;   /* the eight constants' bit patterns as doubles */
+  if (x != x) return x;                                    /* NaN */
+  if (x > 0x1.62e42fefa39efp+9) return INFINITY;           /* overflow threshold of exp() */
+  const double xs = fmax(x, -500.0);
+  kd = fma(xs, K[0], K[1]);
+  memcpy(&ki, &kd, 8);
+  kd = kd - K[1];
+  r = fma(kd, K[2], xs);
+  r = fma(kd, K[3], r);
+  u = PMAF_EXP_DATA[8 + 2 * (ki & (PMAF_EXP_N - 1))];
+  memcpy(&tail, &u, 8);
+  sbits = PMAF_EXP_DATA[9 + 2 * (ki & (PMAF_EXP_N - 1))] + (ki << 45);
+  {
+    const double a = fma(K[5], r, K[4]);                   /* C2 + r C3 */
+    const double tr = r + tail;
+    const double r2 = r * r;
+    const double b = fma(r, K[7], K[6]);                   /* C4 + r C5 */
+    const double c = fma(a, r2, tr);
+    const double r4 = r2 * r2;
+    const double tmp = fma(r4, b, c);
+    memcpy(&scale, &sbits, 8);
+    return fma(scale, tmp, scale);
+  }
 }
+#endif
 static inline double orc_exp(double x) { return g_exp_mode ? pmaf_portable_exp(x) : exp(x); }
 
 static inline double dmax(double a, double b) { return (a < b) ? b : a; }

@@ -70,7 +70,9 @@ kcompile() {  # kcompile <object stem> <source> [defines...]
 # tools/dbg/ab variants; profiles/r3_ab_sched_flags.txt)
 # (last session of round 4: loops aligned to 32 bytes in this unit -- with the repulsive obstacle's rider the unaligned layout
 # cost C1 0.9 % and C2 0.5 %, aligned 0.0 / 0.4 %, and C4 gains another 0.9 %: profiles/r4_ab_w64.txt item 8)
-kcompile k_w64_m2_t1 pmaf_k_w64.hip -DPMAF_W64_MATH=2 -DPMAF_W64_PART=1 -falign-loops=32
+# (round 5, with the glibc-compatible exp and its table load in the scaling chain: -DPMAF_SUM_HOIST=11 keeps that chain's
+# tail in the block of the ordered sum's first chunk -- C1 110.2 -> 108.7, C2 226.0 -> 224.3 us on one box)
+kcompile k_w64_m2_t1 pmaf_k_w64.hip -DPMAF_W64_MATH=2 -DPMAF_W64_PART=1 -falign-loops=32 -DPMAF_SUM_HOIST=11
 # (third session: and with every block that is not fallen into aligned to 64 bytes -- C3 1018.9 -> 1011.2 us on one box, any
 # alignment from 16 to 128 bytes within 2 us of that; the one-slot kernels lose 0.2-0.8 % with it, the group kernel is
 # indifferent: profiles/r3_ab_session3.txt item 19)

@@ -13,7 +13,7 @@
 // Floating point: IEEE double, no FMA contraction (-ffp-contract=off), true
 // divisions and square roots, and the reference's operation order (see
 // oracle/pmaf_oracle.c header), so results are bit-identical to the CPU
-// restatement; exp() (attractorForceScaling :220) is the portable_exp below.
+// restatement; exp() (attractorForceScaling :220) is the portable_exp below (glibc's algorithm restated).
 //
 // The sequential `force_ += curr_force` of circForce (:106) is reproduced by
 // adding the non-zero per-obstacle terms in ascending obstacle index
@@ -312,57 +312,60 @@ __device__ __forceinline__ V3 unit_triple(V3 v, V3 c) {
   }
 }
 
-// exp() of attractorForceScaling (B/src/cf_agent.cpp:220). The reference calls the platform libm, whose last bit is
-// not portable; this is a table-free exp in correctly rounded IEEE operations only (multiply, round-to-nearest-even
-// integer, fused multiply-add, ldexp), the same function as oracle/pmaf_oracle.c:pmaf_portable_exp, so it produces
-// identical bits on the host and on gfx950. Round 3 (second form): Cody-Waite reduction r = x - k ln2 by two FMAs,
-// degree-11 polynomial in Horner form on FMAs (c0 = c1 = 1, c2 = 1/2 exact, c3..c11 fitted on |r| <= ln2 / 2:
-// oracle/exp_poly.py; worst error 0.81 ulp over the reduced range), scaling by v_ldexp_f64 -- 21 instructions where the
-// fdlibm-style rational form (rounds 1-2) took 38, on the step's dependent chain where every instruction is an issue
-// slot. Arguments are clamped to [-708, 710] (below: >= 3.3e-308 instead of a subnormal / 0 -- attractorForceScaling
-// only forms 1 - exp(x); above: ldexp overflows to +inf as exp does); NaN propagates.
-// The constants come in a struct so that a kernel can hold them in VGPRs across its step loop (exp_consts_in_vgprs):
-// as literals they are scalar values the compiler keeps in -- and spills from -- the SGPR file.
+// exp() of attractorForceScaling (B/src/cf_agent.cpp:220). The reference calls std::exp, i.e. its platform's libm. Rounds
+// 1-4 evaluated an exp of their own (0.81 ulp) and accepted a last-bit difference against any libm on 5-10 % of the
+// arguments; round 5 RESTATES the libm the reference runs on instead: glibc >= 2.28's exp (sysdeps/ieee754/dbl-64/e_exp.c,
+// the variant compiled with FMA contraction that the ifunc selects on x86-64 CPUs with FMA), operation for operation --
+//   kd = fma(x, N / ln2, 0x1.8p52); ki = bits(kd); kd -= 0x1.8p52;  r = fma(kd, -ln2lo / N, fma(kd, -ln2hi / N, x));
+//   (tail, sbits) = T[ki % N], sbits += ki << 45;  tmp = fma(r^4, C4 + r C5, fma(C2 + r C3, r^2, tail + r));
+//   exp = fma(scale, tmp, scale)                    (N = 128; data: pmaf_exp_table.hpp, tools/gen_exp_table.py)
+// -- only correctly rounded IEEE operations and integer bit operations, the same function as
+// oracle/pmaf_oracle.c:pmaf_portable_exp, so host and gfx950 produce identical bits, AND the bits of the host libm's exp()
+// wherever that libm is this algorithm (checked on 2e8 arguments on the build image, glibc 2.35): there the oracle's
+// libm mode and its portable mode are one function and the kernels are bit-exact against the reference-faithful mode.
+// 0.511 ulp. The dependent chain is shorter than the degree-11 Horner form's (kd -> r -> r^2 -> two fused stages -> the
+// result: 8 operations deep instead of 16) at about the same instruction count; the table entry is a scalar load in the
+// wave-per-agent kernels (the argument is wave-uniform) and an LDS read in the lane-group kernels.
+// Range: x is clamped to >= -500 (below -512 glibc takes a subnormal-safe path with an unfused last step; the only caller
+// forms 1 - exp(x), which is 1.0 for every x < -37.4, so the clamp changes no result and keeps one straight-line
+// sequence); above 709.78: +inf; NaN propagates (non-NONPOS form).
+#include "pmaf_exp_table.hpp"
 struct ExpK {
-  double ln2HI, ln2LO, invln2, c3, c4, c5, c6, c7, c8, c9, c10, c11;
+  double invln2N, shift, neghi, neglo, c2, c3, c4, c5;
 };
 __device__ __forceinline__ ExpK exp_consts() {
   ExpK K;
-  K.ln2HI = 6.93147180369123816490e-01; K.ln2LO = 1.90821492927058770002e-10; K.invln2 = 1.44269504088896338700e+00;
-  K.c3 = 0x1.5555555555555p-3; K.c4 = 0x1.5555555554cb8p-5; K.c5 = 0x1.1111111110e6bp-7; K.c6 = 0x1.6c16c1738ed26p-10;
-  K.c7 = 0x1.a01a01a4b26ffp-13; K.c8 = 0x1.a019c9ab128cfp-16; K.c9 = 0x1.71de17e78d069p-19;
-  K.c10 = 0x1.2880393b27194p-22; K.c11 = 0x1.af2360fb197fap-26;
+  K.invln2N = 0x1.71547652b82fep+7; K.shift = 0x1.8p52; K.neghi = -0x1.62e42fefa0000p-8; K.neglo = -0x1.cf79abc9e3b3ap-47;
+  K.c2 = 0x1.ffffffffffdbdp-2; K.c3 = 0x1.555555555543cp-3; K.c4 = 0x1.55555cf172b91p-5; K.c5 = 0x1.1111167a4d017p-7;
   return K;
 }
+// the constants pinned in VGPRs across a kernel's step loop: as literals they are scalar values the compiler keeps in --
+// and spills from -- the SGPR file
 __device__ __forceinline__ ExpK exp_consts_in_vgprs() {
   ExpK K = exp_consts();
-  asm volatile("" : "+v"(K.ln2HI), "+v"(K.ln2LO), "+v"(K.invln2), "+v"(K.c3), "+v"(K.c4), "+v"(K.c5), "+v"(K.c6), "+v"(K.c7),
-               "+v"(K.c8), "+v"(K.c9), "+v"(K.c10), "+v"(K.c11));
+  asm volatile("" : "+v"(K.invln2N), "+v"(K.shift), "+v"(K.neghi), "+v"(K.neglo), "+v"(K.c2), "+v"(K.c3), "+v"(K.c4), "+v"(K.c5));
   return K;
 }
-// the same constants as a table (kernels that have no registers to hold twelve more loop-invariant doubles -- the
-// group kernel sits at its two-waves-per-SIMD VGPR budget -- keep the table in LDS and fetch the constants right where
-// the chain uses them: exp_consts_from_lds; volatile, so the compiler cannot hoist the twelve reads out of the step loop
-// and back into registers)
-constexpr int EXPK_N = 12;
+// the same data as an LDS table (kernels that have no registers to hold eight more loop-invariant doubles -- the group
+// kernel sits at its two-waves-per-SIMD VGPR budget -- and every kernel whose exp argument differs from lane to lane):
+// [0..7] the constants, [8 + 2k], [9 + 2k] the table; the constants are fetched right where the chain uses them
+// (exp_consts_from_lds; the address passes through an empty asm so that the reads stay in the step loop)
+constexpr int EXPK_N = PMAF_EXP_DATA_WORDS;
 __device__ __forceinline__ void exp_consts_to_lds(double *tab, int lane) {
-  const ExpK K = exp_consts();
-  double mine = K.ln2HI;
-  mine = (lane == 1) ? K.ln2LO : mine; mine = (lane == 2) ? K.invln2 : mine; mine = (lane == 3) ? K.c3 : mine;
-  mine = (lane == 4) ? K.c4 : mine; mine = (lane == 5) ? K.c5 : mine; mine = (lane == 6) ? K.c6 : mine;
-  mine = (lane == 7) ? K.c7 : mine; mine = (lane == 8) ? K.c8 : mine; mine = (lane == 9) ? K.c9 : mine;
-  mine = (lane == 10) ? K.c10 : mine; mine = (lane == 11) ? K.c11 : mine;
-  if (lane < EXPK_N) tab[lane] = mine;
+  for (int i = lane; i < EXPK_N; i += 64) tab[i] = __longlong_as_double((long long)PMAF_EXP_DATA[i]);
 }
-struct ExpKLds {   // every constant is read from the table at the point of use (a handful of VGPRs live at a time)
+struct ExpKLds {
   unsigned off;    // LDS byte address of the table
-  // the address passes through an empty asm together with the running value: the compiler can neither hoist the
-  // read out of the step loop (address unknown) nor issue it before the chain reaches this point (at most `ahead`
-  // constants in flight instead of twelve at once)
   __device__ __forceinline__ void tie(double &p) { asm volatile("" : "+v"(off), "+v"(p)); }
   __device__ __forceinline__ double get(int i) const {
     typedef const __attribute__((address_space(3))) double *lds_cptr;
     return reinterpret_cast<lds_cptr>(static_cast<uintptr_t>(off))[i];
+  }
+  __device__ __forceinline__ void entry(unsigned idx, double &tail, unsigned long long &sb) const {   // one ds_read_b128
+    typedef const __attribute__((address_space(3))) double *lds_cptr;
+    lds_cptr e = reinterpret_cast<lds_cptr>(static_cast<uintptr_t>(off)) + 8 + 2 * idx;
+    tail = e[0];
+    sb = (unsigned long long)__double_as_longlong(e[1]);
   }
 };
 __device__ __forceinline__ ExpKLds exp_consts_from_lds(const double *tab) {
@@ -371,93 +374,145 @@ __device__ __forceinline__ ExpKLds exp_consts_from_lds(const double *tab) {
   K.off = (unsigned)reinterpret_cast<uintptr_t>((lds_cptr)tab);
   return K;
 }
-struct ExpKRegs {  // the constants as values (literals / SGPRs, or VGPRs with exp_consts_in_vgprs)
+// the constants as values (literals / SGPRs, or VGPRs with exp_consts_in_vgprs). UNIFORM: the caller's argument is the
+// same in every lane (one agent per wave): the table entry is fetched by ONE scalar load (s_load_dwordx4 out of the
+// constant data) instead of a vector load per lane
+template <bool UNIFORM>
+struct ExpKRegs {
   const ExpK K;
   __device__ __forceinline__ void tie(double &) {}
   __device__ __forceinline__ double get(int i) const {
     switch (i) {
-      case 0: return K.ln2HI; case 1: return K.ln2LO; case 2: return K.invln2; case 3: return K.c3; case 4: return K.c4;
-      case 5: return K.c5; case 6: return K.c6; case 7: return K.c7; case 8: return K.c8; case 9: return K.c9;
-      case 10: return K.c10; default: return K.c11;
+      case 0: return K.invln2N; case 1: return K.shift; case 2: return K.neghi; case 3: return K.neglo; case 4: return K.c2;
+      case 5: return K.c3; case 6: return K.c4; default: return K.c5;
     }
+  }
+  __device__ __forceinline__ void entry(unsigned idx, double &tail, unsigned long long &sb) const {
+    const unsigned i = UNIFORM ? (unsigned)__builtin_amdgcn_readfirstlane((int)idx) : idx;
+    tail = __longlong_as_double((long long)PMAF_EXP_DATA[8 + 2 * i]);
+    sb = PMAF_EXP_DATA[9 + 2 * i];
   }
 };
 // NONPOS: the caller guarantees x <= 0 and not NaN, or discards the result otherwise (attractorForceScaling's
-// -sqrt(d) / shell with d in [1e-5, shell): the upper clamp and the NaN replacement drop out (3 instructions)
+// -sqrt(d) / shell with d in [1e-5, shell)): the overflow select and the NaN replacement drop out
 template <int MATH, class KT, bool NONPOS = false>
 __device__ __forceinline__ double portable_exp_k(double x, KT K) {
   double xs0 = x;
   K.tie(xs0);
   x = xs0;
-  const double xlo = __builtin_fmax(x, -708.0);                         // v_max_f64 (a NaN is replaced: see below)
-  const double xs = NONPOS ? xlo : __builtin_fmin(xlo, 710.0);
-  const double kf = __builtin_rint(xs * K.get(2));                      // v_rndne_f64: k = round-to-nearest-even(x / ln2)
-  double r = __builtin_fma(-kf, K.get(0), xs);                          // k * ln2HI is exact (ln2HI has 21 trailing zero bits)
-  r = __builtin_fma(-kf, K.get(1), r);
+  const double xlo = __builtin_fmax(x, -500.0);                          // v_max_f64 (a NaN is replaced: see below)
+  const double xs = NONPOS ? xlo : __builtin_fmin(xlo, 0x1.62e42fefa39efp+9);   // exp's overflow threshold: the scale stays finite up to it
+  double kd = __builtin_fma(xs, K.get(0), K.get(1));
+  const unsigned long long ki = (unsigned long long)__double_as_longlong(kd);
+  kd = kd - K.get(1);
+  double tail;
+  unsigned long long sb;
+  K.entry((unsigned)ki & (PMAF_EXP_N - 1), tail, sb);
+  double r = __builtin_fma(kd, K.get(2), xs);
+  r = __builtin_fma(kd, K.get(3), r);
   K.tie(r);
-  double p = K.get(11);
-#pragma unroll
-  for (int i = 10; i >= 3; i--) {
-    if (i == 7 || i == 4) K.tie(p);   // table variant: the next three / four constants are fetched from here on
-    p = __builtin_fma(p, r, K.get(i));
-  }
-  p = __builtin_fma(p, r, 0.5);
-  p = __builtin_fma(p, r, 1.0); p = __builtin_fma(p, r, 1.0);
-  const double res = __builtin_ldexp(p, (int)kf);                       // v_cvt_i32_f64 + v_ldexp_f64
+  const unsigned long long sbits = sb + (ki << 45);
+  const double a = __builtin_fma(K.get(5), r, K.get(4));                 // C2 + r C3
+  const double tr = r + tail;
+  const double r2 = r * r;
+  const double b = __builtin_fma(r, K.get(7), K.get(6));                 // C4 + r C5
+  const double c = __builtin_fma(a, r2, tr);
+  const double r4 = r2 * r2;
+  const double tmp = __builtin_fma(r4, b, c);
+  const double scale = __longlong_as_double((long long)sbits);
+  const double res = __builtin_fma(scale, tmp, scale);
   if (NONPOS) return res;
-  // NaN in, NaN out (the clamp above returns its other operand for a NaN): only the high word needs replacing
-  const long long bits = __double_as_longlong(res);
-  const long long nan_bits = (bits & 0xffffffffLL) | 0x7ff8000000000000LL;
-  return __longlong_as_double((x != x) ? nan_bits : bits);
+  // above exp's overflow threshold: +inf (the clamp kept the scale finite); NaN in, NaN out (the clamps return their
+  // other operand for a NaN)
+  const double big = (x > 0x1.62e42fefa39efp+9) ? __builtin_inf() : res;
+  return (x != x) ? x : big;
 }
+// portable_exp_nonpos in two halves (the wave-per-agent step): `begin` forms k, requests the table entry and evaluates
+// everything that does not need it; the caller puts independent work (the scaling's second factor: a division sequence)
+// between the halves, `end` consumes the entry -- the scalar load's latency is covered instead of waited out. Same
+// operations in the same order as portable_exp_k: same bits.
+struct ExpPend { double r, a, b, r2, r4, tail; unsigned long long sbits; };
+template <class KT>
+__device__ __forceinline__ ExpPend portable_exp_nonpos_begin(double x, KT K) {
+  ExpPend E;
+  const double xs = __builtin_fmax(x, -500.0);
+  double kd = __builtin_fma(xs, K.get(0), K.get(1));
+  const unsigned long long ki = (unsigned long long)__double_as_longlong(kd);
+  unsigned long long sb;
+  K.entry((unsigned)ki & (PMAF_EXP_N - 1), E.tail, sb);
+  kd = kd - K.get(1);
+  double r = __builtin_fma(kd, K.get(2), xs);
+  r = __builtin_fma(kd, K.get(3), r);
+  E.r = r;
+  E.sbits = sb + (ki << 45);
+  E.a = __builtin_fma(K.get(5), r, K.get(4));
+  E.r2 = r * r;
+  E.b = __builtin_fma(r, K.get(7), K.get(6));
+  E.r4 = E.r2 * E.r2;
+  return E;
+}
+__device__ __forceinline__ double portable_exp_nonpos_end(const ExpPend &E) {
+  const double tr = E.r + E.tail;
+  const double c = __builtin_fma(E.a, E.r2, tr);
+  const double tmp = __builtin_fma(E.r4, E.b, c);
+  const double scale = __longlong_as_double((long long)E.sbits);
+  return __builtin_fma(scale, tmp, scale);
+}
+__device__ __forceinline__ ExpPend portable_exp_nonpos_begin(double x, const ExpK &K) { return portable_exp_nonpos_begin<ExpKRegs<true>>(x, ExpKRegs<true>{K}); }
+__device__ __forceinline__ ExpPend portable_exp_nonpos_begin(double x, const ExpKLds &K) { return portable_exp_nonpos_begin<ExpKLds>(x, K); }
 template <int MATH = MATH_IEEE>
-__device__ __forceinline__ double portable_exp(double x, const ExpK &K) { return portable_exp_k<MATH, ExpKRegs>(x, ExpKRegs{K}); }
+__device__ __forceinline__ double portable_exp(double x, const ExpK &K) { return portable_exp_k<MATH, ExpKRegs<true>>(x, ExpKRegs<true>{K}); }
 template <int MATH = MATH_IEEE>
 __device__ __forceinline__ double portable_exp(double x, const ExpKLds &K) { return portable_exp_k<MATH, ExpKLds>(x, K); }
 template <int MATH = MATH_IEEE>
-__device__ __forceinline__ double portable_exp_nonpos(double x, const ExpK &K) { return portable_exp_k<MATH, ExpKRegs, true>(x, ExpKRegs{K}); }
+__device__ __forceinline__ double portable_exp_nonpos(double x, const ExpK &K) { return portable_exp_k<MATH, ExpKRegs<true>, true>(x, ExpKRegs<true>{K}); }
 template <int MATH = MATH_IEEE>
 __device__ __forceinline__ double portable_exp_nonpos(double x, const ExpKLds &K) { return portable_exp_k<MATH, ExpKLds, true>(x, K); }
+// (no constants handed in: the generic kernels and the self-test -- the argument may differ from lane to lane)
 template <int MATH = MATH_IEEE>
-__device__ __forceinline__ double portable_exp(double x) { return portable_exp<MATH>(x, exp_consts()); }
+__device__ __forceinline__ double portable_exp(double x) { return portable_exp_k<MATH, ExpKRegs<false>>(x, ExpKRegs<false>{exp_consts()}); }
 
-// portable_exp_nonpos with the table fetched in STAGES (round 4; the multi-slot wave-per-agent kernels, whose constants
-// come out of LDS at the point of use): every batch of constants is requested one stage before the chain needs it --
-// the reduction's three before the caller forms the argument (exp_head, tied to the argument's INPUT), c11..c8 as soon
-// as the argument exists, c7..c4 behind the rounding, c3 behind the reduction -- so that a lone wave does not sit out an
-// LDS round trip (~20 issue slots) in front of each batch (profiles/r4_c3_strict_steploop.txt showed four
-// ds_read / s_waitcnt pairs a few instructions apart). Same operations in the same order as portable_exp_k: same bits.
-struct ExpHead { double invln2, ln2HI, ln2LO; };
+// portable_exp_nonpos with its data requested in STAGES (the multi-slot wave-per-agent kernels, whose constants come out
+// of LDS at the point of use): the reduction's four constants before the caller forms the argument (exp_head, tied to the
+// argument's INPUT), the polynomial's four as soon as the argument exists, the table entry as soon as k does -- a lone
+// wave does not sit out an LDS round trip (~20 issue slots) in front of each batch. Same operations in the same order as
+// portable_exp_k: same bits.
+struct ExpHead { double invln2N, shift, neghi, neglo; };
 __device__ __forceinline__ ExpHead exp_head(ExpKLds &K, double &input) {
   K.tie(input);
-  ExpHead H; H.invln2 = K.get(2); H.ln2HI = K.get(0); H.ln2LO = K.get(1);
+  ExpHead H; H.invln2N = K.get(0); H.shift = K.get(1); H.neghi = K.get(2); H.neglo = K.get(3);
   return H;
 }
 __device__ __forceinline__ ExpHead exp_head(const ExpK &K, double &) {
-  ExpHead H; H.invln2 = K.invln2; H.ln2HI = K.ln2HI; H.ln2LO = K.ln2LO;
+  ExpHead H; H.invln2N = K.invln2N; H.shift = K.shift; H.neghi = K.neghi; H.neglo = K.neglo;
   return H;
 }
 template <class KT>
 __device__ __forceinline__ double portable_exp_nonpos_staged(double x, KT K, const ExpHead H) {
   K.tie(x);
-  const double c11 = K.get(11), c10 = K.get(10), c9 = K.get(9), c8 = K.get(8);
-  const double xs = __builtin_fmax(x, -708.0);
-  double kf = __builtin_rint(xs * H.invln2);
-  K.tie(kf);
-  const double c7 = K.get(7), c6 = K.get(6), c5 = K.get(5), c4 = K.get(4);
-  double r = __builtin_fma(-kf, H.ln2HI, xs);
-  r = __builtin_fma(-kf, H.ln2LO, r);
-  K.tie(r);
-  const double c3 = K.get(3);
-  double p = c11;
-  p = __builtin_fma(p, r, c10); p = __builtin_fma(p, r, c9); p = __builtin_fma(p, r, c8); p = __builtin_fma(p, r, c7);
-  p = __builtin_fma(p, r, c6); p = __builtin_fma(p, r, c5); p = __builtin_fma(p, r, c4); p = __builtin_fma(p, r, c3);
-  p = __builtin_fma(p, r, 0.5);
-  p = __builtin_fma(p, r, 1.0); p = __builtin_fma(p, r, 1.0);
-  return __builtin_ldexp(p, (int)kf);
+  const double c2 = K.get(4), c3 = K.get(5), c4 = K.get(6), c5 = K.get(7);
+  const double xs = __builtin_fmax(x, -500.0);
+  double kd = __builtin_fma(xs, H.invln2N, H.shift);
+  const unsigned long long ki = (unsigned long long)__double_as_longlong(kd);
+  double tail;
+  unsigned long long sb;
+  K.entry((unsigned)ki & (PMAF_EXP_N - 1), tail, sb);
+  kd = kd - H.shift;
+  double r = __builtin_fma(kd, H.neghi, xs);
+  r = __builtin_fma(kd, H.neglo, r);
+  const unsigned long long sbits = sb + (ki << 45);
+  const double a = __builtin_fma(c3, r, c2);
+  const double tr = r + tail;
+  const double r2 = r * r;
+  const double b = __builtin_fma(r, c5, c4);
+  const double c = __builtin_fma(a, r2, tr);
+  const double r4 = r2 * r2;
+  const double tmp = __builtin_fma(r4, b, c);
+  const double scale = __longlong_as_double((long long)sbits);
+  return __builtin_fma(scale, tmp, scale);
 }
 __device__ __forceinline__ double portable_exp_nonpos_staged(double x, const ExpK &K, const ExpHead H) {
-  return portable_exp_nonpos_staged<ExpKRegs>(x, ExpKRegs{K}, H);
+  return portable_exp_nonpos_staged<ExpKRegs<true>>(x, ExpKRegs<true>{K}, H);
 }
 __device__ __forceinline__ double portable_exp_nonpos_staged(double x, const ExpKLds &K, const ExpHead H) {
   return portable_exp_nonpos_staged<ExpKLds>(x, K, H);

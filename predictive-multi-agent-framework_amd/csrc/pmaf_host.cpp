@@ -866,12 +866,18 @@ int pmaf_create(const pmaf_params *prm, pmaf_planner **out) {
       // circular-field terms: 64 * TILES entries of 4 doubles
       size_t off = 7 * (size_t)n_obs + ((size_t)n_obs + 1) / 2;
       off += off & 1;
-      // w64: (64 * TILES + 8 padding + 64 scratch) entries; groups: 64 * TILES + one zero entry per group (<= 8)
-      h->lds_rollout = sizeof(double) * (off + (64 * 4 + 8 + 64) * 4 + 8 * 4);
+      // w64: (64 * TILES + 8 padding + 64 scratch) entries; groups: 64 * TILES + one zero entry per group (<= 8).
+      // TILES as dispatched (launch_rollout), never below 2: with the four-slot size a one-wave block of 129 obstacles
+      // asks for 18.5 KB + the kernel's 2.1 KB of static LDS (exp's table) -- over the 20 KB that let eight blocks
+      // share a CU, and 2048+ agents x 128 obstacles ran at 7/8 occupancy with a second round of blocks (+45 %).
+      const int slots = (M + h->lpa - 1) / h->lpa;
+      const bool narrow = h->lpa == 64 || h->lpa == 32 || h->lpa == 16 || h->lpa == 8;
+      const int tiles = (narrow && !h->force_generic && slots <= 2) ? 2 : 4;
+      h->lds_rollout = sizeof(double) * (off + (size_t)pmaf_list_area_doubles(tiles) + 8 * 4);
     }
     // table | known flags | costs | the tuned real step's list (64 * 4 + 8 + 64 entries of 4 doubles)
     // (+ 2: the wave-minimum cell of circ_and_scale_w64 behind the list)
-    h->lds_manager = sizeof(double) * (7 * (size_t)n_obs + ((size_t)n_obs + 1) / 2 + (size_t)N + 1 + (64 * 4 + 8 + 64) * 4 + 2);
+    h->lds_manager = sizeof(double) * (7 * (size_t)n_obs + ((size_t)n_obs + 1) / 2 + (size_t)N + 1 + (size_t)pmaf_list_area_doubles(4) + 2);
     REQUIRE(h->lds_rollout <= 160 * 1024, "pmaf_create: obstacle table does not fit in LDS");
     REQUIRE(h->lds_manager <= 160 * 1024,
             "pmaf_create: n_agents + obstacle table exceed the manager kernel's LDS budget (160 KB: 8 B per agent, 60 B per obstacle)");

@@ -21,9 +21,17 @@ using namespace pmaf;
 // PLAIN: every agent of the launch has k_attr != 0 and the agents have unit mass (the reference's defaults and every
 // shipped task file; decided by the host at pmaf_create): the step then carries neither the `k_attr != 0` select nor the
 // division by the mass -- for a lone wave every instruction is an issue slot
+// (ONE LDS copy of exp's data per block: a __shared__ array declared inside rollout_w64_body would be one array per
+// instantiation of the body -- six heuristics = 12.4 KB of static LDS per one-wave block, and 2048+ agents x 129 obstacles
+// no longer fit eight blocks to a CU: +45 % on those launches, found by tools/regime.py's sweep)
+__device__ __forceinline__ double *w64_exp_lds() {
+  __shared__ double s_expk[EXPK_N];
+  return s_expk;
+}
 template <int TILES>
-__device__ __forceinline__ auto w64_exp_consts(double *tab, int lane) {
+__device__ __forceinline__ auto w64_exp_consts(int lane) {
   if constexpr (TILES >= 2) {
+    double *tab = w64_exp_lds();
     exp_consts_to_lds(tab, lane);
     wave_lds_fence();
     return exp_consts_from_lds(tab);
@@ -50,8 +58,7 @@ __device__ __forceinline__ void rollout_w64_body(const DevView &D, const CostPar
   // portable_exp's twelve constants: pinned in VGPRs in the one-slot kernel; the multi-slot kernels sit at the
   // 256-VGPR ceiling and fetch them from an LDS table right where the chain uses them (one box, C3: 1151 -> 1128 us
   // against literals / SGPRs; the one-slot kernel the other way round, C2 243 against 264 us: profiles/r3_ab_exp.txt)
-  __shared__ double s_expk[EXPK_N];
-  const auto EK = w64_exp_consts<TILES>(s_expk, lane);
+  const auto EK = w64_exp_consts<TILES>(lane);
   const size_t pa = (size_t)pop * D.N + a;
   const double *src = D.obs_start + (size_t)pop * 7 * n_obs;
   const int32_t *ks = D.known_start + (size_t)pop * n_obs;

@@ -367,7 +367,7 @@ __device__ __forceinline__ void circ_and_scale_w64(int lane, V3 p, V3 v, double 
   constexpr int BATCH = 8;                 // list entries summed per LDS round trip (10, 12, 16 measured: no gain)
   constexpr int SCRATCH = 64 * TILES + BATCH;
   constexpr int SUM_SCRATCH = (4 * TILES + 1) * 64;  // PMAF_SUM_DPP: 4 TILES chunks of 64 doubles + the padding chunk
-  constexpr int MIN_CELL_BOUND = (64 * 4 + 8 + 64) * 4;   // doubles of the list area (the wave-minimum cell sits behind it)
+  constexpr int MIN_CELL_BOUND = pmaf_list_area_doubles(TILES);   // doubles of the list area (the wave-minimum cell sits behind it)
   (void)MIN_CELL_BOUND;
   (void)SCRATCH; (void)SUM_SCRATCH;
   const int M = n_obs - 1;
@@ -425,7 +425,7 @@ __device__ __forceinline__ void circ_and_scale_w64(int lane, V3 p, V3 v, double 
   // cell back -- three DS instructions issued here, their latency under the circular terms, instead of the two 6-stage
   // DPP reductions (12 dependent v_min_u32_dpp + read-backs) in the middle of the step. For a lone wave every
   // instruction is a 4-cycle issue slot (tools/slackprof.py), whatever unit executes it.
-  constexpr int MIN_CELL = (64 * 4 + 8 + 64) * 4;   // the double right behind the list area (pmaf_host.cpp: lds_rollout / lds_manager)
+  constexpr int MIN_CELL = pmaf_list_area_doubles(TILES);   // the double right behind the list area (pmaf_host.cpp: lds_rollout / lds_manager)
   unsigned long long *min_cell = reinterpret_cast<unsigned long long *>(clist + MIN_CELL);
   // (kernels with long lists only: with the few obstacles of the LDS-batch variant -- C1: nine -- there is not enough
   // work between the atomic and the read to cover the round trip: C1 136.7 -> 140.6 us, measured)
@@ -621,15 +621,16 @@ __device__ __forceinline__ void circ_and_scale_w64(int lane, V3 p, V3 v, double 
       double m_in = m;
       const ExpHead H = exp_head(EKs, m_in);
       w1 = 1 - portable_exp_nonpos_staged(-MT::div_pos(MT::sqrt_pos(m_in), C.shell), EKs, H);
-    } else {
-      w1 = 1 - portable_exp_nonpos<MATH>(-MT::div_pos(MT::sqrt_pos(m), C.shell), EK);
     }
+    ExpPend EP;
+    if (!(PMAF_EXP_STAGED && TILES >= 2)) EP = portable_exp_nonpos_begin(-MT::div_pos(MT::sqrt_pos(m), C.shell), EK);
     // |ro| and g.ro of the closest obstacle were computed by the lane that
     // owns it (same operands, same bits as recomputing them here)
     const int bl = bi & 63;
     const double sb = readlane_d(best_s, bl), gr = readlane_d(best_gr, bl);
     double w2 = 1 - MT::div(gr, dg * sb);
     w2 = w2 * w2;
+    if (!(PMAF_EXP_STAGED && TILES >= 2)) w1 = 1 - portable_exp_nonpos_end(EP);   // (the table entry has had w2's division to arrive)
     const double w = w1 * w2;
     sc = (bi == 0x7fffffff) ? 1.0 : (stall ? 0.0 : w);
   }

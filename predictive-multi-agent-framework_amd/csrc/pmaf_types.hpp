@@ -25,6 +25,11 @@ namespace pmaf {
 // arithmetic policy of the tuned rollout kernels (see pmaf_device.hpp "arithmetic policy")
 enum : int { MATH_IEEE = 0, MATH_FAST = 1, MATH_XACT = 2, MATH_FMA = 3 };
 
+// LDS list area of the wave-per-agent step (pmaf_rollout_w64.hpp: circ_and_scale_w64) in doubles: (64 * slots + 8 padding
+// + 64 scratch) entries of 4 doubles, sized for two slots per lane when the kernel has one or two and for four otherwise;
+// the wave-minimum cell is the double right behind it. Host (lds_rollout / lds_manager) and kernels agree through this.
+constexpr int pmaf_list_area_doubles(int slots_per_lane) { return (64 * (slots_per_lane <= 2 ? 2 : 4) + 8 + 64) * 4; }
+
 struct PopConst {
   double dt, vel_max, approach, shell, mass, rad;
   // exact squared thresholds (computed on the host, pmaf_host.cpp:sq_gt/sq_ge):

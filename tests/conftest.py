@@ -52,16 +52,35 @@ def oracle(pmaf):
     return orc
 
 
-# Tolerance tests (HIP with portable_exp, or the contracted policy, against the oracle's libm-exp mode) rest on a last-bit
-# difference of exp NOT being amplified past 1e-5 m. On chaotic rollouts (long horizons through moving spheres, C5's scene
-# 1, C3's 500-step chains) whether it is depends on the evaluation order: the cases below pass with the default
-# association and exceed the tolerance with the right-associated pair (profiles/r5_gpu_tests_rassoc.log: e.g. C5's
-# selected trajectory 2.1e-3 m, sim_kobo_dyn_spheres3 1.5e-3 m; set-points still agree while the same agent is selected).
-# They are expected failures THERE -- the 0-tolerance suite (every bit-exact test) is green for both pairs.
+# Tolerance tests of the CONTRACTED policy against the oracle's libm-exp mode rest on last-bit differences NOT being
+# amplified past 1e-5 m. On chaotic rollouts (long horizons through moving spheres, C3's 500-step chains) whether they are
+# depends on the evaluation order AND on every other last bit: with the round-4 exp the two cases below exceeded the
+# tolerance under the right-associated pair (profiles/r5_gpu_tests_rassoc.log of that build); with glibc's exp they happen
+# to hold (6 xpassed -> 2). Kept as NON-strict expected failures there: per-scene luck, not a contract. The strict kernels'
+# comparisons (libm:* / task_libm:* / strict_libm:*) are exact under either association since round 5 and are not listed.
 CHAOTIC_VS_LIBM = {
-    "rassoc": {"libm:C3", "task_libm:sim_kobo_dyn_spheres2", "task_libm:sim_kobo_dyn_spheres3", "strict_libm:C5",
-               "contracted:C3", "contracted_task:sim_kobo_dyn_spheres2"},
+    "rassoc": {"contracted:C3", "contracted_task:sim_kobo_dyn_spheres2"},
 }
+
+
+_LIBM_SAME = {}
+
+
+def libm_is_restated(orc):
+    """True when the host's libm exp is the algorithm oracle/pmaf_oracle.c:pmaf_portable_exp (and the kernels) restate --
+    glibc >= 2.28's FMA variant, as on the build image and the GPU boxes. Decided by comparing 20 000 results."""
+    if "v" not in _LIBM_SAME:
+        import math
+        rng = np.random.default_rng(77)
+        x = np.concatenate([-rng.uniform(0, 3, 12000), -rng.uniform(0, 500, 6000), rng.uniform(0, 700, 2000)])
+        _LIBM_SAME["v"] = bool((orc.portable_exp(x) == np.array([math.exp(v) for v in x])).all())
+    return _LIBM_SAME["v"]
+
+
+def libm_tol(orc, tol):
+    """the tolerance of a strict-kernels-vs-libm-oracle comparison: 0 where the host libm is the restated algorithm
+    (the kernels then ARE the reference's arithmetic, exp included), the north star's 1e-5 m elsewhere"""
+    return 0.0 if libm_is_restated(orc) else tol
 
 
 def expect_chaotic(request, case):

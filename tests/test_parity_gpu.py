@@ -338,6 +338,7 @@ def test_c5_dynamic_obstacles_full_size(pmaf, oracle, scenes):
 def test_libm_exp_oracle_within_north_star_tolerance(pmaf, oracle, scenes, cfg, ticks, request):
     conftest.expect_chaotic(request, "libm:" + cfg)
     oracle.set_exp_mode(0)
+    LIBM_TOL = conftest.libm_tol(oracle, 1e-5)      # 0 on a glibc >= 2.28 host: the kernels' exp is that libm's
     sc = scenes.config_scene(cfg)
     hip, ora = make_pair(pmaf, oracle, sc)
     bh, ph = drive(hip, sc, ticks)
@@ -369,8 +370,17 @@ def test_device_arithmetic_is_ieee_exact(pmaf, oracle):
     assert (pmaf.debug_math(1, a) == np.sqrt(a)).all()
     assert (pmaf.debug_math(3, a, b) == a * b).all()
     assert (pmaf.debug_math(4, a, b) == a + b).all()
-    x = -rng.uniform(0.0, 3.0, 200_000)
-    assert (pmaf.debug_math(2, x) == oracle.portable_exp(x)).all()
+    x = np.concatenate([-rng.uniform(0.0, 3.0, 200_000), -rng.uniform(0.0, 600.0, 50_000), rng.uniform(0.0, 720.0, 20_000),
+                        -np.ldexp(rng.uniform(0.5, 1.0, 20_000), -rng.integers(0, 70, 20_000)), [0.0, -0.0, -37.4, -500.0, -1e9, 709.7, 710.0]])
+    dev = pmaf.debug_math(2, x)
+    assert (dev == oracle.portable_exp(x)).all()
+    # ... and the kernels' exp IS the host libm's exp (glibc >= 2.28, FMA variant: the GPU boxes' image) wherever the
+    # clamp at -500 is not in the way: the reference's std::exp, bit for bit (round 5)
+    import math
+    ref = np.array([math.exp(v) if v <= 709.78 else math.inf for v in x])      # (math.exp raises where exp() returns inf)
+    if (oracle.portable_exp(x[:4000]) == ref[:4000]).all():
+        m = x > -500.0
+        assert (dev[m] == ref[m]).all(), "%d arguments differ from the host libm" % int((dev[m] != ref[m]).sum())
 
 
 # ---------------------------------------------------------------------------
@@ -742,6 +752,7 @@ def test_shipped_task_scenes_against_libm_exp_oracle(pmaf, oracle, scenes, task,
     SELECTED trajectory (the best agent's predicted path that was scored)."""
     conftest.expect_chaotic(request, "task_libm:" + task)
     oracle.set_exp_mode(0)
+    LIBM_TOL = conftest.libm_tol(oracle, 1e-5)
     sc = scenes.scene_from_record(_task_records()[task], task)
     hip, ora = make_pair(pmaf, oracle, sc)
     obs = sc["obstacles"].copy()

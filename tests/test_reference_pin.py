@@ -117,10 +117,12 @@ def test_hip_path_is_held_to_the_reference_fixtures(pmaf, oracle):
     reproduce the fixture bit for bit, else this variant is skipped). Per scenario:
       1. HIP == the oracle in its portable-exp mode, bit for bit, on every call (LockStep);
       2. both against the reference's record: same best-index sequence, set-points and the selected agent's scored
-         trajectory within 1e-5 m. The one difference left between the two sides is exp's last bit (kernels: portable_exp,
-         reference: its libm): scenarios where THAT alone is amplified past 1e-5 m -- the flow check (NOTES, round 5) found
-         the second leg of dyn1_two_goals and the lagged closed loop on static1 -- are reported, not failed: no
-         implementation with another exp can do better there, and the deviation is a property of the scene."""
+         trajectory within 1e-5 m. The one operation that is not a correctly rounded IEEE one is exp: the kernels restate
+         glibc >= 2.28's FMA exp bit for bit (round 5), so against a fixture made on such a machine (any x86-64 glibc >= 2.28
+         with FMA) the deviation printed below is 0. A fixture made with ANOTHER libm differs in exp's last bit now and
+         then; scenarios where that alone is amplified past 1e-5 m -- the flow check with the round-4 exp found the second
+         leg of dyn1_two_goals and the lagged closed loop on static1 -- are reported, not failed: a property of the scene
+         and of the two libms, which no implementation escapes."""
     sys.path.insert(0, PIN)
     import replay
     order = pmaf.load_library().pmaf_eval_order()
@@ -142,7 +144,7 @@ def test_hip_path_is_held_to_the_reference_fixtures(pmaf, oracle):
             oracle.set_exp_mode(0)
         print("%-28s HIP == oracle (portable exp) on every call; vs the reference: %d values over %d ticks, %d beyond 1e-5 m (max %.3g)%s" % (
             name, res["compared"], res["ticks"], res["mismatches"], res["max_abs_diff"],
-            "" if res["match"] else "  <- exp's last bit amplified by this scene: " + str(res["first"])))
+            ("  (exact)" if res["max_abs_diff"] == 0 else "") if res["match"] else "  <- another libm's exp, amplified by this scene: " + str(res["first"])))
         if not res["match"]:
             sensitive.append(name)
     assert len(sensitive) < len(REFS), "every scenario deviates from the reference: not an exp effect"

@@ -32,7 +32,7 @@ misc)
   # the same question at the C++ boundary (no interpreter): planTick open / closed loop, the node's five calls
   { echo "# tests/cpp/facade_tick lat: one planCallback through the C++ facade on an idle stream, static1 scene";
     for nc in "10 1500" "16 101" "64 201"; do echo "## agents, max_prediction_steps: $nc"; tests/cpp/facade_tick lat $nc 1000; done; } > $O/facade_latency.txt 2>&1
-  { echo "# per-agent / per-wave rollout durations from the device clock (round 5: kernels unchanged since round 4)";
+  { echo "# per-agent / per-wave rollout durations from the device clock (round 5 kernels: glibc-compatible exp)";
     python tools/agenttime.py C1 C2 C3; } 2>&1 | grep -v "^$\|amdgpu.ids" > $O/agent_times.txt
   bash tools/fuzz_campaign.sh > $O/fuzz_campaign.txt 2>&1
   ;;

@@ -14,6 +14,11 @@
  *
  * Conventions
  *  - all arithmetic is IEEE double; flat row-major arrays; plain pointers.
+ *    Every operation of the default kernels is the correctly rounded one the
+ *    reference's compiled code performs, in its order (pmaf_eval_order); exp()
+ *    (B/src/cf_agent.cpp:220) is glibc >= 2.28's algorithm restated
+ *    (csrc/pmaf_device.hpp: portable_exp): the bits of std::exp on x86-64
+ *    glibc hosts with FMA.
  *  - a handle batches P independent populations ("scenes": one CfManager
  *    each); every array argument carries a leading [P] dimension. The
  *    reference's single-manager use is P = 1.

@@ -1248,6 +1248,37 @@ def test_narrower_mappings_hold_at_most_two_slots_per_lane(pmaf, oracle, scenes,
     hip.close()
 
 
+def _static_lds_of(pmaf, pattern):
+    """largest `LDS Size [bytes/block]` the compiler reported for the kernels whose mangled name contains `pattern`
+    (csrc/build.sh keeps -Rpass-analysis=kernel-resource-usage in lib/resource_usage.txt)"""
+    import re
+    f = os.path.join(os.path.dirname(pmaf.LIB_PATH), "resource_usage.txt")
+    if not os.path.exists(f):
+        pytest.skip("no resource_usage.txt next to the library (built by another recipe)")
+    sizes = [int(re.search(r"LDS Size \[bytes/block\]: (\d+)", b).group(1))
+             for b in open(f).read().split("Function Name: ")[1:] if pattern in b.split("\n")[0]]
+    assert sizes, pattern
+    return max(sizes)
+
+
+@pytest.mark.parametrize("m", [65, 100, 128])
+def test_eight_one_wave_blocks_of_the_two_slot_kernel_fit_a_cu(pmaf, scenes, m):
+    """2048+ agents x 65..128 obstacles run on k_rollout_w64<2, ...>: one-wave blocks, two waves per SIMD = eight blocks
+    per CU -- if static + dynamic LDS of a block stay within 160 KB / 8. Round 5 broke exactly that once (a __shared__
+    table per instantiation of the step body + the list area sized for four slots: 21.1 KB, seven blocks per CU, a second
+    round of blocks, +45 % per launch; found by tools/regime.py's sweep, not by a test). Sizes as the build reports them
+    and as pmaf_create requests them."""
+    sc = scenes.synthetic_scene(2304, 8, m, 6, 3)
+    hip = pmaf.PmafPlanner(sc, device=0, mgr_init_pos=sc["start"])
+    cfg = hip.launch_config()
+    hip.close()
+    assert cfg["lanes_per_agent"] == 64 and cfg["waves_per_agent"] <= 1
+    static = _static_lds_of(pmaf, "k_rollout_w64ILi2E")
+    granule = 1280       # allocation granule assumed no coarser than 160 KB / 128
+    per_block = -(-(static + cfg["lds_bytes"]) // granule) * granule
+    assert 8 * per_block <= 160 * 1024, (static, cfg["lds_bytes"], per_block)
+
+
 def test_many_agents_with_200_obstacles_stay_on_the_four_slot_kernel(pmaf, oracle, scenes):
     """N x P > 1024 waves with 129..256 obstacles: the launch keeps the
     wave-per-agent mapping (k_rollout_w64<4>, several rounds of waves) instead of

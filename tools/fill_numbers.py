@@ -68,7 +68,7 @@ for name, kk_, kn in (("C2 contracted (opt-in; tolerance parity met)", "C2_contr
         rows.append((name, cf[kk_]["rollouts_per_s"], cf[kk_]["ms_per_tick"], "`%s` %.1f" % (kn, cf[kk_]["avg_kernel_us"])))
 out = []
 kt = rf.get("kernel_timing") or {}
-out.append("One MI355X, round 5 (kernels unchanged since round 4; ABI 6). `profiles/%s_bench_c2_driver_flags.json` = the driver's command "
+out.append("One MI355X, round 5 (the round-4 step with glibc's `exp`, §2: + 2 … 4 %% per launch; ABI 6). `profiles/%s_bench_c2_driver_flags.json` = the driver's command "
            "(`python bench.py --steps 20 --warmup 5`: %d blocks, %.2f s timed; HIP events on every %s-th rollout launch: %s of %s) with its "
            "sub-records; rocprofv3 `--kernel-trace --stats` of the same workloads: `profiles/%s_c{2,3,5}_trace.txt`; PMC passes "
            "`profiles/%s_c*_pmc*.txt` → `profiles/traffic.json`.\n"

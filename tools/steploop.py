@@ -3,7 +3,7 @@ instruction count by class and the number of SGPR-spill v_readlane / v_writelane
 the smallest loop of each kernel. For a lone wave every instruction is a 4-cycle issue slot (tools/slackprof.py), so
 the count is the first-order cost model of the latency shape; the group kernel is VALU-issue bound, so its VALU count is.
 
-usage: python tools/steploop.py <out_dir>          (writes r4_<tag>_steploop.txt per kernel family)
+usage: python tools/steploop.py <out_dir>          [prefix]   (writes <prefix>_<tag>_steploop.txt per kernel family; prefix defaults to r5)
 
 How a spill is recognised: SGPR spills go to lanes of VGPRs that no other instruction touches -- a VGPR that, in the
 whole kernel, is only ever the destination of v_writelane_b32 and the source of v_readlane_b32 with CONSTANT lane
@@ -17,13 +17,14 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PREFIX = sys.argv[2] if len(sys.argv) > 2 else "r5"
 CSRC = os.path.join(ROOT, "predictive-multi-agent-framework_amd", "csrc")
 BASE = ("--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -mllvm -amdgpu-sched-strategy=max-ilp "
         "-mllvm -amdgpu-atomic-optimizer-strategy=None --cuda-device-only -S").split()
 
 # (tag, source, extra flags as in csrc/build.sh, {label: mangled kernel})
 UNITS = [
-    ("c1c2_strict", "pmaf_k_w64.hip", ["-DPMAF_W64_MATH=2", "-DPMAF_W64_PART=1", "-falign-loops=32"],
+    ("c1c2_strict", "pmaf_k_w64.hip", ["-DPMAF_W64_MATH=2", "-DPMAF_W64_PART=1", "-falign-loops=32", "-DPMAF_SUM_HOIST=11"],
      {"C2 / C4 k_rollout_w64<1,2,dpp,plain>": "_Z13k_rollout_w64ILi1ELi2ELb1ELb1EEv7DevView10CostParams"}),
     ("c3_strict", "pmaf_k_w64.hip", ["-DPMAF_W64_MATH=2", "-DPMAF_W64_PART=2", "-mllvm", "-misched-prera-direction=topdown",
                                      "-mllvm", "-align-all-nofallthru-blocks=6"],
@@ -158,7 +159,7 @@ def main():
         asm = "/tmp/steploop_%s.s" % tag
         subprocess.check_call(["/opt/rocm/bin/hipcc"] + BASE + flags + [os.path.join(CSRC, src), "-o", asm], stderr=subprocess.DEVNULL)
         lines = open(asm).readlines()
-        with open(os.path.join(out_dir, "r4_%s_steploop.txt" % tag), "w") as f:
+        with open(os.path.join(out_dir, "%s_%s_steploop.txt" % (PREFIX, tag)), "w") as f:
             f.write("# tools/steploop.py -- %s %s\n# (hipcc %s)\n" % (src, " ".join(flags), " ".join(BASE)))
             for label, k in kernels.items():
                 loops, spills, nspill = analyse(lines, k)

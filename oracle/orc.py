@@ -81,6 +81,8 @@ def lib():
         L.orc_set_best.argtypes = [C.c_void_p, C.c_int, C.c_int, _dp]
         L.pmaf_portable_exp.restype = C.c_double
         L.pmaf_portable_exp.argtypes = [C.c_double]
+        L.pmaf_exp_array.restype = None
+        L.pmaf_exp_array.argtypes = [C.c_int, _dp, _dp, C.c_long]
         _LIB = L
     return _LIB
 
@@ -142,9 +144,21 @@ def get_exp_mode():
     return lib().orc_get_exp_mode()
 
 
+def _exp_array(which, x):
+    xs = np.ascontiguousarray(np.ravel(x), dtype=np.float64)
+    y = np.empty_like(xs)
+    lib().pmaf_exp_array(which, xs.ctypes.data_as(_dp), y.ctypes.data_as(_dp), xs.size)
+    return y.reshape(np.shape(x))
+
+
 def portable_exp(x):
-    L = lib()
-    return np.array([L.pmaf_portable_exp(float(v)) for v in np.ravel(x)]).reshape(np.shape(x))
+    """pmaf_portable_exp (the restatement of glibc >= 2.28's exp the kernels share), element-wise"""
+    return _exp_array(1, x)
+
+
+def libm_exp(x):
+    """the HOST libm's exp(), element-wise (np.exp is numpy's own SIMD implementation, not libm)"""
+    return _exp_array(0, x)
 
 
 def _d(a):

@@ -125,6 +125,11 @@ double pmaf_portable_exp(double x) {
 }
 #endif
 static inline double orc_exp(double x) { return g_exp_mode ? pmaf_portable_exp(x) : exp(x); }
+/* array forms for the tests that compare the restatement with the host libm (and the kernels with both) on millions of
+ * arguments: which = 1 -> pmaf_portable_exp, 0 -> the host libm's exp() */
+void pmaf_exp_array(int which, const double *x, double *y, long n) {
+  for (long i = 0; i < n; i++) y[i] = which ? pmaf_portable_exp(x[i]) : exp(x[i]);
+}
 
 static inline double dmax(double a, double b) { return (a < b) ? b : a; }
 static inline double dmin(double a, double b) { return (b < a) ? b : a; }

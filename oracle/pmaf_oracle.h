@@ -61,6 +61,8 @@ typedef struct orc_planner orc_planner;
 void orc_set_exp_mode(int mode);
 int orc_get_exp_mode(void);
 double pmaf_portable_exp(double x);
+/* y[i] = pmaf_portable_exp(x[i]) (which = 1) or the host libm's exp(x[i]) (which = 0) */
+void pmaf_exp_array(int which, const double *x, double *y, long n);
 
 /*
  * CfManager::init on a default-constructed manager

@@ -68,12 +68,11 @@ _LIBM_SAME = {}
 
 def libm_is_restated(orc):
     """True when the host's libm exp is the algorithm oracle/pmaf_oracle.c:pmaf_portable_exp (and the kernels) restate --
-    glibc >= 2.28's FMA variant, as on the build image and the GPU boxes. Decided by comparing 20 000 results."""
+    glibc >= 2.28's FMA variant, as on the build image and the GPU boxes. Decided by comparing 200 000 results."""
     if "v" not in _LIBM_SAME:
-        import math
         rng = np.random.default_rng(77)
-        x = np.concatenate([-rng.uniform(0, 3, 12000), -rng.uniform(0, 500, 6000), rng.uniform(0, 700, 2000)])
-        _LIBM_SAME["v"] = bool((orc.portable_exp(x) == np.array([math.exp(v) for v in x])).all())
+        x = np.concatenate([-rng.uniform(0, 3, 120000), -rng.uniform(0, 500, 60000), rng.uniform(0, 700, 20000)])
+        _LIBM_SAME["v"] = bool((orc.portable_exp(x) == orc.libm_exp(x)).all())
     return _LIBM_SAME["v"]
 
 

@@ -125,8 +125,8 @@ def _exp_args(seed, n):
 
 def host_libm_is_the_restated_algorithm(oracle):
     """True when the host's exp() is glibc >= 2.28's (FMA variant): decided by comparing, not by version strings"""
-    x = _exp_args(99, 4000)
-    return bool((oracle.portable_exp(x) == np.array([math.exp(v) for v in x])).all())
+    x = _exp_args(99, 40000)
+    return bool((oracle.portable_exp(x) == oracle.libm_exp(x)).all())
 
 
 def test_exp_data_is_current_and_the_same_on_both_sides():
@@ -146,10 +146,11 @@ def test_exp_data_is_current_and_the_same_on_both_sides():
 def test_portable_exp_is_the_hosts_libm_exp_bit_for_bit(oracle):
     """pmaf_portable_exp restates glibc >= 2.28's exp (what std::exp is on the reference's platforms): on a host whose
     libm is that algorithm (any x86-64 glibc >= 2.28 on a CPU with FMA -- the build image and the GPU boxes) it returns
-    libm's bits on every argument: 2e8 arguments at development time, 1.2e6 here. Elsewhere: within one ulp."""
-    x = _exp_args(3, 640000)
+    libm's bits on every argument: 2e8 arguments at development time, 1e7 here. Elsewhere: within one ulp."""
+    x = _exp_args(3, 5_000_000)
     pe = oracle.portable_exp(x)
-    ref = np.array([math.exp(v) for v in x])
+    ref = oracle.libm_exp(x)
+    assert all(math.exp(v) == r for v, r in zip(x[:2000], ref[:2000]))      # (libm_exp is the libm Python calls too)
     assert (np.abs(pe - ref) <= np.spacing(np.maximum(ref, 1e-300))).all()
     assert oracle.portable_exp([0.0])[0] == 1.0 and math.isnan(oracle.portable_exp([float("nan")])[0])
     assert oracle.portable_exp([710.0])[0] == math.inf and oracle.portable_exp([-1e9])[0] == math.exp(-500.0)
@@ -158,7 +159,7 @@ def test_portable_exp_is_the_hosts_libm_exp_bit_for_bit(oracle):
     assert (pe == ref).all(), "%d of %d arguments differ from libm" % (int((pe != ref).sum()), x.size)
     # what the planner forms: 1 - exp(x); below the clamp it is 1.0 on both sides
     xs = -np.logspace(1.5, 9, 200)
-    assert (1.0 - oracle.portable_exp(xs) == np.array([1.0 - math.exp(v) for v in xs])).all()
+    assert (1.0 - oracle.portable_exp(xs) == 1.0 - oracle.libm_exp(xs)).all()
 
 
 def test_libm_and_portable_modes_of_the_oracle_are_one_function_here(oracle, scenes):

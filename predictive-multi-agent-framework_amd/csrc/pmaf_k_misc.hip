@@ -7,6 +7,7 @@
 //   k_score         re-scores stored paths (before the first rollout / other workspace gains).
 //   k_link_force    CfAgent::bodyForce (B/src/cf_agent.cpp:229-234).
 //   k_winner        packs winner records for sharded runs.
+#include <mutex>
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 
@@ -966,6 +967,18 @@ void pmaf_k_launch_eval_obstacle_distance(const DevView &D, const double *obs, d
 
 hipError_t pmaf_k_set_lds_limits(size_t lds_manager, size_t lds_rollout) {
   hipError_t e = hipSuccess;
+  // the attribute belongs to the kernel, not to a handle: a second handle with a smaller (still > 64 KB) table must not
+  // lower the limit under the first one's launches -- the largest request of the process stands (per device: the
+  // attribute is set on the current device's copy of the function; a handle re-raises it on its own device)
+  static size_t max_manager[16] = {0}, max_rollout[16] = {0};
+  static std::mutex mtx;                      // (handles may be created from different threads)
+  std::lock_guard<std::mutex> lock(mtx);
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev >= 0 && dev < 16) {
+    if (lds_manager < max_manager[dev]) lds_manager = max_manager[dev]; else max_manager[dev] = lds_manager;
+    if (lds_rollout < max_rollout[dev]) lds_rollout = max_rollout[dev]; else max_rollout[dev] = lds_rollout;
+  }
   if (lds_manager > 64 * 1024)
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_manager), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds_manager);

@@ -1278,6 +1278,26 @@ def test_eight_one_wave_blocks_of_the_two_slot_kernel_fit_a_cu(pmaf, scenes, m):
     assert 8 * per_block <= 160 * 1024, (static, cfg["lds_bytes"], per_block)
 
 
+def test_two_handles_with_obstacle_tables_beyond_64_kb(pmaf, oracle, scenes):
+    """more than 64 KB of dynamic LDS needs a per-KERNEL opt-in (hipFuncAttributeMaxDynamicSharedMemorySize): a second
+    handle with a smaller table (still > 64 KB) must not lower the limit under the first one's launches -- the largest
+    request of the process stands (csrc/pmaf_k_misc.hip: pmaf_k_set_lds_limits). 1500 and 1000 obstacles, the larger
+    handle created first, ticked alternately. (ROCm 7.2 does not enforce the attribute -- the per-handle setter passed
+    this test as well; the rule is kept for runtimes that do.)"""
+    scs = [scenes.synthetic_scene(5, 10, 1500, 6, 11), scenes.synthetic_scene(5, 10, 1000, 6, 12)]
+    pairs = [make_pair(pmaf, oracle, sc) for sc in scs]
+    assert [p[0].launch_config()["lds_bytes"] > 64 * 1024 for p in pairs] == [True, True]
+    assert pairs[0][0].launch_config()["lds_bytes"] > pairs[1][0].launch_config()["lds_bytes"]
+    for t in range(2):
+        for (hip, ora), sc in zip(pairs, scs):
+            assert hip.tick(sc["obstacles"], sc["dt"], sc["cost_gains"], sc["ws_limits"]) == \
+                ora.tick(sc["obstacles"], sc["dt"], sc["cost_gains"], sc["ws_limits"])
+    for hip, ora in pairs:
+        hip.stop()
+        assert_state_equal(hip, ora)
+        hip.close()
+
+
 def test_many_agents_with_200_obstacles_stay_on_the_four_slot_kernel(pmaf, oracle, scenes):
     """N x P > 1024 waves with 129..256 obstacles: the launch keeps the
     wave-per-agent mapping (k_rollout_w64<4>, several rounds of waves) instead of

@@ -153,7 +153,7 @@ int main(int argc, char **argv) {
     // what the numbers depend on besides the sources: Eigen's version and whether its packet path is compiled in (the
     // 3-vector dot-product association, include/pmaf.h pmaf_eval_order), the compiler, the libm behind std::exp
     fprintf(f, "{\"format\": \"pmaf-reference-pin-1\", \"scenario\": \"%s\",\n \"meta\": {\"eigen\": \"%d.%d.%d\", \"eigen_vectorize\": %s, "
-               "\"eigen_dont_vectorize\": %s, \"compiler\": \"%s\", \"optimize\": %s, \"fma_contraction_possible\": %s, \"glibc\": \"%s\"},\n",
+               "\"eigen_dont_vectorize\": %s, \"compiler\": \"%s\", \"optimize\": %s, \"fma_contraction_possible\": %s, \"glibc\": \"%s\", \"cpu_fma\": %s},\n",
             s.name.c_str(), EIGEN_WORLD_VERSION, EIGEN_MAJOR_VERSION, EIGEN_MINOR_VERSION,
 #ifdef EIGEN_VECTORIZE
             "true",
@@ -176,7 +176,15 @@ int main(int argc, char **argv) {
 #else
             "false",
 #endif
-            gnu_get_libc_version());
+            gnu_get_libc_version(),
+            // glibc >= 2.28 picks its exp variant by the CPU at run time (ifunc), not by this file's compile flags: with FMA
+            // it is the algorithm the kernels and the oracle's portable mode restate (tools/gen_exp_table.py)
+#if defined(__x86_64__)
+            __builtin_cpu_supports("fma") ? "true" : "false"
+#else
+            "null"
+#endif
+            );
     std::vector<Obstacle> obstacles = s.obstacles;
     const Eigen::Matrix<double, 6, 1> ws = (Eigen::Matrix<double, 6, 1>() << s.ws[0], s.ws[1], s.ws[2], s.ws[3], s.ws[4], s.ws[5]).finished();
     const int n = s.n_agents;

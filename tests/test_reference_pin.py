@@ -69,8 +69,8 @@ def test_oracle_is_held_to_the_reference_fixtures():
             assert r.returncode == 0, r.stderr[-3000:]
             res[variant] = json.loads(r.stdout.strip().splitlines()[-1])
         ok = [v for v in res if res[v]["match"]]
-        print("%-28s Eigen %s vectorize=%s | left-assoc: %s  right-assoc: %s" % (
-            name, meta["eigen"], meta["eigen_vectorize"],
+        print("%-28s Eigen %s vectorize=%s glibc %s cpu_fma=%s | left-assoc: %s  right-assoc: %s" % (
+            name, meta["eigen"], meta["eigen_vectorize"], meta.get("glibc"), meta.get("cpu_fma"),
             "MATCH" if res[""]["match"] else "%d of %d differ (max %.3g, first %s)" % (res[""]["mismatches"], res[""]["compared"], res[""]["max_abs_diff"], res[""]["first"]),
             "MATCH" if res["rassoc"]["match"] else "%d of %d differ (max %.3g)" % (res["rassoc"]["mismatches"], res["rassoc"]["compared"], res["rassoc"]["max_abs_diff"])))
         assert ok, "%s: the oracle reproduces the reference under NEITHER association: %s" % (name, res)
@@ -145,6 +145,10 @@ def test_hip_path_is_held_to_the_reference_fixtures(pmaf, oracle):
         print("%-28s HIP == oracle (portable exp) on every call; vs the reference: %d values over %d ticks, %d beyond 1e-5 m (max %.3g)%s" % (
             name, res["compared"], res["ticks"], res["mismatches"], res["max_abs_diff"],
             ("  (exact)" if res["max_abs_diff"] == 0 else "") if res["match"] else "  <- another libm's exp, amplified by this scene: " + str(res["first"])))
+        if conftest.libm_is_restated(oracle):
+            # the oracle with THIS host's libm reproduced the fixture bit for bit (above), this host's libm is the algorithm
+            # the kernels restate, and HIP == the oracle call by call: nothing is left to tolerate
+            assert res["match"] and res["max_abs_diff"] == 0, (name, res["first"])
         if not res["match"]:
             sensitive.append(name)
     assert len(sensitive) < len(REFS), "every scenario deviates from the reference: not an exp effect"

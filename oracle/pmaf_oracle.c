@@ -95,7 +95,8 @@ double pmaf_portable_exp(double x) { return exp(x); }
  * on: 2e8 arguments without a mismatch on the build image, glibc 2.35). Error 0.511 ulp.
  * Range: x is clamped to >= -500 -- below -512 glibc leaves this path for its subnormal-safe one (an unfused last step),
  * and the only caller forms 1 - exp(x), which is 1.0 for every exp(x) < 2^-54 (x < -37.4): the clamp changes no result
- * of the planner and keeps ONE straight-line sequence on the device; x above 709.78 -> +inf like exp(). */
+ * of the planner and keeps ONE straight-line sequence on the device. x >= 512: glibc's specialcase() for large positive
+ * arguments, restated too (the exponent of the scale would overflow); x above 709.78 -> +inf like exp(). */
 double pmaf_portable_exp(double x) {
   double kd, r, tail, scale;
   uint64_t ki, sbits, u;
@@ -119,6 +120,15 @@ double pmaf_portable_exp(double x) {
     const double c = fma(a, r2, tr);
     const double r4 = r2 * r2;
     const double tmp = fma(r4, b, c);
+    if (xs >= 512.0) {
+      /* glibc's specialcase(), k > 0 branch: up here 2^(k/N)'s exponent field may overflow (k / N reaches 1024 just
+       * below the threshold: `sbits` would be +inf's pattern and fma(inf, tmp < 0, inf) a NaN -- ADVICE r5), so the scale
+       * is formed 2^-1009 lower and the result multiplied back up; above the threshold the product overflows to +inf by
+       * itself. The planner never gets here (its arguments are <= 0). */
+      sbits -= (uint64_t)1009 << 52;
+      memcpy(&scale, &sbits, 8);
+      return 0x1p1009 * fma(scale, tmp, scale);
+    }
     memcpy(&scale, &sbits, 8);
     return fma(scale, tmp, scale);
   }

@@ -401,7 +401,7 @@ __device__ __forceinline__ double portable_exp_k(double x, KT K) {
   K.tie(xs0);
   x = xs0;
   const double xlo = __builtin_fmax(x, -500.0);                          // v_max_f64 (a NaN is replaced: see below)
-  const double xs = NONPOS ? xlo : __builtin_fmin(xlo, 0x1.62e42fefa39efp+9);   // exp's overflow threshold: the scale stays finite up to it
+  const double xs = NONPOS ? xlo : __builtin_fmin(xlo, 0x1.62e42fefa39efp+9);   // exp's overflow threshold (the scale's exponent is handled below: x >= 512)
   double kd = __builtin_fma(xs, K.get(0), K.get(1));
   const unsigned long long ki = (unsigned long long)__double_as_longlong(kd);
   kd = kd - K.get(1);
@@ -419,11 +419,16 @@ __device__ __forceinline__ double portable_exp_k(double x, KT K) {
   const double c = __builtin_fma(a, r2, tr);
   const double r4 = r2 * r2;
   const double tmp = __builtin_fma(r4, b, c);
-  const double scale = __longlong_as_double((long long)sbits);
-  const double res = __builtin_fma(scale, tmp, scale);
-  if (NONPOS) return res;
-  // above exp's overflow threshold: +inf (the clamp kept the scale finite); NaN in, NaN out (the clamps return their
-  // other operand for a NaN)
+  if (NONPOS) return __builtin_fma(__longlong_as_double((long long)sbits), tmp, __longlong_as_double((long long)sbits));
+  // x >= 512: glibc's specialcase(), k > 0 branch -- 2^(k/N)'s exponent field would overflow just below the threshold
+  // (k / N = 1024: `sbits` = +inf's pattern, fma(inf, tmp < 0, inf) = NaN), so the scale is formed 2^-1009 lower
+  // and the result multiplied back up; same operations as oracle/pmaf_oracle.c:pmaf_portable_exp. Selects, no branch.
+  const bool top = xs >= 512.0;
+  const unsigned long long sb2 = top ? sbits - (1009ull << 52) : sbits;
+  const double scale = __longlong_as_double((long long)sb2);
+  const double res0 = __builtin_fma(scale, tmp, scale);
+  const double res = top ? 0x1p1009 * res0 : res0;
+  // above exp's overflow threshold: +inf; NaN in, NaN out (the clamps return their other operand for a NaN)
   const double big = (x > 0x1.62e42fefa39efp+9) ? __builtin_inf() : res;
   return (x != x) ? x : big;
 }

@@ -480,6 +480,15 @@ static const double *stage_live_obstacles_zero_copy(pmaf_planner *h, const doubl
   return h->d_zc;
 }
 
+// Staging marks the caller's list as resident BEFORE a manager kernel has read it. Whatever fails between the staging and
+// that kernel's published result (an upload that throws, a launch error, a mailbox time-out): the list may not have reached
+// D.obs_live, so it must not count as resident -- a retry with the same list has to hand it over again. Armed on
+// construction; the caller disarms it once the mailbox result of the launch that carried the list is in.
+struct ResidentGuard {
+  pmaf_planner *h; bool armed = true;
+  ~ResidentGuard() { if (armed) { h->live_resident.clear(); h->last_live.clear(); h->closest_dirty = true; } }
+};
+
 // a pending closed-loop position into D.real_pos the slow way (stream sync + copy), for the consumers of D.real_pos
 // that are not manager launches (winner-record packing, the state blob)
 static void flush_real_position(pmaf_planner *h) {
@@ -1177,6 +1186,11 @@ int pmaf_move_real(pmaf_planner *h, const double *obstacles, double dt, int32_t 
     // the call's small inputs travel like pmaf_tick's: the obstacle list through the mapped pinned buffer (not at all when
     // it is the resident one), the agent indices by value in the kernel arguments (<= 4 populations), the result through
     // the mailbox -- no copy command and no stream synchronisation (round 5; the node's five calls 106 -> ~45 us)
+    // steps == 0: no manager launch reads the list, so it is not staged either (staging marks it resident; a later call
+    // with the same list would then hand nothing over and plan on the old obstacles). The reference's moveRealEEAgent
+    // passes the list to cfPlanner inside its steps loop only (B/src/cf_manager.cpp:257-263): zero steps leave no trace.
+    if (steps == 0) return;
+    ResidentGuard resident_guard{h};
     const double *live = stage_live_obstacles_zero_copy(h, obstacles);
     const bool inl = h->D.P <= PMAF_RP_INLINE;
     if (!inl) h->upload(h->d_agent_id, agent_id, h->D.P);
@@ -1189,8 +1203,9 @@ int pmaf_move_real(pmaf_planner *h, const double *obstacles, double dt, int32_t 
       A.live_src = (s == 0) ? live : nullptr;
       A.out = h->d_out;
       A.seq = (h->call_seq -= 1.0);
-      try { launch_manager(h, A); wait_mailbox(h, A.seq, "pmaf_move_real"); }
-      catch (...) { h->live_resident.clear(); h->last_live.clear(); h->closest_dirty = true; throw; }
+      launch_manager(h, A);
+      wait_mailbox(h, A.seq, "pmaf_move_real");
+      resident_guard.armed = false;   // the first launch has read the list (later ones use D.obs_live)
       refresh_real_cache(h);
       append_real_path(h);
     }
@@ -1208,6 +1223,7 @@ int pmaf_reset_agents(pmaf_planner *h, const double *pos, const double *vel, con
     // paths' first points); everything else is ordered by the stream
     for (auto &sl : h->x.slot)
       if (sl.pack_pending) { HIP_CHECK(hipEventSynchronize(sl.ev_pack)); sl.pack_pending = false; }
+    ResidentGuard resident_guard{h};
     const double *live = stage_live_obstacles_zero_copy(h, obstacles);
     ManagerArgs A{};
     A.do_reset = 1;
@@ -1225,10 +1241,13 @@ int pmaf_reset_agents(pmaf_planner *h, const double *pos, const double *vel, con
     A.live_src = live;
     A.out = h->d_out;
     A.seq = (h->call_seq -= 1.0);
-    // (the mailbox is published once the kernel has read its inputs -- the staging buffer is free again -- and before
-    // its reset stores, which the stream orders in front of whatever is launched next)
-    try { launch_manager(h, A); wait_mailbox(h, A.seq, "pmaf_reset_agents"); }
-    catch (...) { h->live_resident.clear(); h->last_live.clear(); h->closest_dirty = true; throw; }
+    // The mailbox is published once the kernel has read EVERY input of this call (the pinned obstacle list, d_reset_in:
+    // both are loaded in front of the publication in k_manager) -- the staging buffers are free again -- and BEFORE its
+    // reset stores (obs_start, known_start, the agents' state). Invariant the host relies on for those: whatever reads
+    // or overwrites them next is either a launch on h->stream (ordered behind this kernel) or a getter that calls sync().
+    launch_manager(h, A);
+    wait_mailbox(h, A.seq, "pmaf_reset_agents");
+    resident_guard.armed = false;
     refresh_real_cache(h);
     h->scores_valid = false;
     h->rollout_pending = true;
@@ -1245,10 +1264,7 @@ int pmaf_tick(pmaf_planner *h, const double *obstacles, double dt, const double 
     require_drained(h, "pmaf_tick");
     // whatever fails between here and the manager kernel's result: the list handed over with this call may not have
     // reached D.obs_live, so it must not count as resident (a retry with the same list has to hand it over again)
-    struct ResidentGuard {
-      pmaf_planner *h; bool armed = true;
-      ~ResidentGuard() { if (armed) { h->live_resident.clear(); h->last_live.clear(); h->closest_dirty = true; } }
-    } resident_guard{h};
+    ResidentGuard resident_guard{h};
     set_cost_params(h, cost_gains, ws);
     ensure_scores(h);
     ManagerArgs A{};

@@ -537,6 +537,15 @@ __global__ __launch_bounds__(64) void k_manager(DevView D, CostParams CP, Manage
     }
   }
 
+  // pmaf_reset_agents with more than PMAF_RP_INLINE populations: position / velocity come from a device buffer. Loaded
+  // HERE, in front of the publication: the host may reuse the buffer as soon as the mailbox is out (with the publication in
+  // front of this load only the stream order of the next upload protected it).
+  V3 reset_sp = mk(0.0, 0.0, 0.0), reset_sv = mk(0.0, 0.0, 0.0);
+  if (A.do_reset && !A.reset_from_real && !A.reset_in_inline) {
+    const double *in = A.reset_in + pop * 6;
+    reset_sp = mk(in[0], in[1], in[2]);
+    reset_sv = mk(in[3], in[4], in[5]);
+  }
   // host-visible outputs first: the caller waits for these only
   if (A.out) {
     double *o = A.out + pop * PMAF_MBOX;
@@ -591,11 +600,7 @@ __global__ __launch_bounds__(64) void k_manager(DevView D, CostParams CP, Manage
     else if (A.reset_in_inline) {
       sp = mk(A.reset_in_val[pop * 6], A.reset_in_val[pop * 6 + 1], A.reset_in_val[pop * 6 + 2]);
       sv = mk(A.reset_in_val[pop * 6 + 3], A.reset_in_val[pop * 6 + 4], A.reset_in_val[pop * 6 + 5]);
-    } else {
-      const double *in = A.reset_in + pop * 6;
-      sp = mk(in[0], in[1], in[2]);
-      sv = mk(in[3], in[4], in[5]);
-    }
+    } else { sp = reset_sp; sv = reset_sv; }
     // setVelocity clamp, B/src/cf_agent.cpp:54-61
     double vn = norm(sv);
     if (vn > C.vel_max) sv = (C.vel_max / vn) * sv;

@@ -389,3 +389,41 @@ def test_node_prediction_freq_multiple_task_matches_oracle(pmaf, oracle, scenes,
     _compare(data, notes, rows, traj)
     # (that the multiple really is in the rollouts: test_prediction_freq_multiple compares the predicted paths)
     assert len(data) == 400
+
+
+@pytest.mark.parametrize("n_pops", [1, 6])
+def test_move_real_with_zero_steps_does_not_mark_its_list_resident(pmaf, oracle, scenes, n_pops):
+    """`pmaf_move_real(list, dt, steps = 0, ...)` staged the list -- which marks it resident -- although no
+    manager launch ever read it; the next call with the SAME list then handed nothing over and planned on the old obstacles.
+    Zero steps leave no trace in the reference either (the list is an argument of cfPlanner inside the steps loop,
+    B/src/cf_manager.cpp:257-263). Six populations: the path where agent indices travel through a device buffer."""
+    scs = [scenes.config_scene("C2", scene_id=i, dynamic=True) for i in range(n_pops)]
+    sc = scs[0]
+    starts = np.stack([s["start"] for s in scs])
+    arg = scs if n_pops > 1 else sc
+    hip = pmaf.PmafPlanner(arg, device=0, mgr_init_pos=starts if n_pops > 1 else sc["start"])
+    oras = [oracle.OraclePlanner(s, mgr_init_pos=s["start"]) for s in scs]
+    hip.set_initial_position(starts if n_pops > 1 else sc["start"])
+    for o, s in zip(oras, scs):
+        o.set_initial_position(s["start"])
+    obs = np.stack([s["obstacles"] for s in scs])
+    for t in range(3):
+        bh = np.atleast_1d(hip.tick(obs, sc["dt"], sc["cost_gains"], sc["ws_limits"]))
+        bo = [o.tick(obs[p], sc["dt"], sc["cost_gains"], sc["ws_limits"]) for p, o in enumerate(oras)]
+        assert list(bh) == bo
+    moved = np.stack([scenes.advance_live_obstacles(scenes.advance_live_obstacles(o)) for o in obs])
+    hip.stop()
+    hip.move_real(moved, sc["dt"], 0, bh)            # nothing happens, nothing is remembered
+    for t in range(3):                               # ... so this tick hands `moved` over and plans on it
+        bh = np.atleast_1d(hip.tick(moved, sc["dt"], sc["cost_gains"], sc["ws_limits"]))
+        bo = [o.tick(moved[p], sc["dt"], sc["cost_gains"], sc["ws_limits"]) for p, o in enumerate(oras)]
+        assert list(bh) == bo
+        for p, o in enumerate(oras):
+            _same(np.asarray(hip.real_state()[0]).reshape(n_pops, 3)[p], o.real_state()[0])
+    hip.stop()
+    ph, nh = hip.paths()
+    for p, o in enumerate(oras):
+        po, no = o.paths()
+        _same(np.asarray(nh).reshape(n_pops, -1)[p], no)
+        _same(np.asarray(ph).reshape((n_pops,) + np.asarray(po).shape)[p], po)
+    hip.close()

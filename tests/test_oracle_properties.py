@@ -6,6 +6,8 @@ import os
 import numpy as np
 import pytest
 
+EXP_OVERFLOW = float.fromhex("0x1.62e42fefa39efp+9")   # exp()'s overflow threshold, 709.782712893384
+
 from conftest import drive
 
 
@@ -120,7 +122,11 @@ def _exp_args(seed, n):
     rng = np.random.default_rng(seed)
     return np.concatenate([-rng.uniform(0, 3, n), -rng.uniform(0, 40, n // 2), -rng.uniform(0, 500, n // 4), rng.uniform(0, 709.7, n // 8),
                            -np.ldexp(rng.uniform(0.5, 1, n // 8), -rng.integers(0, 70, n // 8)),
-                           [0.0, -0.0, -1e-10, 1e-10, 0.3465735, -0.3465736, -37.4, -500.0]])
+                           # the top of the range: from 512 up glibc's specialcase() forms the scale 2^-1009 lower (the exponent
+                           # field of 2^(k/128) overflows in (709.7800, 709.7827]: ADVICE r5, a NaN before round 6)
+                           rng.uniform(511.0, 513.0, n // 64), rng.uniform(709.7, 709.79, n // 32),
+                           [0.0, -0.0, -1e-10, 1e-10, 0.3465735, -0.3465736, -37.4, -500.0, 512.0, 709.781, 709.7827,
+                            EXP_OVERFLOW, np.nextafter(EXP_OVERFLOW, 1e9), 709.79, 1023.0, 1024.0, 1e300]])
 
 
 def host_libm_is_the_restated_algorithm(oracle):
@@ -151,7 +157,9 @@ def test_portable_exp_is_the_hosts_libm_exp_bit_for_bit(oracle):
     pe = oracle.portable_exp(x)
     ref = oracle.libm_exp(x)
     assert all(math.exp(v) == r for v, r in zip(x[:2000], ref[:2000]))      # (libm_exp is the libm Python calls too)
-    assert (np.abs(pe - ref) <= np.spacing(np.maximum(ref, 1e-300))).all()
+    fin = np.isfinite(ref)
+    assert (np.isfinite(pe) == fin).all() and (pe[~fin] == ref[~fin]).all()     # +inf above the overflow threshold on both sides
+    assert (np.abs(pe[fin] - ref[fin]) <= np.spacing(np.maximum(ref[fin], 1e-300))).all()
     assert oracle.portable_exp([0.0])[0] == 1.0 and math.isnan(oracle.portable_exp([float("nan")])[0])
     assert oracle.portable_exp([710.0])[0] == math.inf and oracle.portable_exp([-1e9])[0] == math.exp(-500.0)
     if not host_libm_is_the_restated_algorithm(oracle):

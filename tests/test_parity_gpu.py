@@ -19,6 +19,8 @@ import os
 import numpy as np
 import pytest
 
+EXP_OVERFLOW = float.fromhex("0x1.62e42fefa39efp+9")   # exp()'s overflow threshold, 709.782712893384
+
 import conftest
 from conftest import drive
 
@@ -371,7 +373,10 @@ def test_device_arithmetic_is_ieee_exact(pmaf, oracle):
     assert (pmaf.debug_math(3, a, b) == a * b).all()
     assert (pmaf.debug_math(4, a, b) == a + b).all()
     x = np.concatenate([-rng.uniform(0.0, 3.0, 4_000_000), -rng.uniform(0.0, 600.0, 1_000_000), rng.uniform(0.0, 720.0, 500_000),
-                        -np.ldexp(rng.uniform(0.5, 1.0, 500_000), -rng.integers(0, 70, 500_000)), [0.0, -0.0, -37.4, -500.0, -1e9, 709.7, 710.0]])
+                        -np.ldexp(rng.uniform(0.5, 1.0, 500_000), -rng.integers(0, 70, 500_000)), [0.0, -0.0, -37.4, -500.0, -1e9, 709.7, 710.0],
+                        # the top of the range (glibc's specialcase, x >= 512; (709.7800, 709.7827] was a NaN before round 6)
+                        rng.uniform(511.0, 513.0, 50_000), rng.uniform(709.7, 709.79, 200_000),
+                        [512.0, 709.781, 709.7827, EXP_OVERFLOW, np.nextafter(EXP_OVERFLOW, 1e9), 1023.0, 1024.0, 1e300, np.inf]])
     dev = pmaf.debug_math(2, x)
     assert (dev == oracle.portable_exp(x)).all()
     # ... and the kernels' exp IS the host libm's exp (glibc >= 2.28, FMA variant: the GPU boxes' image) wherever the

@@ -47,7 +47,8 @@
 extern "C" {
 #endif
 
-#define PMAF_ABI_VERSION 6   /* 6: pmaf_eval_order (build-time evaluation-order policy); pmaf_set_real_position no longer waits
+#define PMAF_ABI_VERSION 7   /* 7: pmaf_pick_lanes_per_agent / pmaf_estimate_rollout_us (the mapping rule as a pure function);
+                              * pmaf_move_real with steps = 0 leaves no trace; 6: pmaf_eval_order (build-time evaluation-order policy); pmaf_set_real_position no longer waits
                               * for the running rollout; 5: PMAF_FLAG_CONTRACTED, pmaf_get_health, the winner path in pinned
                               * memory, the tick's time limit */
 
@@ -509,6 +510,19 @@ int pmaf_get_launch_config(pmaf_planner *h, int32_t *lanes_per_agent,
  * every wave of the launch gets a SIMD of its own; PMAF_MW=0 in the environment keeps the one-wave kernels, PMAF_MW=3|4
  * asks for more waves than the obstacle count needs (tests, timing). Results are bit-identical either way. */
 int pmaf_get_waves_per_agent(pmaf_planner *h, int32_t *waves_per_agent, int32_t *obstacles_per_wave);
+/* The mapping rule as a pure function (no handle, no device): the lanes-per-agent mapping pmaf_create chooses for
+ * n_populations x n_agents agents and n_field_obstacles circular-field obstacles (M, without the trailing repulsive one)
+ * when pmaf_params.lanes_per_agent is 0, on a device with n_simds SIMDs (0 = MI355X's 1024). The reference has no
+ * counterpart (it runs one std::thread per agent, B/src/cf_manager.cpp:118-123); this is the scheduling decision that
+ * replaces it. 0 on invalid arguments. The rule is a table of measured launch times (csrc/pmaf_lpa_model.hpp,
+ * profiles/r6_lpa_grid.txt); pmaf_estimate_rollout_us returns its estimate of the rollout kernel's duration in
+ * microseconds for one mapping (lanes_per_agent in {64, 32, 16, 8}; horizon = steps per rollout) or a negative value
+ * when the mapping is not offered for that obstacle count (a narrower mapping than the wave per agent holds at most two
+ * obstacles per lane). Estimates, not promises: capacity planning (how many populations fit a control period) and the
+ * tests that hold the rule to the measured grid (tests/test_lpa_model.py). */
+int32_t pmaf_pick_lanes_per_agent(int32_t n_agents, int32_t n_populations, int32_t n_field_obstacles, int32_t n_simds);
+double pmaf_estimate_rollout_us(int32_t lanes_per_agent, int32_t n_agents, int32_t n_populations, int32_t n_field_obstacles,
+                                int32_t horizon, int32_t n_simds);
 
 /* Measurement tooling (tools/slackprof): from now on the handle's rollout launches run `kernel_name` out of the code
  * object file at `code_object_path` (same arguments, grid and LDS as the built-in wave-per-agent kernel: the product

@@ -6,7 +6,9 @@ order the reference's constructors call makeRandomVector(): agents 5 .. N-1, one
 normalises them itself (B/include/bimanual_planning_ros/cf_agent.h:338-342), and tests/test_reference_pin.py
 normalises the same triples in the association it is testing.
 
-TEST INFRASTRUCTURE. usage: python oracle/pin/make_scenarios.py"""
+TEST INFRASTRUCTURE. usage: python oracle/pin/make_scenarios.py [--out DIR]
+(default DIR: oracle/pin/scenarios, the committed files; tests/test_reference_pin.py writes into a temporary directory and
+compares -- a test run never rewrites tracked files)"""
 import json
 import os
 import sys
@@ -51,6 +53,8 @@ def emit(S, name, sc, goals, seed, dynamic=False, lag=None, mult=1, dump_paths=0
 
 
 if __name__ == "__main__":
+    if "--out" in sys.argv:
+        OUT = os.path.abspath(sys.argv[sys.argv.index("--out") + 1])
     S = graft.load_package().scenes
     os.makedirs(OUT, exist_ok=True)
     tasks = json.load(open(os.path.join(ROOT, "tests", "golden", "task_scenes.json")))

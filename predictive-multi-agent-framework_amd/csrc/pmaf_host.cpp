@@ -17,6 +17,7 @@
 #include "../../include/pmaf.h"
 #include "pmaf_comm.hpp"
 #include "pmaf_types.hpp"
+#include "pmaf_lpa_model.hpp"
 
 using namespace pmaf;
 
@@ -297,33 +298,16 @@ static void refresh_plain_step(pmaf_planner *h, const double *k_attr) {
   h->plain_step = plain;
 }
 
-static int pick_lpa(int N, int P, int M) {
-  // Heuristic: fill the 1024 SIMDs of the chip with waves, but never use more
-  // lanes per agent than there are field obstacles to share.
-  // Measured on C2-shaped populations (tools/lpasweep.py, kernel us for 1024 / 2048 / 4096 / 8192 agents):
-  //   wave per agent 360 / 549 / 1024 / -,  32 lanes 512 / 492 / 697 / 1348,  16 lanes 672 / 712 / 684 / 1017.
-  // The wave-per-agent kernel is the fastest while every wave has a SIMD to itself (<= 1024 waves); a second
-  // wave per SIMD costs it more than the group kernels' narrower mapping does, and those run best at 2 per SIMD.
-  // Re-measured at the end of round 3 (C5-shaped populations, kernel us for 1024 / 2048 / 4096 / 8192 agents):
-  //   wave per agent 239 / 395 / 722 / 1336,  32 lanes 416 / 417 / 519 / 1019,  16 lanes 532 / 570 / 561 / 739:
-  // with the shorter step the wave-per-agent kernel also wins at TWO waves per SIMD (2048 agents), so every mapping
-  // now runs up to 2048 waves.
-  int lpa = 64;
-  while (lpa > 1) {
-    long waves = ((long)N * lpa + 63) / 64 * P;
-    if (waves > 2048) lpa /= 2; else break;
-  }
-  // Never more than TWO obstacle slots per lane in a narrower mapping (round 5, tools/lpasweep.py, profiles/r5_lpa_rule.txt;
-  // kernel us per launch, 200 steps, old choice -> the mapping with <= 2 slots):
-  //   128 obstacles: 2304 agents 1674 -> 876, 4096 agents 1882 -> 1149, 8192 agents 4143 -> 2154 (32 / 16 lanes -> wave per agent)
-  //   70 obstacles: 4096 agents 1509 -> 1105;  64 obstacles, 8192 agents 1606 -> 1301 (16 -> 32 lanes);  40 obstacles,
-  //   12288 agents 2519 -> 1862 (8 -> 32);  32 obstacles, 16384 agents 1744 -> 1317 (8 -> 16);  20 obstacles: 1509 -> 1204
-  // -- the group kernels' three- and four-slot bodies (and the generic kernel beyond them) cost more per agent-step than
-  // another round of waves of a mapping that holds the obstacles in <= 2 slots; with <= 2 slots the wave-count rule above
-  // stands (64 obstacles x 4096 agents: 32 lanes 688 against 1089 us for the wave per agent; C5: 16 lanes).
-  // (This subsumes rounds 2-4's rule for 129..256 obstacles: those always take the four-slot wave-per-agent kernel, 2.7-3.7 x
-  // faster than the generic LDS-table kernel a narrower mapping would fall to.)
-  while (lpa < 64 && (M + lpa - 1) / lpa > 2) lpa *= 2;
+static int pick_lpa(int N, int P, int M, int n_simds) {
+  // The mapping with the smallest estimated kernel time (pmaf_lpa_model.hpp: a table of measured launch times per
+  // mapping, obstacle slots per lane and waves per SIMD; profiles/r6_lpa_grid.txt). History of the rule it replaces:
+  // rounds 1-4 narrowed the mapping until the launch had <= 2048 waves (the wave per agent wins while every wave has a SIMD
+  // to itself and still at two per SIMD; the group kernels run best at two per SIMD); round 5 added "never more than two
+  // obstacle slots per lane in a narrower mapping" (profiles/r5_lpa_rule.txt: the three- / four-slot group bodies and the
+  // generic kernel cost more than another round of waves: 128 obstacles x 4096 agents 1882 -> 1149 us); round 6 measured
+  // the whole plane and found that rule 20 ... 31 % off in three regions (header of pmaf_lpa_model.hpp). BASELINE's
+  // configurations keep their mappings: C1-C4 the wave per agent, C5 x 8 on one GPU 16 lanes, x 4 32 lanes, x 2 / x 1 64.
+  int lpa = pmaf_lpa::pick(N, P, M, n_simds);
   // known-flag bitmask holds 64 tiles per lane
   while ((M + lpa - 1) / lpa > 64 && lpa < 64) lpa *= 2;
   return lpa;
@@ -852,7 +836,12 @@ int pmaf_create(const pmaf_params *prm, pmaf_planner **out) {
     h->math = (prm->flags & PMAF_FLAG_CONTRACTED) ? MATH_FMA : (prm->flags & PMAF_FLAG_FAST_MATH) ? MATH_FAST
               : (prm->flags & PMAF_FLAG_IEEE_SEQUENCES) ? MATH_IEEE : MATH_XACT;
     h->blocking_wait = (prm->flags & PMAF_FLAG_BLOCKING_WAIT) != 0;
-    h->lpa = lp ? lp : pick_lpa(N, P, M);
+    {
+      int cus = 0;
+      HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device));
+      D.n_simds = 4 * (cus > 0 ? cus : 256);
+    }
+    h->lpa = lp ? lp : pick_lpa(N, P, M, D.n_simds);
     { const char *fg = getenv("PMAF_FORCE_GENERIC"); h->force_generic = fg && fg[0] == '1'; }
     { const char *ab = getenv("PMAF_ABLATE"); D.ablate = ab ? atoi(ab) : 0; }
     { const char *to = getenv("PMAF_EXCHANGE_TIMEOUT_S"); if (to && atof(to) > 0.0) h->exchange_timeout_s = atof(to); }
@@ -862,11 +851,6 @@ int pmaf_create(const pmaf_params *prm, pmaf_planner **out) {
     // switched to LDS batches below 21 obstacles). PMAF_SUM=lds selects the LDS-batch kernels (tests, timing).
     h->dpp_sum = true;
     { const char *ds = getenv("PMAF_SUM"); if (ds && ds[0]) h->dpp_sum = (ds[0] == 'd'); }  // "dpp" / "lds": tests, timing
-    {
-      int cus = 0;
-      HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device));
-      D.n_simds = 4 * (cus > 0 ? cus : 256);
-    }
     pick_mw(h, N, P, M);
     REQUIRE((M + h->lpa - 1) / h->lpa <= 64, "pmaf_create: too many obstacles for this lanes_per_agent (need M <= 64*lanes_per_agent)");
     h->n_blocks = (N * h->lpa + 63) / 64;
@@ -2313,6 +2297,16 @@ int pmaf_get_waves_per_agent(pmaf_planner *h, int32_t *waves_per_agent, int32_t 
     if (waves_per_agent) *waves_per_agent = h->mw_waves ? h->mw_waves : 1;
     if (obstacles_per_wave) *obstacles_per_wave = h->mw_waves ? h->mw_per : h->D.n_obs - 1;
   });
+}
+
+int32_t pmaf_pick_lanes_per_agent(int32_t n_agents, int32_t n_populations, int32_t n_field_obstacles, int32_t n_simds) {
+  if (n_agents < 1 || n_populations < 1 || n_field_obstacles < 0) return 0;
+  return pick_lpa(n_agents, n_populations, n_field_obstacles, n_simds > 0 ? n_simds : 1024);
+}
+
+double pmaf_estimate_rollout_us(int32_t lanes_per_agent, int32_t n_agents, int32_t n_populations, int32_t n_field_obstacles,
+                                int32_t horizon, int32_t n_simds) {
+  return pmaf_lpa::estimate_us(lanes_per_agent, n_agents, n_populations, n_field_obstacles, horizon, n_simds > 0 ? n_simds : 1024);
 }
 
 }  // extern "C"

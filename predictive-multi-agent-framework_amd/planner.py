@@ -112,6 +112,8 @@ SYMBOLS = {
     "pmaf_get_launch_count": (C.c_int, [_V, C.POINTER(C.c_int64)]),
     "pmaf_get_launch_config": (C.c_int, [_V, _ip, _ip, _ip]),
     "pmaf_get_waves_per_agent": (C.c_int, [_V, _ip, _ip]),
+    "pmaf_pick_lanes_per_agent": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    "pmaf_estimate_rollout_us": (C.c_double, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "pmaf_debug_math": (C.c_int, [C.c_int32, C.c_int32, _dp, _dp, _dp]),
     "pmaf_debug_external_rollout": (C.c_int, [_V, C.c_char_p, C.c_char_p]),
     "pmaf_get_health": (C.c_int, [_V, _ip]),

@@ -24,7 +24,7 @@ def test_every_declared_symbol_is_exported_and_bound(pmaf, hip_lib):
     for name in declared:
         assert hasattr(raw, name), "libpmaf_hip.so does not export %s" % name
     assert sorted(pmaf.SYMBOLS) == declared, "planner.py binding table out of sync with include/pmaf.h"
-    assert hip_lib.pmaf_abi_version() == 6
+    assert hip_lib.pmaf_abi_version() == 7
 
 
 def test_params_struct_matches_header(pmaf):
@@ -40,7 +40,7 @@ def test_argument_validation_messages(pmaf, hip_lib, scenes):
     prm.abi_version = 99
     assert hip_lib.pmaf_create(C.byref(prm), C.byref(h)) == -1
     assert b"ABI version" in hip_lib.pmaf_last_error()
-    prm.abi_version = 6
+    prm.abi_version = hip_lib.pmaf_abi_version()
     prm.n_populations, prm.n_agents, prm.n_obstacles, prm.max_prediction_steps = 1, 4, 0, 10
     assert hip_lib.pmaf_create(C.byref(prm), C.byref(h)) == -1
     assert b"obstacle" in hip_lib.pmaf_last_error()  # empty obstacle list (reference underflows)

@@ -1234,21 +1234,52 @@ def test_synchronous_stepping_api_matches_oracle(pmaf, oracle, scenes, lpa):
     hip.close()
 
 
-@pytest.mark.parametrize("n,m,want", [(2304, 128, 64), (2304, 70, 64), (4400, 64, 32), (4400, 33, 32), (2304, 64, 32),
-                                      (4400, 32, 16), (8400, 20, 16), (8400, 16, 8)])
-def test_narrower_mappings_hold_at_most_two_slots_per_lane(pmaf, oracle, scenes, n, m, want):
-    """pick_lpa (round 5, profiles/r5_lpa_rule.txt): more agents than 2048 waves narrow the mapping, but never to more
-    than two obstacle slots per lane -- the three- / four-slot group bodies cost more than another round of waves
-    (128 obstacles x 2304 agents: 1674 -> 876 us). Parity of the populations whose mapping changed, and of their
-    neighbours whose mapping stayed."""
-    sc = scenes.synthetic_scene(n, 12, m, 6, 9)
-    hip, ora = make_pair(pmaf, oracle, sc)
+@pytest.mark.parametrize("n,p,m,want", [
+    # round 5's rows: never more than two obstacle slots per lane in a narrower mapping
+    (2304, 1, 128, 64), (2304, 1, 70, 64), (4096, 1, 64, 32), (4096, 1, 33, 32), (2304, 1, 64, 32), (8192, 1, 32, 16),
+    (8400, 1, 20, 16), (12288, 1, 16, 8),
+    # round 6 (pmaf_lpa_model.hpp, profiles/r6_lpa_grid.txt): the three regions where the wave-count rule was 20-31 % off ...
+    (2304, 1, 9, 16), (3072, 1, 16, 16), (4096, 1, 12, 16),                # few obstacles: 16 lanes, not 32
+    (2304, 1, 48, 64), (3072, 1, 60, 64), (6144, 1, 60, 64),               # one-slot wave per agent through a third round
+    (1536, 1, 64, 32), (2048, 1, 62, 32),                                  # 61-64 obstacles: 32 lanes x 2 slots at one wave per SIMD
+    # ... the same decisions for several populations in one handle (waves = P x ceil(N L / 64)) ...
+    (1024, 3, 9, 16), (256, 8, 62, 32), (300, 9, 50, 64),
+    # ... and the band between one and two waves per SIMD of the wave per agent, where nothing changes (profiles/r6_lpa_band.txt)
+    (1280, 1, 32, 64), (2048, 1, 32, 64), (1024, 2, 32, 64), (1792, 1, 9, 64), (2048, 1, 60, 64)])
+def test_narrower_mappings_are_chosen_by_the_measured_table(pmaf, oracle, scenes, n, p, m, want):
+    """pick_lpa: the mapping with the smallest estimated launch time (csrc/pmaf_lpa_model.hpp, a table of measured times;
+    round 5's structural rule -- at most two obstacle slots per lane in a narrower mapping -- is what it offers from).
+    Parity of the populations whose mapping changed in round 6, of round 5's, and of neighbours whose mapping stayed:
+    every path point, cost and index against the oracle, tolerance 0, P populations against P oracles."""
+    assert pmaf.load_library().pmaf_pick_lanes_per_agent(n, p, m, 0) == want
+    scs = [scenes.synthetic_scene(n, 12, m, 6, 9 + i) for i in range(p)]
+    sc = scs[0]
+    starts = np.stack([s["start"] for s in scs])
+    hip = pmaf.PmafPlanner(scs if p > 1 else sc, device=0, mgr_init_pos=starts if p > 1 else sc["start"])
+    hip.set_initial_position(starts if p > 1 else sc["start"])
     assert hip.launch_config()["lanes_per_agent"] == want
+    oras = []
+    for q in scs:
+        o = oracle.OraclePlanner(q, mgr_init_pos=q["start"])
+        o.set_initial_position(q["start"])
+        oras.append(o)
+    obs = np.stack([q["obstacles"] for q in scs])
     for t in range(2):
-        assert hip.tick(sc["obstacles"], sc["dt"], sc["cost_gains"], sc["ws_limits"]) == \
-            ora.tick(sc["obstacles"], sc["dt"], sc["cost_gains"], sc["ws_limits"])
+        bh = np.atleast_1d(hip.tick(obs, sc["dt"], sc["cost_gains"], sc["ws_limits"]))
+        bo = [o.tick(obs[i], sc["dt"], sc["cost_gains"], sc["ws_limits"]) for i, o in enumerate(oras)]
+        np.testing.assert_array_equal(bh, bo)
     hip.stop()
-    assert_state_equal(hip, ora)
+    if p == 1:
+        assert_state_equal(hip, oras[0])
+    else:
+        ph, nh = hip.paths()
+        for i, o in enumerate(oras):
+            po, no = o.paths()
+            np.testing.assert_array_equal(nh[i], no)
+            np.testing.assert_array_equal(ph[i], po)
+            np.testing.assert_array_equal(hip.costs()[i], o.costs())
+            np.testing.assert_array_equal(hip.rot_vecs()[i], o.rot_vecs())
+            np.testing.assert_array_equal(np.asarray(hip.real_state()[0]).reshape(p, 3)[i], o.real_state()[0])
     hip.close()
 
 

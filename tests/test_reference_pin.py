@@ -21,22 +21,120 @@ PIN = os.path.join(ROOT, "oracle", "pin")
 REFS = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "ref_*.json")))
 
 
-def test_scenarios_are_current_and_parse():
-    """oracle/pin/scenarios/*.txt are what make_scenarios.py writes from scenes.py, and replay.py reads them back"""
+def test_scenarios_are_current_and_parse(tmp_path):
+    """oracle/pin/scenarios/*.txt are what make_scenarios.py writes from scenes.py (written into a temporary directory and
+    compared: a test run never rewrites tracked files -- ADVICE r5), and replay.py reads them back"""
     sys.path.insert(0, PIN)
     import replay
     names = sorted(os.path.basename(f)[:-4] for f in glob.glob(os.path.join(PIN, "scenarios", "*.txt")))
     assert {"static1_n10_h100", "c1_static1_n16_h100", "static1_shipped", "dyn1_shipped", "trap_shipped", "dyn1_h300_hysteresis",
             "c2_64x200x32", "static1_closed_loop_lag30", "dyn1_two_goals", "dyn1_freq2"} <= set(names)
-    before = {n: open(os.path.join(PIN, "scenarios", n + ".txt")).read() for n in names}
-    subprocess.run([sys.executable, os.path.join(PIN, "make_scenarios.py")], check=True, capture_output=True)
+    subprocess.run([sys.executable, os.path.join(PIN, "make_scenarios.py"), "--out", str(tmp_path)], check=True, capture_output=True)
+    assert sorted(os.listdir(tmp_path)) == [n + ".txt" for n in names]
     for n in names:
-        assert open(os.path.join(PIN, "scenarios", n + ".txt")).read() == before[n], n + ": regenerate and commit"
+        assert open(os.path.join(PIN, "scenarios", n + ".txt")).read() == open(os.path.join(tmp_path, n + ".txt")).read(), \
+            n + ": run `python oracle/pin/make_scenarios.py` and commit"
         s = replay.load_scenario(os.path.join(PIN, "scenarios", n + ".txt"))
         per_init = max(0, s["n_agents"] - 5) * s["obstacles"].shape[0]
         assert len(s["random"]) == per_init * len(s["goals"]) and s["name"] == n
     s = replay.load_scenario(os.path.join(PIN, "scenarios", "trap_shipped.txt"))
     assert s["obstacles"].shape == (22, 7) and s["max_prediction_steps"] == 1500
+
+
+# ---------------------------------------------------------------------------
+# TOOL VALIDATION -- not parity evidence. The pin machinery (pin_harness.cpp's schema, replay.py's call sequence and
+# comparison, the GPU LockStep) would otherwise run for the first time on a maintainer's machine. These tests record a
+# fixture in the harness's schema FROM THE ORACLE into a temporary directory (never tests/golden/ref_*: that name is
+# reserved for files the reference itself produced), replay it, corrupt single values and require exactly those to be
+# reported. An oracle-made fixture agreeing with the oracle says nothing about the reference.
+# ---------------------------------------------------------------------------
+TOOL_SCENARIOS = ["c1_static1_n16_h100", "dyn1_two_goals", "static1_closed_loop_lag30", "dyn1_freq2", "c2_64x200x32"]
+
+
+def _record(tmp_path, name):
+    sys.path.insert(0, PIN)
+    import replay
+    scn = replay.load_scenario(os.path.join(PIN, "scenarios", name + ".txt"))
+    res = replay.replay(scn, None)
+    out = os.path.join(str(tmp_path), "oraclemade_" + name + ".json")
+    json.dump(res["fixture"], open(out, "w"))
+    return replay, scn, json.load(open(out)), res
+
+
+def _flip(hexstr):
+    """the next double up: the smallest corruption a hex literal can carry"""
+    import numpy as np
+    return float(np.nextafter(float.fromhex(hexstr), np.inf)).hex()
+
+
+def test_fixture_schema_is_one_definition_for_harness_and_replay():
+    """pin_harness.cpp writes exactly the keys oracle/pin/fixture_schema.py defines, and replay.py names no key of its own"""
+    sys.path.insert(0, PIN)
+    import re
+    import fixture_schema as FS
+    written = FS.keys_written_by_harness(open(os.path.join(PIN, "pin_harness.cpp")).read())
+    assert written == FS.ALL_KEYS, sorted(written ^ FS.ALL_KEYS)
+    src = open(os.path.join(PIN, "replay.py")).read()
+    used = set(re.findall(r'(?:rt|rg|ref|out)\[\s*"([a-z_]+)"\s*\]', src)) | set(re.findall(r'"([a-z_]+)" in rt', src))
+    assert used and used <= FS.ALL_KEYS, sorted(used - FS.ALL_KEYS)
+    assert '"pmaf-reference-pin-1"' not in src and "FS.FORMAT" in src       # the format tag comes from the schema too
+    assert 'pmaf-reference-pin-1' in open(os.path.join(PIN, "pin_harness.cpp")).read() and FS.FORMAT == "pmaf-reference-pin-1"
+
+
+@pytest.mark.parametrize("name", TOOL_SCENARIOS)
+def test_tool_validation_record_replay_round_trip(tmp_path, name):
+    """TOOL VALIDATION, not parity evidence: a fixture recorded from the oracle in the harness's schema passes the schema
+    check and replays with 0 mismatches -- under the association it was recorded with, and NOT under the other one on the
+    scenarios where the two orders part (the comparison can tell them apart)."""
+    sys.path.insert(0, PIN)
+    import fixture_schema as FS
+    replay, scn, fx, rec = _record(tmp_path, name)
+    n_ticks = FS.check(fx)
+    assert n_ticks == rec["ticks"] > 0 and fx["scenario"] == name and len(fx["goals"]) == len(scn["goals"])
+    assert "NOT the reference" in fx["meta"]["compiler"]
+    res = replay.replay(scn, fx)
+    assert res["match"] and res["mismatches"] == 0 and res["fields"] == {} and res["compared"] > 100 * n_ticks / 25
+    # through the command line the test of the real fixtures uses, with the OTHER association of the oracle
+    path = os.path.join(str(tmp_path), "oraclemade_" + name + ".json")
+    other = "rassoc" if os.environ.get("PMAF_VARIANT", "") == "" else ""
+    r = subprocess.run([sys.executable, os.path.join(PIN, "replay.py"), os.path.join(PIN, "scenarios", name + ".txt"), path],
+                       env=dict(os.environ, PMAF_VARIANT=other), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    o = json.loads(r.stdout.strip().splitlines()[-1])
+    assert o["order"] != res["order"]
+    if name != "c2_64x200x32":
+        assert not o["match"] and o["mismatches"] > 0, "the other dot-product association reproduced the record: the comparison is blind"
+
+
+def test_tool_validation_corrupted_values_are_reported_exactly(tmp_path):
+    """TOOL VALIDATION: the last bit flipped in (a) a path point, (b) a best index, (c) a set-point of an oracle-made
+    fixture -- replay.py reports exactly those three, with their tick and field, and nothing else (open loop: the replayed
+    planner does not depend on the record, so a corrupted record cannot spread)"""
+    replay, scn, fx, _ = _record(tmp_path, "c1_static1_n16_h100")
+    ticks = fx["goals"][0]["ticks"]
+    t_path = next(i for i, t in enumerate(ticks) if "paths" in t and i > 0)
+    agent, point = 3, 7
+    assert ticks[t_path]["n"][agent] > point + 1
+    ticks[t_path]["paths"][agent][point][1] = _flip(ticks[t_path]["paths"][agent][point][1])
+    t_best = 4
+    ticks[t_best]["best"] = (ticks[t_best]["best"] + 1) % scn["n_agents"]
+    t_sp = 9
+    ticks[t_sp]["pos"][2] = _flip(ticks[t_sp]["pos"][2])
+    res = replay.replay(scn, fx)
+    assert not res["match"] and res["mismatches"] == 3
+    assert res["fields"] == {"path of agent %d" % agent: {"count": 1, "ticks": [t_path]},
+                             "best index": {"count": 1, "ticks": [t_best]},
+                             "set-point": {"count": 1, "ticks": [t_sp]}}
+    assert res["first"]["what"] == "best index" and res["first"]["tick"] == t_best
+    assert 0 < res["max_abs_diff"] < 1e-15           # one ulp
+    # the tolerance mode used for the HIP path forgives the two last-bit flips, never the index
+    res = replay.replay(scn, fx, tol=1e-5)
+    assert res["mismatches"] == 1 and list(res["fields"]) == ["best index"]
+    # a truncated record (the reference's run ended earlier) and a wrong planned-trajectory length are run-length mismatches
+    fx["goals"][0]["ticks"] = ticks[:-3]
+    fx["goals"][0]["planned_trajectory"] += 1
+    res = replay.replay(scn, fx, tol=1e-5)
+    assert {"run length of goal 0", "ticks of goal 0", "planned trajectory points"} <= set(res["fields"])
 
 
 def test_pin_recipe_skips_without_real_eigen_and_dqrobotics_or_writes_fixtures():
@@ -109,6 +207,51 @@ class LockStep:
         return call
 
 
+def _lockstep_replay(replay, pmaf, oracle, scn, ref, order):
+    """the HIP planner (C-ABI) and the oracle in its portable-exp mode, call by call bit-identical (LockStep), replayed
+    against a fixture: best-index sequence exact, set-points and the selected agent's scored trajectory within 1e-5 m"""
+    oracle.set_exp_mode(1)
+    try:
+        return replay.replay(scn, ref, tol=1e-5, selected_only=True, order=order,
+                             make=lambda sc, ip: LockStep(pmaf.PmafPlanner(sc, device=0, mgr_init_pos=ip),
+                                                          oracle.OraclePlanner(sc, mgr_init_pos=ip)))
+    finally:
+        oracle.set_exp_mode(0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["c1_static1_n16_h100", "c2_64x200x32", "dyn1_two_goals", "static1_closed_loop_lag30", "dyn1_freq2",
+                                  "trap_shipped"])
+def test_tool_validation_lockstep_over_an_oracle_made_fixture(tmp_path, pmaf, oracle, name):
+    """TOOL VALIDATION, not parity evidence (the fixture is recorded from the ORACLE into a temporary directory; files the
+    reference produced are the only ones called tests/golden/ref_*.json). What it buys: the comparison code of
+    test_hip_path_is_held_to_the_reference_fixtures -- LockStep, replay.py's call sequence for goal changes / closed loop /
+    freq multiples driven through the HIP planner, the tolerance mode -- runs HERE on every GPU test run, not for the first
+    time on the machine of a maintainer who has just built the reference. Also shows the comparison is not vacuous: a
+    set-point of the record moved by 1e-3 m and a best index changed are reported at their ticks, and nothing else is."""
+    replay, scn, fx, rec = _record(tmp_path, name)           # oracle, libm exp (mode 0), this build's association
+    order = pmaf.load_library().pmaf_eval_order()
+    assert rec["order"] == order, "oracle and HIP library are built with different evaluation orders (PMAF_VARIANT)"
+    res = _lockstep_replay(replay, pmaf, oracle, scn, fx, order)
+    assert res["ticks"] == rec["ticks"] and res["compared"] > 5 * res["ticks"]
+    if conftest.libm_is_restated(oracle):
+        # HIP == oracle(portable exp) call by call, and the portable exp IS this host's libm: nothing to tolerate
+        assert res["match"] and res["max_abs_diff"] == 0.0, res["first"]
+    else:
+        assert res["fields"].keys() <= {"set-point", "velocity", "goal distance", "path of the selected agent",
+                                        "last point of the selected agent"} or res["match"], res["fields"]
+    # corrupt the record: the HIP side must be reported against it
+    g = fx["goals"][-1]
+    t_sp, t_best = len(g["ticks"]) // 2, len(g["ticks"]) // 3
+    g["ticks"][t_sp]["pos"][0] = (float.fromhex(g["ticks"][t_sp]["pos"][0]) + 1e-3).hex()
+    g["ticks"][t_best]["best"] = (g["ticks"][t_best]["best"] + 1) % scn["n_agents"]
+    bad = _lockstep_replay(replay, pmaf, oracle, scn, fx, order)
+    assert not bad["match"]
+    assert bad["fields"]["set-point"] == {"count": 1, "ticks": [t_sp]} and bad["fields"]["best index"] == {"count": 1, "ticks": [t_best]}
+    if conftest.libm_is_restated(oracle):
+        assert set(bad["fields"]) == {"set-point", "best index"} and abs(bad["max_abs_diff"] - 1e-3) < 1e-12
+
+
 @pytest.mark.gpu
 @pytest.mark.skipif(not REFS, reason="no tests/golden/ref_*.json yet (see test_oracle_is_held_to_the_reference_fixtures)")
 def test_hip_path_is_held_to_the_reference_fixtures(pmaf, oracle):
@@ -135,13 +278,7 @@ def test_hip_path_is_held_to_the_reference_fixtures(pmaf, oracle):
         if not exact["match"]:
             pytest.skip("evaluation order %d is not the reference build's (oracle differs on %s: %s) -- run with the other PMAF_VARIANT"
                         % (order, name, exact["first"]))
-        oracle.set_exp_mode(1)
-        try:
-            res = replay.replay(scn, ref, tol=1e-5, selected_only=True, order=order,
-                                make=lambda sc, ip: LockStep(pmaf.PmafPlanner(sc, device=0, mgr_init_pos=ip),
-                                                             oracle.OraclePlanner(sc, mgr_init_pos=ip)))
-        finally:
-            oracle.set_exp_mode(0)
+        res = _lockstep_replay(replay, pmaf, oracle, scn, ref, order)
         print("%-28s HIP == oracle (portable exp) on every call; vs the reference: %d values over %d ticks, %d beyond 1e-5 m (max %.3g)%s" % (
             name, res["compared"], res["ticks"], res["mismatches"], res["max_abs_diff"],
             ("  (exact)" if res["max_abs_diff"] == 0 else "") if res["match"] else "  <- another libm's exp, amplified by this scene: " + str(res["first"])))

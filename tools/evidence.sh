@@ -1,12 +1,13 @@
 #!/bin/bash
-# Round-5 evidence run on the GPU box (gpurun -- bash tools/r5_evidence.sh [part ...]): bench lines, rocprofv3 trace + PMC
-# summaries (C2 / C3 / C5 x 8), the evaluation-order variant (full GPU suite + kernel times of both libraries), the regime
-# table, tick latency open / closed loop, fuzz campaign, the GPU suite. Everything lands in gpurun_out/r5/; what is kept is
-# copied to profiles/r5_* by tools/r5_collect.sh.
+# The round's evidence run on the GPU box (gpurun -- bash tools/evidence.sh [part ...]; ROUND=r6 by default): bench lines,
+# the emulated C5 strong-scaling curve, rocprofv3 trace + PMC summaries (C2 / C3 / C5 x 8), the evaluation-order variant
+# (full GPU suite + kernel times of both libraries), the regime table, tick latency open / closed loop, fuzz campaign, the
+# GPU suite. Everything lands in gpurun_out/$ROUND/; what is kept is copied to profiles/${ROUND}_* by tools/collect.sh.
 cd ${GRAFT_REPO_ROOT:-$(pwd)}
-O=gpurun_out/r5
+R=${ROUND:-r6}
+O=gpurun_out/$R
 mkdir -p $O
-PARTS=${@:-bench prof misc variant tests}
+PARTS=${@:-bench scaling prof misc variant tests}
 for part in $PARTS; do case $part in
 bench)
   python bench.py --steps 20 --warmup 5 > $O/bench_c2_driver_flags.json 2> $O/bench.err
@@ -21,10 +22,18 @@ bench)
   python oracle/cpu_bench.py --config C2 --budget 12 > $O/cpu_bench_c2_run1.json 2>> $O/bench.err
   python oracle/cpu_bench.py --config C2 --budget 12 > $O/cpu_bench_c2_run2.json 2>> $O/bench.err
   ;;
+scaling)
+  # BASELINE C5's strong-scaling curve emulated on this one GPU (bench.py: emulate_c5_scaling) + what the all-gather of
+  # the winner records costs where it can be measured here: RCCL with ONE rank (the enqueue + kernel of ncclAllGather on
+  # the exchange stream) and two ranks sharing this GPU over the host transport -> profiles/${R}_scaling_emulated.json
+  PMAF_BENCH_FORCE_DIST=1 MASTER_PORT=29533 python bench.py --config C5 --shard --only-headline --cpu-seconds 0 --flop-ticks 0 --steps 200 2>> $O/bench.err | grep "^{" | tail -1 > $O/bench_c5_rccl_1rank.json
+  PMAF_BENCH_BACKEND=gloo PMAF_BENCH_SINGLE_DEVICE=1 python bench.py --gpus 2 --config C5 --shard --only-headline --cpu-seconds 0 --flop-ticks 0 --steps 200 2>> $O/bench.err | grep "^{" | tail -1 > $O/bench_c5shard_2ranks_1gpu_host.json
+  python tools/scaling_emulated.py $O/bench_c2_driver_flags.json $O/bench_c5_rccl_1rank.json $O/bench_c5shard_2ranks_1gpu_host.json > $O/scaling_emulated.json 2>> $O/bench.err
+  ;;
 prof)
-  bash tools/gpu_prof.sh r5_c2 > /dev/null 2>&1
-  bash tools/gpu_prof.sh r5_c3 --config C3 --steps 400 > /dev/null 2>&1
-  bash tools/gpu_prof.sh r5_c5 --config C5 --populations 8 --steps 400 > /dev/null 2>&1
+  bash tools/gpu_prof.sh ${R}_c2 > /dev/null 2>&1
+  bash tools/gpu_prof.sh ${R}_c3 --config C3 --steps 400 > /dev/null 2>&1
+  bash tools/gpu_prof.sh ${R}_c5 --config C5 --populations 8 --steps 400 > /dev/null 2>&1
   ;;
 misc)
   python tools/regime.py --out $O/regime.json > $O/regime.txt 2>&1
@@ -32,7 +41,7 @@ misc)
   # the same question at the C++ boundary (no interpreter): planTick open / closed loop, the node's five calls
   { echo "# tests/cpp/facade_tick lat: one planCallback through the C++ facade on an idle stream, static1 scene";
     for nc in "10 1500" "16 101" "64 201"; do echo "## agents, max_prediction_steps: $nc"; tests/cpp/facade_tick lat $nc 1000; done; } > $O/facade_latency.txt 2>&1
-  { echo "# per-agent / per-wave rollout durations from the device clock (round 5 kernels: glibc-compatible exp)";
+  { echo "# per-agent / per-wave rollout durations from the device clock (glibc-compatible exp since round 5)";
     python tools/agenttime.py C1 C2 C3; } 2>&1 | grep -v "^$\|amdgpu.ids" > $O/agent_times.txt
   bash tools/fuzz_campaign.sh > $O/fuzz_campaign.txt 2>&1
   ;;

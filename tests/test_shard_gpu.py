@@ -581,7 +581,7 @@ def test_bench_self_spawns_its_ranks_and_reports_every_config():
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert out["n_gpus"] == 2 and out["config"]["collective_world"] == 2
     cfgs = out["configs"]
-    assert set(cfgs) == {"C1", "C3", "C5_sharded", "C4", "task_static1", "C2_contracted", "C3_contracted", "C5_sharded_contracted"}
+    assert set(cfgs) == {"C1", "C3", "C5_sharded", "C5_one_gpu", "C4", "task_static1", "C2_contracted", "C3_contracted", "C5_sharded_contracted"}
     assert all(cfgs[k]["arithmetic_policy"] == ("contracted" if k.endswith("_contracted") else "strict") for k in cfgs)
     # parity flags: strict = bit-exact; the contracted policy's tolerance contract does not hold on C5
     assert all(cfgs[k]["parity_met"] for k in cfgs if not k.endswith("_contracted"))

@@ -28,7 +28,7 @@ scaling)
   # the exchange stream) and two ranks sharing this GPU over the host transport -> profiles/${R}_scaling_emulated.json
   PMAF_BENCH_FORCE_DIST=1 MASTER_PORT=29533 python bench.py --config C5 --shard --only-headline --cpu-seconds 0 --flop-ticks 0 --steps 200 2>> $O/bench.err | grep "^{" | tail -1 > $O/bench_c5_rccl_1rank.json
   PMAF_BENCH_BACKEND=gloo PMAF_BENCH_SINGLE_DEVICE=1 python bench.py --gpus 2 --config C5 --shard --only-headline --cpu-seconds 0 --flop-ticks 0 --steps 200 2>> $O/bench.err | grep "^{" | tail -1 > $O/bench_c5shard_2ranks_1gpu_host.json
-  python tools/scaling_emulated.py $O/bench_c2_driver_flags.json $O/bench_c5_rccl_1rank.json $O/bench_c5shard_2ranks_1gpu_host.json > $O/scaling_emulated.json 2>> $O/bench.err
+  python tools/scaling_emulated.py $O/bench_c2_driver_flags.json $O/bench_c5_rccl_1rank.json $O/bench_c5shard_2ranks_1gpu_host.json $O/bench_c2_rccl_1rank.json > $O/scaling_emulated.json 2>> $O/bench.err
   ;;
 prof)
   bash tools/gpu_prof.sh ${R}_c2 > /dev/null 2>&1

@@ -1,7 +1,10 @@
-"""Regenerates the measured-numbers block of DESIGN.md (between the `numbers:begin` / `numbers:end` markers) and the
-generated blocks of README.md from the committed evidence of round 5: profiles/r5_bench_c2_driver_flags.json (the
-driver's command), r5_bench_c2.json, r5_bench_c3.json, r5_bench_c5x8.json, r5_c{2,3,5}_trace.txt (rocprofv3 --kernel-trace
---stats), traffic.json, r5_regime.json, r5_ticklat.txt, r5_cpu_bench_c2_run{1,2}.json.
+"""Regenerates the measured-numbers block of DESIGN.md (between the `numbers:begin` / `numbers:end` markers), the BOUND
+paragraphs of its section 4 (`bound_w64` / `bound_mw` / `bound_grp` markers: instructions per wave-step by class, issue slots,
+issue fraction, traffic ratio, FP64 fraction -- from the PMC summaries), the scaling table of section 6 (`scaling` markers,
+from <round>_scaling_emulated.json) and the generated blocks of README.md from the committed evidence of the round
+(ROUND in the environment, default r6): profiles/<round>_bench_c2_driver_flags.json (the driver's command),
+_bench_c2.json, _bench_c3.json, _bench_c5x8.json, _c{2,3,5}_trace.txt (rocprofv3 --kernel-trace --stats), _c{2,3,5}_pmc{1,2}.txt,
+traffic.json, _regime.json, _ticklat.txt, _cpu_bench_c2_run{1,2}.json.
 FAILS when the bench line's roofline.traffic is not the value of profiles/traffic.json (a bench line taken before the PMC
 passes were regenerated must not be quoted beside them: VERDICT r4 weak 5). usage: python tools/fill_numbers.py"""
 import json
@@ -11,7 +14,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 P = os.path.join(ROOT, "profiles")
-R = "r5"
+R = os.environ.get("ROUND", "r6")
 
 
 def load(name):
@@ -68,7 +71,7 @@ for name, kk_, kn in (("C2 contracted (opt-in; tolerance parity met)", "C2_contr
         rows.append((name, cf[kk_]["rollouts_per_s"], cf[kk_]["ms_per_tick"], "`%s` %.1f" % (kn, cf[kk_]["avg_kernel_us"])))
 out = []
 kt = rf.get("kernel_timing") or {}
-out.append("One MI355X, round 5 (the round-4 step with glibc's `exp`, §2: + 2 … 4 %% per launch; ABI 6). `profiles/%s_bench_c2_driver_flags.json` = the driver's command "
+out.append("One MI355X, round 6 (the kernels are round 5's; ABI 7). `profiles/%s_bench_c2_driver_flags.json` = the driver's command "
            "(`python bench.py --steps 20 --warmup 5`: %d blocks, %.2f s timed; HIP events on every %s-th rollout launch: %s of %s) with its "
            "sub-records; rocprofv3 `--kernel-trace --stats` of the same workloads: `profiles/%s_c{2,3,5}_trace.txt`; PMC passes "
            "`profiles/%s_c*_pmc*.txt` → `profiles/traffic.json`.\n"
@@ -180,9 +183,115 @@ try:
 except (OSError, KeyError) as e:
     out.append("(regime table unavailable: %s)" % e)
 block = "\n".join(out) + "\n"
+
+
+# ---- section 4: what bounds each tuned kernel, from the PMC passes (no hand-carried number)
+def pmc(tag, i, kernel_prefix):
+    """counter -> average per dispatch of the kernel whose name starts with kernel_prefix (tools/prof_summary.py's table)"""
+    vals = {}
+    for line in open(os.path.join(P, "%s_%s_pmc%d.txt" % (R, tag, i))):
+        f = [x.strip() for x in line.split("|")]
+        if len(f) == 5 and kernel_prefix in f[0] and f[1] not in ("counter", "calls"):
+            try:
+                vals[f[1]] = float(f[3])
+            except ValueError:
+                pass
+    return vals
+
+
+def bound(tag, kernel_prefix, line, tj_key, agents_per_wave):
+    a, b = pmc(tag, 1, kernel_prefix), pmc(tag, 2, kernel_prefix)
+    if not a or "SQ_WAVES" not in a:
+        sys.exit("fill_numbers: no PMC summary for %s in profiles/%s_%s_pmc1.txt" % (kernel_prefix, R, tag))
+    waves, steps = a["SQ_WAVES"], line["h_eff"]
+    per = lambda c: a.get(c, 0.0) / waves / steps
+    valu, salu, lds = per("SQ_INSTS_VALU"), per("SQ_INSTS_SALU"), per("SQ_INSTS_LDS")
+    vmem = per("SQ_INSTS_VMEM_RD") + per("SQ_INSTS_VMEM_WR")
+    slots = per("SQ_WAVE_CYCLES")
+    tot = valu + salu + lds + vmem
+    t = tj[tj_key]
+    # consistency gate (like the traffic one): the PMC passes and the bench line must describe the same kernel launch
+    rfl = line["roofline"]
+    if abs(t["waves_per_launch"] - waves) > 1.0 or kernel_prefix.replace(" ", "") not in rfl["kernel"].replace(" ", ""):
+        sys.exit("fill_numbers: %s: PMC waves %.1f vs traffic.json %.1f / bench kernel %s" % (tag, waves, t["waves_per_launch"], rfl["kernel"]))
+    fv_ = line["fp64_valu"]
+    return dict(waves=waves, steps=steps, valu=valu, salu=salu, lds=lds, vmem=vmem, tot=tot, slots=slots, issue=tot / slots,
+                vaf=t["valu_active_frac_of_wave_cycles"], ratio=t["traffic_bytes_per_launch"] / rfl["algorithmic_bytes_per_launch"],
+                hbm=rfl["frac"], tf=fv_["achieved_tflops"], fpfrac=fv_["frac"], us=rfl["avg_kernel_us"],
+                flop_per_lane_op=fv_["flops_per_agent_step"] * agents_per_wave / (valu * 64.0))
+
+
+B2 = bound("c2", "k_rollout_w64<1, 2, true, true>", d, "C2:k_rollout_w64<1, 2, true, true>", 1)
+B3 = bound("c3", "k_rollout_mw<2, 2, true, false>", c3, "C3:k_rollout_mw<2, 2, true, false>", 0.5)
+B5 = bound("c5", "k_rollout_grp<16, 2, 2>", c5, "C5x8:k_rollout_grp<16, 2, 2>", 4)
+bw64 = ("**Bound** (C2; generated from `profiles/%s_c2_pmc1.txt`, `_pmc2.txt`, `traffic.json`, `%s_bench_c2_driver_flags.json`): %d waves on 1 024 SIMDs; per "
+        "wave-step %.0f VALU + %.0f SALU + %.0f LDS + %.1f VMEM = %.0f instructions in %.0f issue slots (`SQ_WAVE_CYCLES` ÷ waves ÷ steps) = "
+        "**%.0f %% of the one-wave issue limit**; `SQ_ACTIVE_INST_VALU` / `SQ_WAVE_CYCLES` = %.2f. The launch (%.1f µs) is as long as its slowest "
+        "agent + ≈ 10 µs. HBM traffic %.2f × algorithmic (the cost pass re-reads the path; the LDS-ring fix is 2–5 %% slower, NOTES §2): "
+        "irrelevant at %.2g of peak; FP64 %.3f TF = %.2f %% of 78.6 TF."
+        % (R, R, round(B2["waves"]), B2["valu"], B2["salu"], B2["lds"], B2["vmem"], B2["tot"], B2["slots"], 100 * B2["issue"], B2["vaf"], B2["us"],
+           B2["ratio"], B2["hbm"], B2["tf"], 100 * B2["fpfrac"]))
+bmw = ("**Bound** (C3; generated from `profiles/%s_c3_pmc1.txt`, `_pmc2.txt`, `traffic.json`, `%s_bench_c3.json`): the chain is as long as in the one-wave "
+       "kernel (sweep → terms → ordered sum of ≈ 57 dependent accumulates → tail); only the per-obstacle ISSUE is spread over the block's waves: "
+       "%d waves, per wave-step %.0f VALU + %.0f SALU + %.0f LDS + %.1f VMEM = %.0f instructions in %.0f issue slots = %.0f %% of a wave's issue "
+       "limit (`SQ_ACTIVE_INST_VALU` / `SQ_WAVE_CYCLES` = %.2f); launch %.1f µs, %.2g of HBM peak, traffic %.2f × algorithmic, FP64 %.2f TF = %.2f %% "
+       "of peak. History: C3 977 → 930 µs against the two-slot one-wave kernel, 129…256 obstacles −26…32 %% (`profiles/r4_ab_mw.txt`); barrier wait "
+       "0.4–3 %% of the loop."
+       % (R, R, round(B3["waves"]), B3["valu"], B3["salu"], B3["lds"], B3["vmem"], B3["tot"], B3["slots"], 100 * B3["issue"], B3["vaf"], B3["us"], B3["hbm"],
+          B3["ratio"], B3["tf"], 100 * B3["fpfrac"]))
+bgrp = ("**Bound** (C5 × 8; generated from `profiles/%s_c5_pmc1.txt`, `_pmc2.txt`, `traffic.json`, `%s_bench_c5x8.json`): FP64-VALU issue — %d waves = two "
+        "per SIMD, per wave-step (4 agents) %.0f VALU + %.0f SALU + %.0f LDS + %.1f VMEM instructions; `SQ_ACTIVE_INST_VALU` / `SQ_WAVE_CYCLES` = %.2f per "
+        "wave ⇒ the SIMD's VALU ≈ %.0f %% busy; launch %.1f µs, %.2f TF = **%.2f %% of FP64 peak**, %.2f flop per lane-operation (the per-agent part "
+        "is replicated over the group's lanes; split / helper wave / LPA 8 were built, measured slower, rejected: NOTES §2); %.2g of HBM peak, "
+        "traffic %.2f × algorithmic."
+        % (R, R, round(B5["waves"]), B5["valu"], B5["salu"], B5["lds"], B5["vmem"], B5["vaf"], 200 * B5["vaf"], B5["us"], B5["tf"], 100 * B5["fpfrac"],
+           B5["flop_per_lane_op"], B5["hbm"], B5["ratio"]))
+
+# ---- section 6: the emulated strong-scaling curve of BASELINE C5
+sc_block = "(no profiles/%s_scaling_emulated.json)" % R
+try:
+    se = json.load(open(os.path.join(P, "%s_scaling_emulated.json" % R)))
+    rows6 = ["| GPUs | scenes per GPU | lanes per agent | rollout kernel µs (slowest rank) | ms per tick | aggregate rollouts/s | speed-up | efficiency vs 1 GPU |",
+             "|---|---|---|---|---|---|---|---|"]
+    for n in ("1", "2", "4", "8"):
+        r_ = se["predicted_by_n"][n]
+        rows6.append("| %s | %d | %d | %.1f | %.4f | %s | %.2f × | %.0f %% |" % (
+            n, r_["populations_per_gpu"], r_["lanes_per_agent"], r_["kernel_us_slowest_rank"], r_["ms_per_tick"], k(r_["rollouts_per_s"]),
+            r_["speedup_vs_1gpu"], 100 * r_["efficiency_vs_1gpu"]))
+    ag = se.get("allgather", {})
+    r1_ = ag.get("rccl_one_rank_free_cus") or {}
+    r8_ = ag.get("rccl_one_rank_under_c5x8") or {}
+    h2_ = ag.get("two_ranks_one_gpu_host_transport") or {}
+    ser = se.get("if_the_allgather_were_serialised") or {}
+    sc_block = ("**Predicted 1 → 8-GPU curve of BASELINE C5 (strong scaling), emulated on ONE GPU** (`bench.py`: `scaling_c5.prediction`; "
+                "`profiles/%s_scaling_emulated.json`): every rank's share of the eight scenes run in a handle of its own, one after the other; the "
+                "job's tick at N GPUs is its slowest rank's; the winner-record all-gather is not on the tick's critical path.\n\n" % R
+                + "\n".join(rows6) + "\n\n"
+                + "**Why it saturates at ≈ %.1f ×**: a rollout is one dependent 200-step chain; with one scene per GPU (1 024 waves, one per SIMD) the "
+                  "launch sits on the chain floor of ≈ %.0f µs and cannot get shorter, while ONE GPU already runs all eight scenes in %.2f ms by "
+                  "packing four agents into a wave at two waves per SIMD. Strong scaling of this configuration is bounded by construction, "
+                  "not by communication: the curve to expect from `SCALE_rNN.json` is this table, and the line's `scaling_c5` block (not `value`, "
+                  "which is BASELINE C2 replicated per GPU: weak scaling, ≈ N × by construction) is where to read it. "
+                  % (se["predicted_by_n"]["8"]["speedup_vs_1gpu"], se["chain_floor_us"], se["predicted_by_n"]["1"]["ms_per_tick"])
+                + ("The all-gather where it can be measured here: `ncclAllGather` with a ONE-rank RCCL communicator costs %.1f µs median / %.1f p99 on "
+                   "the exchange stream when its kernel gets a CU at once (C2)" % (r1_["median_us"], r1_["p99_us"]) if r1_ else "")
+                + ("; beside the 8-scene rollout it completes only after %.0f µs — the group kernel's 2 × 252 VGPRs fill every SIMD, the collective's "
+                   "kernel waits for the first waves to retire — and the tick does not wait for it (%.4f ms per tick with it, %.4f without)"
+                   % (r8_["median_us"], r8_["ms_per_tick_with_it"], r8_["ms_per_tick_without"]) if r8_ else "")
+                + ("; two ranks sharing this GPU over the host transport: %.0f µs (plumbing, not xGMI)" % h2_["median_us"] if h2_ else "")
+                + (". Were the collective serialised behind every tick at the free-CU cost per ring step, the 8-GPU efficiency would be %.0f %% instead "
+                   "of %.0f %%." % (100 * ser["8"]["efficiency_vs_1gpu"], 100 * se["predicted_by_n"]["8"]["efficiency_vs_1gpu"]) if ser else ".")
+                + " Weak scaling (more scenes than GPUs × 8, or BASELINE C2 per GPU) has no such bound: ranks share nothing.")
+except (OSError, KeyError, ValueError) as e:
+    sc_block = "(scaling table unavailable: %s)" % e
+
 p = os.path.join(ROOT, "DESIGN.md")
 s = open(p).read()
 s = re.sub(r"(<!-- numbers:begin[^\n]*-->\n).*?(<!-- numbers:end -->)", lambda m: m.group(1) + block + m.group(2), s, flags=re.S)
+for name, text in (("bound_w64", bw64), ("bound_mw", bmw), ("bound_grp", bgrp), ("scaling", sc_block)):
+    if ("<!-- %s:begin -->" % name) not in s:
+        sys.exit("fill_numbers: DESIGN.md has no %s markers" % name)
+    s = re.sub(r"(<!-- %s:begin -->\n).*?(<!-- %s:end -->)" % (name, name), lambda m: m.group(1) + text + "\n" + m.group(2), s, flags=re.S)
 open(p, "w").write(s)
 
 # README

@@ -3,7 +3,7 @@ instruction count by class and the number of SGPR-spill v_readlane / v_writelane
 the smallest loop of each kernel. For a lone wave every instruction is a 4-cycle issue slot (tools/slackprof.py), so
 the count is the first-order cost model of the latency shape; the group kernel is VALU-issue bound, so its VALU count is.
 
-usage: python tools/steploop.py <out_dir>          [prefix]   (writes <prefix>_<tag>_steploop.txt per kernel family; prefix defaults to r5)
+usage: python tools/steploop.py <out_dir>          [prefix]   (writes <prefix>_<tag>_steploop.txt per kernel family; prefix defaults to r6)
 
 How a spill is recognised: SGPR spills go to lanes of VGPRs that no other instruction touches -- a VGPR that, in the
 whole kernel, is only ever the destination of v_writelane_b32 and the source of v_readlane_b32 with CONSTANT lane
@@ -17,7 +17,7 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-PREFIX = sys.argv[2] if len(sys.argv) > 2 else "r5"
+PREFIX = sys.argv[2] if len(sys.argv) > 2 else "r6"
 CSRC = os.path.join(ROOT, "predictive-multi-agent-framework_amd", "csrc")
 BASE = ("--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -mllvm -amdgpu-sched-strategy=max-ilp "
         "-mllvm -amdgpu-atomic-optimizer-strategy=None --cuda-device-only -S").split()

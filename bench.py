@@ -170,6 +170,8 @@ def kernel_name_of(cfg, n_obs, math=2):
         dpp = True    # (rounds 1-2: LDS batches for <= 20 obstacles; round 3: the DPP chain for every count)
         if os.environ.get("PMAF_SUM"):
             dpp = t > 1 or os.environ["PMAF_SUM"].startswith("d")
+        if cfg.get("priority_slices") and t == 1 and dpp and plain:   # two waves per SIMD (pmaf_get_priority_slices)
+            return "k_rollout_w64_sliced<%d>" % math
         # <TILES, MATH_XACT, DPPSUM, PLAIN>; the bench scenes have k_attr != 0 and unit mass = the PLAIN step
         return "k_rollout_w64<%d, %d, %s, %s>" % (t, math, "true" if dpp else "false", "true" if plain else "false")
     if cfg["lanes_per_agent"] in (8, 16, 32) and (n_obs - 2) // cfg["lanes_per_agent"] + 1 <= 4 and not generic:

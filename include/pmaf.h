@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define PMAF_ABI_VERSION 7   /* 7: pmaf_pick_lanes_per_agent / pmaf_estimate_rollout_us (the mapping rule as a pure function);
+#define PMAF_ABI_VERSION 7   /* 7: pmaf_pick_lanes_per_agent / pmaf_estimate_rollout_us (the mapping rule as a pure function), pmaf_get_priority_slices;
                               * pmaf_move_real with steps = 0 leaves no trace; 6: pmaf_eval_order (build-time evaluation-order policy); pmaf_set_real_position no longer waits
                               * for the running rollout; 5: PMAF_FLAG_CONTRACTED, pmaf_get_health, the winner path in pinned
                               * memory, the tick's time limit */
@@ -510,6 +510,13 @@ int pmaf_get_launch_config(pmaf_planner *h, int32_t *lanes_per_agent,
  * every wave of the launch gets a SIMD of its own; PMAF_MW=0 in the environment keeps the one-wave kernels, PMAF_MW=3|4
  * asks for more waves than the obstacle count needs (tests, timing). Results are bit-identical either way. */
 int pmaf_get_waves_per_agent(pmaf_planner *h, int32_t *waves_per_agent, int32_t *obstacles_per_wave);
+/* Whether the handle's rollout launches run the wave-per-agent kernel's PRIORITY-SLICING loop (k_rollout_w64_sliced): with
+ * 1 025 ... 2 048 one-slot wave-per-agent rollouts in the handle two waves share a SIMD, the issue arbiter would serve the older
+ * one first (the launch then lasts 1.64 x a lone wave's rollout), and the two trade issue priority in slices of the 100 MHz
+ * wall clock instead (slice_ticks x 10 ns each, the younger wave holding `younger_of_8` of every eight) so that both finish
+ * together: -4 ... -7 % per launch (profiles/r6_slice_sweep.txt). Scheduling only -- the arithmetic is the same instruction
+ * sequence, results are bit-identical. No counterpart in the reference (the OS schedules its threads). */
+int pmaf_get_priority_slices(pmaf_planner *h, int32_t *enabled, int32_t *slice_ticks, int32_t *younger_of_8);
 /* The mapping rule as a pure function (no handle, no device): the lanes-per-agent mapping pmaf_create chooses for
  * n_populations x n_agents agents and n_field_obstacles circular-field obstacles (M, without the trailing repulsive one)
  * when pmaf_params.lanes_per_agent is 0, on a device with n_simds SIMDs (0 = MI355X's 1024). The reference has no

@@ -19,6 +19,10 @@
 #include "pmaf_types.hpp"
 #include "pmaf_lpa_model.hpp"
 
+#ifndef PMAF_W64_SLICE_DEFAULT
+#define PMAF_W64_SLICE_DEFAULT true
+#endif
+
 using namespace pmaf;
 
 static thread_local std::string g_err;
@@ -59,6 +63,7 @@ struct pmaf_planner {
   int lpa = 64;
   int math = MATH_XACT;        // arithmetic policy of the w64 rollout kernels (pmaf_device.hpp)
   bool force_generic = false;  // PMAF_FORCE_GENERIC=1: always use the generic k_rollout<LPA>
+  bool w64_slice = false;      // two waves of the wave-per-agent kernel on a SIMD trade issue priority (pmaf_k_w64.hip, SLICE)
   bool plain_step = false;     // every k_attr != 0 and unit mass: the wave-per-agent kernels' PLAIN step (pmaf_k_w64.hip)
   bool blocking_wait = false;  // PMAF_FLAG_BLOCKING_WAIT: pmaf_tick sleeps on an event instead of spinning on the mailbox
   bool dpp_sum = true;         // w64 kernels: ordered force sum by the DPP chain (M > 20) or LDS batches
@@ -403,7 +408,10 @@ static void launch_rollout(pmaf_planner *h) {
     // the one-wave kernels serve every such population, bit for bit the same; pmaf_get_waves_per_agent reports 1 from now on)
     if (h->mw_waves) { (void)hipGetLastError(); h->mw_waves = 0; h->mw_per = 0; }
     // ordered force sum: the DPP chain (h->dpp_sum, see pmaf_create), LDS batches on request (pmaf_rollout_w64.hpp)
-    ok = pmaf_k_launch_w64(h->D, h->cp, tiles64, h->math, h->dpp_sum, h->plain_step, h->lds_rollout, h->stream, e0, e1);
+    // more waves than SIMDs (and at most two per SIMD): the one-slot kernel's priority-slicing loop (pmaf_k_w64.hip, SLICE)
+    const long waves = (long)h->D.N * h->D.P;
+    const bool slice = h->w64_slice && waves > h->D.n_simds && waves <= 2L * h->D.n_simds;
+    ok = pmaf_k_launch_w64(h->D, h->cp, tiles64, h->math, h->dpp_sum, h->plain_step, h->lds_rollout, h->stream, e0, e1, slice);
   } else if (!h->force_generic && (h->lpa == 32 || h->lpa == 16 || h->lpa == 8) && (M + h->lpa - 1) / h->lpa <= 4)
     // (policy 1, the plain fast arithmetic, exists for the w64 kernels only)
     ok = pmaf_k_launch_grp(h->D, h->cp, h->lpa, (M + h->lpa - 1) / h->lpa, h->math == MATH_FAST ? MATH_XACT : h->math,
@@ -843,6 +851,16 @@ int pmaf_create(const pmaf_params *prm, pmaf_planner **out) {
     }
     h->lpa = lp ? lp : pick_lpa(N, P, M, D.n_simds);
     { const char *fg = getenv("PMAF_FORCE_GENERIC"); h->force_generic = fg && fg[0] == '1'; }
+    // Two waves of the wave-per-agent kernel on one SIMD (1 025 ... 2 048 agents in the handle) trade issue priority in slices
+    // of the wall clock so that both finish together (pmaf_k_w64.hip, SLICE; pmaf_get_priority_slices). tools/slicesweep.py,
+    // profiles/r6_slice_sweep.txt, kernel us per launch without -> with (slices of 2^9 ticks = 5.1 us, the younger wave 5 of 8):
+    //   32 obstacles: 1 280 agents 347 -> 326, 1 536: 359 -> 334, 2 048: 381 -> 364;  9 x 2 048: 376 -> 362;  60 x 2 048: 383 -> 370;
+    //   BASELINE C5, two scenes in the handle (its per-GPU load at 4 GPUs): 386 -> 372.  Settings 2^8 ... 2^10 x 4 ... 6 of 8: within 2 %.
+    // The arithmetic and its order are the same instructions: bit-identical results (tests/test_parity_gpu.py runs these shapes).
+    // PMAF_W64_SLICE=0|1, PMAF_W64_SLICE_LOG2, PMAF_W64_SLICE_YOUNGER in the environment: timing experiments.
+    { const char *e = getenv("PMAF_W64_SLICE"); h->w64_slice = e ? (e[0] == '1') : PMAF_W64_SLICE_DEFAULT; }
+    { const char *e = getenv("PMAF_W64_SLICE_LOG2"); D.prio_slice_log2 = e ? atoi(e) : 9; }
+    { const char *e = getenv("PMAF_W64_SLICE_YOUNGER"); D.prio_younger_of_8 = e ? atoi(e) : 5; }
     { const char *ab = getenv("PMAF_ABLATE"); D.ablate = ab ? atoi(ab) : 0; }
     { const char *to = getenv("PMAF_EXCHANGE_TIMEOUT_S"); if (to && atof(to) > 0.0) h->exchange_timeout_s = atof(to); }
     { const char *to = getenv("PMAF_TICK_TIMEOUT_S"); if (to && atof(to) > 0.0) h->tick_timeout_s = atof(to); }
@@ -2296,6 +2314,19 @@ int pmaf_get_waves_per_agent(pmaf_planner *h, int32_t *waves_per_agent, int32_t 
     REQUIRE(h, "pmaf_get_waves_per_agent: NULL handle");
     if (waves_per_agent) *waves_per_agent = h->mw_waves ? h->mw_waves : 1;
     if (obstacles_per_wave) *obstacles_per_wave = h->mw_waves ? h->mw_per : h->D.n_obs - 1;
+  });
+}
+
+int pmaf_get_priority_slices(pmaf_planner *h, int32_t *enabled, int32_t *slice_ticks, int32_t *younger_of_8) {
+  return guarded([&] {
+    REQUIRE(h, "pmaf_get_priority_slices: NULL handle");
+    const int M = h->D.n_obs - 1;
+    const long waves = (long)h->D.N * h->D.P;
+    const bool on = h->w64_slice && h->lpa == 64 && !h->force_generic && !h->mw_waves && !h->ext_fn && M <= 60 && h->dpp_sum && h->plain_step &&
+                    (h->math == MATH_XACT || h->math == MATH_FMA) && waves > h->D.n_simds && waves <= 2L * h->D.n_simds;
+    if (enabled) *enabled = on ? 1 : 0;
+    if (slice_ticks) *slice_ticks = 1 << h->D.prio_slice_log2;
+    if (younger_of_8) *younger_of_8 = h->D.prio_younger_of_8;
   });
 }
 

@@ -893,22 +893,22 @@ __global__ void k_eval_obstacle_distance(DevView D, const double *obs, double *o
 // ---------------------------------------------------------------------------
 // launch interface (pmaf_types.hpp)
 // ---------------------------------------------------------------------------
-bool pmaf_k_launch_w64_m0(const DevView &, const CostParams &, int, bool, bool, size_t, hipStream_t, hipEvent_t, hipEvent_t);
-bool pmaf_k_launch_w64_m1(const DevView &, const CostParams &, int, bool, bool, size_t, hipStream_t, hipEvent_t, hipEvent_t);
-bool pmaf_k_launch_w64_m2_t1(const DevView &, const CostParams &, int, bool, bool, size_t, hipStream_t, hipEvent_t, hipEvent_t);   // one slot per lane
-bool pmaf_k_launch_w64_m2_tn(const DevView &, const CostParams &, int, bool, bool, size_t, hipStream_t, hipEvent_t, hipEvent_t);   // two / four slots
+bool pmaf_k_launch_w64_m0(const DevView &, const CostParams &, int, bool, bool, size_t, hipStream_t, hipEvent_t, hipEvent_t, bool);
+bool pmaf_k_launch_w64_m1(const DevView &, const CostParams &, int, bool, bool, size_t, hipStream_t, hipEvent_t, hipEvent_t, bool);
+bool pmaf_k_launch_w64_m2_t1(const DevView &, const CostParams &, int, bool, bool, size_t, hipStream_t, hipEvent_t, hipEvent_t, bool);   // one slot per lane
+bool pmaf_k_launch_w64_m2_tn(const DevView &, const CostParams &, int, bool, bool, size_t, hipStream_t, hipEvent_t, hipEvent_t, bool);   // two / four slots
 bool pmaf_k_launch_grp_m0(const DevView &, const CostParams &, int, int, int, size_t, hipStream_t, hipEvent_t, hipEvent_t);
 bool pmaf_k_launch_grp_m2(const DevView &, const CostParams &, int, int, int, size_t, hipStream_t, hipEvent_t, hipEvent_t);
-bool pmaf_k_launch_w64_m3(const DevView &, const CostParams &, int, bool, bool, size_t, hipStream_t, hipEvent_t, hipEvent_t);      // contracted policy
+bool pmaf_k_launch_w64_m3(const DevView &, const CostParams &, int, bool, bool, size_t, hipStream_t, hipEvent_t, hipEvent_t, bool);      // contracted policy
 bool pmaf_k_launch_grp_m3(const DevView &, const CostParams &, int, int, int, size_t, hipStream_t, hipEvent_t, hipEvent_t);
 
 bool pmaf_k_launch_w64(const DevView &D, const CostParams &cp, int tiles, int math, bool dppsum, bool plain, size_t lds,
-                       hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
-  if (math == MATH_FMA) return pmaf_k_launch_w64_m3(D, cp, tiles, dppsum, plain, lds, s, e0, e1);
-  if (math == MATH_FAST) return pmaf_k_launch_w64_m1(D, cp, tiles, dppsum, plain, lds, s, e0, e1);
-  if (math == MATH_IEEE) return pmaf_k_launch_w64_m0(D, cp, tiles, dppsum, plain, lds, s, e0, e1);
-  return (tiles <= 1) ? pmaf_k_launch_w64_m2_t1(D, cp, tiles, dppsum, plain, lds, s, e0, e1)
-                      : pmaf_k_launch_w64_m2_tn(D, cp, tiles, dppsum, plain, lds, s, e0, e1);
+                       hipStream_t s, hipEvent_t e0, hipEvent_t e1, bool slice) {
+  if (math == MATH_FMA) return pmaf_k_launch_w64_m3(D, cp, tiles, dppsum, plain, lds, s, e0, e1, slice);
+  if (math == MATH_FAST) return pmaf_k_launch_w64_m1(D, cp, tiles, dppsum, plain, lds, s, e0, e1, slice);
+  if (math == MATH_IEEE) return pmaf_k_launch_w64_m0(D, cp, tiles, dppsum, plain, lds, s, e0, e1, slice);
+  return (tiles <= 1) ? pmaf_k_launch_w64_m2_t1(D, cp, tiles, dppsum, plain, lds, s, e0, e1, slice)
+                      : pmaf_k_launch_w64_m2_tn(D, cp, tiles, dppsum, plain, lds, s, e0, e1, slice);
 }
 
 bool pmaf_k_launch_mw_m1(const DevView &, const CostParams &, int, int, bool, int, hipStream_t, hipEvent_t, hipEvent_t);

@@ -41,7 +41,13 @@ __device__ __forceinline__ auto w64_exp_consts(int lane) {
 }
 // STATICV (one slot per lane): every field obstacle of the population is at rest with +0.0 velocities and the lane the
 // rel_vel rider needs is idle -- decided per block by the kernel (pmaf_rollout_w64.hpp, NVL)
-template <int TILES, int TYPE, int MATH, int SENT = 2, bool DPPSUM = false, bool PLAIN = false, bool STATICV = false>
+// SLICE (round 6): launches of MORE waves than the device has SIMDs -- 1 025 ... 2 048 agents on this kernel: two waves on
+// half or all of the SIMDs. The issue arbiter serves the older wave first, absolutely: the first n_simds waves run at their
+// stand-alone speed T, the others on the slots left over (0.42 of a wave's rate) and then alone, 1.58 T in all (232 -> 375 us
+// at 2 048 agents x 32 obstacles, profiles/r6_lpa_band.txt). With SLICE the two waves of a SIMD trade issue priority in
+// slices of the wall clock (the group kernel's scheme, pmaf_k_grp.hip) so that both finish together at 2 T / 1.42.
+// A template parameter, not a run-time flag: the one-wave-per-SIMD launches (C1, C2, C4) keep their step loop untouched.
+template <int TILES, int TYPE, int MATH, int SENT = 2, bool DPPSUM = false, bool PLAIN = false, bool STATICV = false, bool SLICE = false>
 __device__ __forceinline__ void rollout_w64_body(const DevView &D, const CostParams &CP, const int lane,
                                                  const int pop, const int a) {
   extern __shared__ double smem[];
@@ -185,7 +191,11 @@ __device__ __forceinline__ void rollout_w64_body(const DevView &D, const CostPar
 #ifdef PMAF_SECTION_TIMERS
   ST.start();
 #endif
+  const bool younger = SLICE && ((((unsigned)blockIdx.y * gridDim.x + blockIdx.x) / (unsigned)D.n_simds) & 1u) != 0u;
+  const unsigned slice_log2 = (unsigned)D.prio_slice_log2, younger_of_8 = (unsigned)D.prio_younger_of_8;
   while ((dg > 0.1) && (n < D.cap)) {  // wave-uniform guard, B/src/cf_agent.cpp:310-311
+    unsigned long long clk = 0ull;
+    if (SLICE) clk = wall_clock64();
     // gate, :315-317
     // |v| < 0.5 vmax and |p - init| < 0.2 on exact squared thresholds
     // (as a lane mask built from single compares: pmaf_rollout_w64.hpp, "lane predicates as masks")
@@ -318,7 +328,12 @@ __device__ __forceinline__ void rollout_w64_body(const DevView &D, const CostPar
       repel = sentinel_repel_m<MATH>(p, C, k_repel, sent_p, sent_r, zsent_lt, inv_shell);
     }
     PMAF_SEC(ST, 7);
+    if (SLICE) {
+      if (((((unsigned)(clk >> slice_log2)) & 7u) < younger_of_8) == younger) __builtin_amdgcn_s_setprio(1);
+      else __builtin_amdgcn_s_setprio(0);
+    }
   }
+  if (SLICE) __builtin_amdgcn_s_setprio(0);
 #ifdef PMAF_SECTION_TIMERS
   if (lane == 0 && pop == 0 && a < 7)
     printf("agent %d type %d steps %d | verr+gate %llu sweep %llu scale %llu circ %llu sum %llu (skip) %llu finish %llu tail %llu | "
@@ -364,8 +379,8 @@ __device__ __forceinline__ void rollout_w64_body(const DevView &D, const CostPar
   }
 }
 
-template <int TILES, int MATH, bool DPPSUM, bool PLAIN>
-__global__ __launch_bounds__(64) void k_rollout_w64(DevView D, CostParams CP) {
+template <int TILES, int MATH, bool DPPSUM, bool PLAIN, bool SLICE>
+__device__ __forceinline__ void rollout_w64_dispatch(const DevView &D, const CostParams &CP) {
   const int lane = threadIdx.x;
   const int pop = blockIdx.y;
   const int a = blockIdx.x;  // grid.x == N
@@ -392,10 +407,10 @@ __global__ __launch_bounds__(64) void k_rollout_w64(DevView D, CostParams CP) {
     const bool st = !wave_any(!rest) && (M <= 59 || !reach);
 #define PMAF_BODY(T) \
     if (st) { \
-      if (!reach) rollout_w64_body<TILES, T, MATH, 0, DPPSUM, PLAIN, true>(D, CP, lane, pop, a); \
-      else rollout_w64_body<TILES, T, MATH, 1, DPPSUM, PLAIN, true>(D, CP, lane, pop, a); \
-    } else if (!reach) rollout_w64_body<TILES, T, MATH, 0, DPPSUM, PLAIN>(D, CP, lane, pop, a); \
-    else rollout_w64_body<TILES, T, MATH, 1, DPPSUM, PLAIN>(D, CP, lane, pop, a)
+      if (!reach) rollout_w64_body<TILES, T, MATH, 0, DPPSUM, PLAIN, true, SLICE>(D, CP, lane, pop, a); \
+      else rollout_w64_body<TILES, T, MATH, 1, DPPSUM, PLAIN, true, SLICE>(D, CP, lane, pop, a); \
+    } else if (!reach) rollout_w64_body<TILES, T, MATH, 0, DPPSUM, PLAIN, false, SLICE>(D, CP, lane, pop, a); \
+    else rollout_w64_body<TILES, T, MATH, 1, DPPSUM, PLAIN, false, SLICE>(D, CP, lane, pop, a)
     switch (D.types[a]) {
       case T_GOAL: PMAF_BODY(T_GOAL); break;
       case T_OBST: PMAF_BODY(T_OBST); break;
@@ -419,6 +434,17 @@ __global__ __launch_bounds__(64) void k_rollout_w64(DevView D, CostParams CP) {
   }
 }
 
+template <int TILES, int MATH, bool DPPSUM, bool PLAIN>
+__global__ __launch_bounds__(64) void k_rollout_w64(DevView D, CostParams CP) {
+  rollout_w64_dispatch<TILES, MATH, DPPSUM, PLAIN, false>(D, CP);
+}
+// the one-slot kernel (DPP sum, PLAIN step) with the priority-slicing loop: launches with two waves on a SIMD (SLICE above).
+// A kernel of its own so that k_rollout_w64's names -- what the rocprofv3 summaries and profiles/traffic.json are keyed by -- stay.
+template <int MATH>
+__global__ __launch_bounds__(64) void k_rollout_w64_sliced(DevView D, CostParams CP) {
+  rollout_w64_dispatch<1, MATH, true, true, true>(D, CP);
+}
+
 
 #ifndef PMAF_W64_MATH
 #error "compile with -DPMAF_W64_MATH=0|1|2|3"
@@ -436,7 +462,7 @@ __global__ __launch_bounds__(64) void k_rollout_w64(DevView D, CostParams CP) {
 #define PMAF_W64_LAUNCH PMAF_CAT(pmaf_k_launch_w64_m, PMAF_W64_MATH)
 #endif
 bool PMAF_W64_LAUNCH(const DevView &D, const CostParams &cp, int tiles, bool dppsum,
-                     bool plain, size_t lds, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
+                     bool plain, size_t lds, hipStream_t s, hipEvent_t e0, hipEvent_t e1, bool slice) {
   const dim3 g64((unsigned)D.N, (unsigned)D.P), block(64);
 #define PMAF_L(K) hipExtLaunchKernelGGL(K, g64, block, (unsigned)lds, s, e0, e1, 0, D, cp)
   // one slot per lane: both ordered-sum variants (the host picks); two / four slots: DPP only
@@ -447,6 +473,10 @@ bool PMAF_W64_LAUNCH(const DevView &D, const CostParams &cp, int tiles, bool dpp
 #define PMAF_LP(T, S) do { if (plain) PMAF_L((k_rollout_w64<T, PMAF_W64_MATH, S, true>)); \
                            else PMAF_L((k_rollout_w64<T, PMAF_W64_MATH, S, false>)); } while (0)
 #if !defined(PMAF_W64_PART) || PMAF_W64_PART == 1
+#if PMAF_W64_MATH >= 2
+  // two waves per SIMD: the priority-slicing loop (one-slot, DPP sum, PLAIN -- what many-agent populations run)
+  if (slice && tiles <= 1 && dppsum && plain) { PMAF_L((k_rollout_w64_sliced<PMAF_W64_MATH>)); return true; }
+#endif
   if (tiles <= 1 && !dppsum) { PMAF_LP(1, false); return true; }
   if (tiles <= 1) { PMAF_LP(1, true); return true; }
 #endif

@@ -36,7 +36,7 @@ struct Row {
 // profiles/r6_lpa_grid.txt (MI355X, 1024 SIMDs); (8, 1) from the 4- and 8-obstacle rows of profiles/r6_lpa_heldout.txt,
 // its three- / four-wave entries scaled from (8, 2) (no launch of that size fits a population: 8 B of LDS per agent).
 static const Row kRows[] = {
-  {64, 1, 9, {232, 374, 541, 685}, 147, 60, {239, 384, 553, 716}, 152},
+  {64, 1, 9, {232, 362, 541, 685}, 147, 60, {239, 370, 553, 716}, 152},   // two per SIMD: WITH the priority slices (r6_slice_sweep.txt; 374 / 384 without)
   {64, 2, 64, {364, 594, 852, 1100}, 231, 128, {393, 625, 894, 1148}, 244},
   {64, 4, 129, {534, 1019, 1478, 1941}, 462, 256, {691, 1292, 1861, 2434}, 578},   // profiles/r6_lpa_fourslot.txt
   {32, 1, 9, {362, 485, 847, 928}, 214, 32, {377, 488, 880, 959}, 218},

@@ -88,6 +88,7 @@ struct DevView {
   const double *zsent_lt;            // [P] exact squared-distance boundary of the repel range test
   int ablate;                        // timing experiments only (PMAF_ABLATE), 0 in production
   int n_simds;                       // SIMDs of the device (4 per CU): a launch of more waves doubles them up
+  int prio_slice_log2, prio_younger_of_8;   // wave-per-agent SLICE loop (pmaf_k_w64.hip): slice length in 2^k ticks of the 100 MHz clock, the younger wave's share
   // closest-other table of the rollout-start obstacles (round 3): closest_idx[p][i] = the index the Obstacle /
   // GoalObstacle heuristics' scan for the field obstacle nearest to obstacle i returns (B/src/cf_agent.cpp:434-446 /
   // :480-492), valid while closest_ok[p] != 0: k_manager computes it when it writes obs_start from a NEW live list whose
@@ -184,7 +185,7 @@ struct PlanArgs {
 // e0 / e1 (may be NULL): HIP events attached to the kernel's own dispatch packet (hipExtLaunchKernel start / stop
 // events) -- no marker packets in the stream, so timing a launch does not put anything between two kernels
 bool pmaf_k_launch_w64(const DevView &D, const CostParams &cp, int tiles, int math, bool dppsum, bool plain, size_t lds,
-                       hipStream_t s, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
+                       hipStream_t s, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr, bool slice = false);
 // k_rollout_grp<LPA, TILES, MATH> on grid (n_blocks, P); lpa in {8,16,32}, tiles in {1,2,4}, math XACT, IEEE or FMA
 // W waves per agent (pmaf_k_mw.hip): waves in 2..4, per = field obstacles per wave (<= 61); every policy but MATH_IEEE
 // lds_kb: dynamic LDS per block in KB (0: the launcher's placement rule)

@@ -112,6 +112,7 @@ SYMBOLS = {
     "pmaf_get_launch_count": (C.c_int, [_V, C.POINTER(C.c_int64)]),
     "pmaf_get_launch_config": (C.c_int, [_V, _ip, _ip, _ip]),
     "pmaf_get_waves_per_agent": (C.c_int, [_V, _ip, _ip]),
+    "pmaf_get_priority_slices": (C.c_int, [_V, _ip, _ip, _ip]),
     "pmaf_pick_lanes_per_agent": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "pmaf_estimate_rollout_us": (C.c_double, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "pmaf_debug_math": (C.c_int, [C.c_int32, C.c_int32, _dp, _dp, _dp]),
@@ -573,8 +574,10 @@ class PmafPlanner:
         self._chk(self.L.pmaf_get_launch_config(self._h, C.byref(a), C.byref(b), C.byref(c)))
         w, pw = C.c_int32(0), C.c_int32(0)
         self._chk(self.L.pmaf_get_waves_per_agent(self._h, C.byref(w), C.byref(pw)))
+        ps = C.c_int32(0)
+        self._chk(self.L.pmaf_get_priority_slices(self._h, C.byref(ps), None, None))
         return dict(lanes_per_agent=a.value, n_blocks=b.value, lds_bytes=c.value, waves_per_agent=w.value,
-                    obstacles_per_wave=pw.value)
+                    obstacles_per_wave=pw.value, priority_slices=bool(ps.value))
 
 
 HOST_ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)

@@ -592,9 +592,21 @@ def test_bench_self_spawns_its_ranks_and_reports_every_config():
     assert ts["kernel"] == "k_rollout_w64<1, 2, true, true>"
     for name, c in cfgs.items():
         assert c["rollouts_per_s"] > 0 and c["blocks"] >= 5 and c["h_eff"] == c["horizon"], name
-        assert c["allgather_us"]["n"] >= 10 and c["kernel"].startswith("k_rollout")
+        assert c["kernel"].startswith("k_rollout")
+        if name == "C5_one_gpu":   # all eight scenes on rank 0's GPU alone: no exchange, one GPU
+            assert c["allgather_us"] is None and c["gpus_used"] == 1 and c["populations_per_gpu"] == 8 and c["populations_total"] == 8
+        else:
+            assert c["allgather_us"]["n"] >= 10
     assert cfgs["C4"]["coupling"] == "peer mailboxes"
     assert cfgs["C5_sharded"]["populations_total"] == 8 and cfgs["C5_sharded"]["populations_per_gpu"] == 4
+    # BASELINE C5's strong-scaling record at the top level, beside the weak-scaling `value`: measured at this N, the same eight
+    # scenes on rank 0's GPU alone in the same job, and the ratio of the two (two ranks SHARING one GPU here: below 1)
+    sc5 = out["scaling_c5"]
+    assert sc5["n_gpus"] == 2 and sc5["scaling"] == "strong" and "weak" in sc5["read_this_for_scaling"]
+    assert sc5["measured"]["rollouts_per_s"] == cfgs["C5_sharded"]["rollouts_per_s"]
+    assert sc5["one_gpu_same_job"]["rollouts_per_s"] == cfgs["C5_one_gpu"]["rollouts_per_s"]
+    assert abs(sc5["measured"]["speedup_vs_one_gpu_same_job"] - cfgs["C5_sharded"]["rollouts_per_s"] / cfgs["C5_one_gpu"]["rollouts_per_s"]) < 1e-12
+    assert abs(sc5["measured"]["efficiency_vs_one_gpu_same_job"] * 2 - sc5["measured"]["speedup_vs_one_gpu_same_job"]) < 1e-12
     assert cfgs["C2_contracted"]["kernel"] == "k_rollout_w64<1, 3, true, true>"
     hx = cfgs["C4"]["header_exchange_us"]
     assert hx["n"] >= 50 and hx["wait_median"] is not None and cfgs["C4"]["gpus_used"] == 2

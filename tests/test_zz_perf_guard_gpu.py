@@ -95,7 +95,7 @@ def test_c5_populations_per_gpu_kernel_time(pmaf, scenes, box_factor, pops, reco
     (2048, 128, 640.0, 64, 1), (4096, 128, 1185.0, 64, 1), (8192, 32, 700.0, 16, 1), (1024, 128, 409.0, 64, 1),
     (256, 128, 339.0, 64, 2),                    # the SPLIT kernel (one block per CU: N P <= 256; ADVICE r5: 1024 x 128 never ran it)
     # round 6, between one and two waves per SIMD of the wave per agent and just beyond (profiles/r6_lpa_band.txt, r6_lpa_grid.txt)
-    (2048, 32, 379.0, 64, 1), (2048, 9, 374.0, 64, 1), (2048, 60, 384.0, 64, 1), (2048, 62, 520.0, 32, 1),
+    (2048, 32, 379.0, 64, 1), (2048, 9, 360.0, 32, 1), (1792, 9, 361.0, 64, 1), (2048, 60, 384.0, 64, 1), (2048, 62, 520.0, 32, 1),
     (2304, 9, 351.0, 16, 1), (2304, 48, 530.0, 64, 1), (3072, 60, 553.0, 64, 1), (4096, 16, 391.0, 16, 1)])
 def test_many_agent_kernel_time(pmaf, scenes, box_factor, n, m, record, lpa, waves):
     """the agent-count sweeps of tools/regime.py / tools/lpaband.py at their corners: one-wave two-slot kernel with every

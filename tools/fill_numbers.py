@@ -320,5 +320,12 @@ r = re.sub(r"(<!-- target:begin -->).*?(<!-- target:end -->)", lambda m: m.group
 r = re.sub(r"(<!-- lat:begin -->).*?(<!-- lat:end -->)", lambda m: m.group(1) + (
     "with the selected trajectory on the host too (SURVEY §8(d)'s tick) %.1f µs median, %.1f µs p99; set-point alone %.1f µs median, %.1f µs p99 "
     "— both on the library's own clock (`pmaf_get_winner_path_times_us`, `pmaf_get_tick_times_us`)" % (wp.get("median", float("nan")), wp.get("p99", float("nan")), lib["median"], lib["p99"])) + m.group(2), r, flags=re.S)
+try:
+    se_ = json.load(open(os.path.join(P, "%s_scaling_emulated.json" % R)))["predicted_by_n"]
+    r = re.sub(r"(<!-- scale:begin -->).*?(<!-- scale:end -->)", lambda m: m.group(1) + " / ".join(
+        "%s GPU%s %.2f ms per tick (%.0f %%)" % (n, "" if n == "1" else "s", se_[n]["ms_per_tick"], 100 * se_[n]["efficiency_vs_1gpu"]) for n in ("1", "2", "4", "8"))
+        + ", i.e. %.1f × at 8 GPUs" % se_["8"]["speedup_vs_1gpu"] + m.group(2), r, flags=re.S)
+except (OSError, KeyError, ValueError):
+    pass
 open(rp, "w").write(r)
 print(block)

@@ -1258,6 +1258,8 @@ def test_narrower_mappings_are_chosen_by_the_measured_table(pmaf, oracle, scenes
     hip = pmaf.PmafPlanner(scs if p > 1 else sc, device=0, mgr_init_pos=starts if p > 1 else sc["start"])
     hip.set_initial_position(starts if p > 1 else sc["start"])
     assert hip.launch_config()["lanes_per_agent"] == want
+    # two one-slot wave-per-agent rollouts per SIMD run k_rollout_w64_sliced (priority slices: scheduling only, same bits)
+    assert hip.launch_config()["priority_slices"] == (want == 64 and m <= 60 and 1024 < n * p <= 2048)
     oras = []
     for q in scs:
         o = oracle.OraclePlanner(q, mgr_init_pos=q["start"])

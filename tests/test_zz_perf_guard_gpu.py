@@ -81,21 +81,22 @@ def test_baseline_config_kernel_time(pmaf, scenes, box_factor, cfg, record, boun
     check(us, bound, 1.0 if cfg == "C2" else box_factor, cfg)       # (C2 is the yardstick: its own bound does not stretch)
 
 
-@pytest.mark.parametrize("pops,record,lpa", [(8, 710.0, 16), (4, 505.0, 32), (2, 383.0, 64), (1, 235.0, 64)])
+@pytest.mark.parametrize("pops,record,lpa", [(8, 710.0, 16), (4, 505.0, 32), (2, 370.0, 64), (1, 235.0, 64)])
 def test_c5_populations_per_gpu_kernel_time(pmaf, scenes, box_factor, pops, record, lpa):
     """BASELINE C5's per-GPU load at 1 / 2 / 4 / 8 GPUs (8 / 4 / 2 / 1 scenes of 1024 agents in one handle): the mapping each
     gets (16 / 32 / 64 / 64 lanes per agent) and its launch time -- the rows of the emulated scaling curve"""
     us, lc = kernel_us(pmaf, [scenes.config_scene("C5", scene_id=s) for s in range(pops)], ticks=12, warm=3, bound=1.2 * record)
     print("C5 x %d: %.1f us per rollout launch (record %.0f, bound %.0f, box factor %.2f), %r" % (pops, us, record, 1.2 * record, box_factor, lc))
-    assert (lc["lanes_per_agent"], lc["waves_per_agent"]) == (lpa, 1), lc
+    assert (lc["lanes_per_agent"], lc["waves_per_agent"], lc["priority_slices"]) == (lpa, 1, pops == 2), lc
     check(us, 1.2 * record, box_factor, "C5 x %d" % pops)
 
 
 @pytest.mark.parametrize("n,m,record,lpa,waves", [
     (2048, 128, 640.0, 64, 1), (4096, 128, 1185.0, 64, 1), (8192, 32, 700.0, 16, 1), (1024, 128, 409.0, 64, 1),
     (256, 128, 339.0, 64, 2),                    # the SPLIT kernel (one block per CU: N P <= 256; ADVICE r5: 1024 x 128 never ran it)
-    # round 6, between one and two waves per SIMD of the wave per agent and just beyond (profiles/r6_lpa_band.txt, r6_lpa_grid.txt)
-    (2048, 32, 379.0, 64, 1), (2048, 9, 360.0, 32, 1), (1792, 9, 361.0, 64, 1), (2048, 60, 384.0, 64, 1), (2048, 62, 520.0, 32, 1),
+    # round 6, between one and two waves per SIMD of the wave per agent (its priority-slicing loop: `priority_slices` below) and just
+    # beyond (profiles/r6_lpa_band.txt, r6_lpa_grid.txt, r6_slice_sweep.txt)
+    (2048, 32, 362.0, 64, 1), (2048, 9, 356.0, 64, 1), (1280, 32, 326.0, 64, 1), (2048, 60, 370.0, 64, 1), (2048, 62, 520.0, 32, 1),
     (2304, 9, 351.0, 16, 1), (2304, 48, 530.0, 64, 1), (3072, 60, 553.0, 64, 1), (4096, 16, 391.0, 16, 1)])
 def test_many_agent_kernel_time(pmaf, scenes, box_factor, n, m, record, lpa, waves):
     """the agent-count sweeps of tools/regime.py / tools/lpaband.py at their corners: one-wave two-slot kernel with every
@@ -105,4 +106,5 @@ def test_many_agent_kernel_time(pmaf, scenes, box_factor, n, m, record, lpa, wav
     us, lc = kernel_us(pmaf, scenes.synthetic_scene(n, 200, m, 3 if n >= 2048 and m <= 64 else 2, 0), ticks=10, warm=3, bound=bound)
     print("%d agents x 200 steps x %d obstacles: %.1f us per launch (record %.1f, bound %.1f, box factor %.2f), %r" % (n, m, us, record, bound, box_factor, lc))
     assert (lc["lanes_per_agent"], lc["waves_per_agent"]) == (lpa, waves), lc
+    assert lc["priority_slices"] == (lpa == 64 and m <= 60 and 1024 < n <= 2048), lc     # two one-slot waves per SIMD trade priority
     check(us, bound, box_factor, "%d x %d" % (n, m))

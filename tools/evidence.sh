@@ -59,6 +59,7 @@ tests)
   rm -f $PMAF_TOL_REPORT
   python -m pytest tests -m gpu -q -s -p no:cacheprovider 2>&1 | grep -v "^RCCL\|^HIP\|^ROCm\|^Hostname\|^Librccl" > $O/gpu_tests_full.log
   tail -6 $O/gpu_tests_full.log > $O/gpu_tests.log
+  python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1
   ;;
 esac; done
 for f in $O/bench_*.json; do echo "== $f"; python - "$f" <<'PY'

@@ -6,8 +6,9 @@
 #   heldout   other obstacle / agent counts + several populations per handle (used to CORRECT the first table)
 #   heldout2  a second set, never used for fitting (tests/test_lpa_model.py: regret of the chosen mapping <= 8 %)
 #   fourslot  129 ... 256 obstacles (the wave per agent's four-slot kernel, the only mapping offered there)
-# `lpa N (auto)` = what the library of the day chose: r5's rule in band / grid, the table's first version in heldout,
-# the current one in heldout2.
+# `lpa N (auto)` = what the library of the day chose: band and grid were re-measured with the round's final library (the table's
+# choice; the wave per agent's two-per-SIMD rows run its priority-slicing loop), heldout with the table's first version,
+# heldout2 with its second. tests/test_lpa_model.py restates rounds 1-5's rule and compares both with the best measured mapping.
 set -u
 cd "${GRAFT_REPO_ROOT:-$(pwd)}"
 O=gpurun_out/r6; mkdir -p $O

@@ -1,6 +1,7 @@
 #!/bin/bash
 # Sanitizer / debug-bounds builds of the library (SURVEY.md section 5 "race detection / sanitizers": the reference has
-# none). Build here (no GPU needed), run on the GPU box:  gpurun -- bash tools/asan.sh run
+# none). Build here (no GPU needed), run on the GPU box (lib_asan/ and lib_bounds/ do not travel: .gpurunignore):
+#   gpurun -- 'bash tools/asan.sh build > /dev/null 2>&1; bash tools/asan.sh run'
 #   lib_asan/    host side (pmaf_host.cpp, pmaf_shard.cpp) with -fsanitize=address,undefined; product kernels
 #   lib_bounds/  kernels with -DPMAF_DEBUG_BOUNDS (every path / list / slot index checked, the wave traps)
 set -e
@@ -14,7 +15,7 @@ if [ "${1:-build}" = build ]; then
 fi
 cd "$R"
 mkdir -p gpurun_out
-OUT=gpurun_out/r5_asan.txt
+OUT=gpurun_out/${ROUND:-r6}_asan.txt
 ASAN_SO=$(g++ -print-file-name=libasan.so)
 UBSAN_SO=$(g++ -print-file-name=libubsan.so)
 rm -f /tmp/asan_log.* /tmp/ubsan_log.*
@@ -34,7 +35,7 @@ export UBSAN_OPTIONS=print_stacktrace=1:log_path=/tmp/ubsan_log
     --deselect tests/test_abi.py::test_no_kernel_touches_scratch_memory \
     --deselect tests/test_shard_gpu.py::test_exchange_lifecycle_does_not_leak \
     --deselect tests/test_parity_gpu.py::test_handle_lifecycle_does_not_leak_device_memory \
-    -k "abi or symbol or validation or error_reporting or checkpoint or stepping or attached or peer_mailbox_couples or peer_mailbox_two_handles or one_way or missing_header or step_api or health or time_limit or winner_path or set_agent or lifecycle or range or closed_loop or prediction_freq or new_goal" 2>&1 \
+    -k "abi or symbol or validation or error_reporting or checkpoint or stepping or attached or peer_mailbox_couples or peer_mailbox_two_handles or one_way or missing_header or step_api or health or time_limit or winner_path or set_agent or lifecycle or range or closed_loop or prediction_freq or new_goal or move_real or narrower_mappings" 2>&1 \
     | grep -E "PASSED|FAILED|ERROR|SKIPPED|passed|failed|^E  " | sed -e "s#$R/##" | tail -80
   echo "== tools/fuzz_api.py 1000 trials"
   PMAF_LIB_PATH=$R/predictive-multi-agent-framework_amd/lib_asan/libpmaf_hip.so LD_PRELOAD="$ASAN_SO $UBSAN_SO" \

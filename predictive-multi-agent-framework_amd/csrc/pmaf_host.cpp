@@ -368,6 +368,16 @@ static void drain_events(pmaf_planner *h, bool all) {
   h->ev_inflight.erase(h->ev_inflight.begin(), h->ev_inflight.begin() + (long)done);
 }
 
+// Does this handle's wave-per-agent launch run the priority-slicing loop (k_rollout_w64_sliced)? ONE predicate for the launch and
+// for pmaf_get_priority_slices: more one-slot waves than SIMDs and at most two per SIMD, the kernel variants that exist with
+// the loop (DPP sum, PLAIN step, strict or contracted arithmetic), and none of the routes that bypass k_rollout_w64.
+static bool w64_sliced(const pmaf_planner *h) {
+  const int M = h->D.n_obs - 1;
+  const long waves = (long)h->D.N * h->D.P;
+  return h->w64_slice && h->lpa == 64 && !h->force_generic && !h->mw_waves && !h->ext_fn && M <= 60 && h->dpp_sum && h->plain_step &&
+         (h->math == MATH_XACT || h->math == MATH_FMA) && waves > h->D.n_simds && waves <= 2L * h->D.n_simds;
+}
+
 static void launch_rollout(pmaf_planner *h) {
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (h->profiling && (h->prof_phase++ % h->prof_every) == 0) {
@@ -408,9 +418,7 @@ static void launch_rollout(pmaf_planner *h) {
     // the one-wave kernels serve every such population, bit for bit the same; pmaf_get_waves_per_agent reports 1 from now on)
     if (h->mw_waves) { (void)hipGetLastError(); h->mw_waves = 0; h->mw_per = 0; }
     // ordered force sum: the DPP chain (h->dpp_sum, see pmaf_create), LDS batches on request (pmaf_rollout_w64.hpp)
-    // more waves than SIMDs (and at most two per SIMD): the one-slot kernel's priority-slicing loop (pmaf_k_w64.hip, SLICE)
-    const long waves = (long)h->D.N * h->D.P;
-    const bool slice = h->w64_slice && waves > h->D.n_simds && waves <= 2L * h->D.n_simds;
+    const bool slice = w64_sliced(h);   // two one-slot waves per SIMD: the priority-slicing loop (pmaf_k_w64.hip, SLICE)
     ok = pmaf_k_launch_w64(h->D, h->cp, tiles64, h->math, h->dpp_sum, h->plain_step, h->lds_rollout, h->stream, e0, e1, slice);
   } else if (!h->force_generic && (h->lpa == 32 || h->lpa == 16 || h->lpa == 8) && (M + h->lpa - 1) / h->lpa <= 4)
     // (policy 1, the plain fast arithmetic, exists for the w64 kernels only)
@@ -2320,10 +2328,7 @@ int pmaf_get_waves_per_agent(pmaf_planner *h, int32_t *waves_per_agent, int32_t 
 int pmaf_get_priority_slices(pmaf_planner *h, int32_t *enabled, int32_t *slice_ticks, int32_t *younger_of_8) {
   return guarded([&] {
     REQUIRE(h, "pmaf_get_priority_slices: NULL handle");
-    const int M = h->D.n_obs - 1;
-    const long waves = (long)h->D.N * h->D.P;
-    const bool on = h->w64_slice && h->lpa == 64 && !h->force_generic && !h->mw_waves && !h->ext_fn && M <= 60 && h->dpp_sum && h->plain_step &&
-                    (h->math == MATH_XACT || h->math == MATH_FMA) && waves > h->D.n_simds && waves <= 2L * h->D.n_simds;
+    const bool on = w64_sliced(h);
     if (enabled) *enabled = on ? 1 : 0;
     if (slice_ticks) *slice_ticks = 1 << h->D.prio_slice_log2;
     if (younger_of_8) *younger_of_8 = h->D.prio_younger_of_8;

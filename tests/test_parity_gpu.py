@@ -14,6 +14,7 @@ Two oracle modes (oracle/pmaf_oracle.c):
     rollout amplifies a 1-ulp perturbation (mildly over the BASELINE horizons,
     chaotically over 1000+ steps). test_libm_exp_oracle_* assert the north-star
     tolerance 1e-5 m on the BASELINE configs in that mode."""
+import copy
 import os
 
 import numpy as np
@@ -333,6 +334,50 @@ def test_c5_dynamic_obstacles_full_size(pmaf, oracle, scenes):
         np.testing.assert_array_equal(ph[i], po)
         np.testing.assert_array_equal(hip.costs()[i], o.costs())
         np.testing.assert_array_equal(rot[i], o.rot_vecs())
+    hip.close()
+
+
+@pytest.mark.parametrize("dynamic,coupled_sentinel", [(False, False), (True, False), (True, True)])
+def test_c5_two_scenes_per_gpu_run_the_sliced_wave_per_agent_kernel(pmaf, oracle, scenes, dynamic, coupled_sentinel):
+    """BASELINE C5's per-GPU load at 4 GPUs: two scenes x 1024 agents in one handle = 2048 one-slot wave-per-agent rollouts,
+    two per SIMD, which trade issue priority in time slices (k_rollout_w64_sliced: scheduling only). Six ticks at full size,
+    every path point / cost / rotation vector of all 2048 agents against two oracles, tolerance 0 -- static obstacles (the
+    STATIC-velocity loops), obstacles streamed per tick, and with the trailing repulsive obstacle flying through the scene
+    (the loops that carry the lane-60 rider)."""
+    scs = [copy.deepcopy(scenes.config_scene("C5", scene_id=s, dynamic=dynamic)) for s in (0, 1)]
+    if coupled_sentinel:
+        for q in scs:   # a repulsive obstacle that is in range of the rollouts: near the straight line, moving
+            q["obstacles"][-1] = np.array([0.0, 0.05, 0.72, -0.03, 0.01, 0.0, 0.08])
+    starts = np.stack([q["start"] for q in scs])
+    hip = pmaf.PmafPlanner(scs, device=0, mgr_init_pos=starts)
+    hip.set_initial_position(starts)
+    lc = hip.launch_config()
+    assert (lc["lanes_per_agent"], lc["waves_per_agent"], lc["priority_slices"]) == (64, 1, True), lc
+    oras = []
+    for q in scs:
+        o = oracle.OraclePlanner(q, mgr_init_pos=q["start"])
+        o.set_initial_position(q["start"])
+        oras.append(o)
+    obs = np.stack([q["obstacles"] for q in scs])
+    sc = scs[0]
+    for t in range(6):
+        bh = hip.tick(obs, sc["dt"], sc["cost_gains"], sc["ws_limits"])
+        bo = [o.tick(obs[i], sc["dt"], sc["cost_gains"], sc["ws_limits"]) for i, o in enumerate(oras)]
+        np.testing.assert_array_equal(bh, bo)
+        np.testing.assert_array_equal(hip.real_state()[0], np.stack([o.real_state()[0] for o in oras]))
+        if dynamic:
+            obs = np.stack([scenes.advance_live_obstacles(o) for o in obs])
+            if coupled_sentinel:
+                obs[:, -1, 0:3] += obs[:, -1, 3:6] * sc["dt"]
+    ph, nh = hip.paths()
+    rot = hip.rot_vecs()
+    for i, o in enumerate(oras):
+        po, no = o.paths()
+        np.testing.assert_array_equal(nh[i], no)
+        np.testing.assert_array_equal(ph[i], po)
+        np.testing.assert_array_equal(hip.costs()[i], o.costs())
+        np.testing.assert_array_equal(rot[i], o.rot_vecs())
+        np.testing.assert_array_equal(hip.min_obs_dist()[i], o.min_obs_dist())
     hip.close()
 
 

@@ -632,6 +632,38 @@ def test_bench_single_rank_rccl_exchange():
 
 
 @pytest.mark.timeout(600)
+def test_bench_one_gpu_line_carries_the_emulated_c5_scaling_curve():
+    """the driver's own command on one GPU: next to `value` (BASELINE C2) the line holds `scaling_c5` -- BASELINE C5's
+    measured one-GPU record and the 1 / 2 / 4 / 8-GPU curve emulated on this GPU (each rank's share of the eight scenes in a
+    handle of its own; tick at N GPUs = the slowest rank's): VERDICT r5 item 1, SURVEY 8(e)"""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "PMAF_BENCH_FORCE_DIST")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "5", "--min-seconds", "0.1",
+                        "--sub-seconds", "0.05", "--cpu-seconds", "0", "--flop-ticks", "0"],
+                       capture_output=True, text=True, timeout=500, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["n_gpus"] == 1 and out["scaling"] == "weak" and out["config"]["agents"] == 64
+    sc5 = out["scaling_c5"]
+    assert sc5["scaling"] == "strong" and sc5["n_gpus"] == 1 and sc5["measured"]["populations_per_gpu"] == 8
+    assert sc5["measured"]["rollouts_per_s"] == out["configs"]["C5_sharded"]["rollouts_per_s"]
+    by_n = sc5["prediction"]["predicted_by_n"]
+    assert sorted(by_n) == ["1", "2", "4", "8"] and out["configs"]["C5_sharded"]["predicted_by_n"] == by_n
+    assert [by_n[n]["populations_per_gpu"] for n in ("1", "2", "4", "8")] == [8, 4, 2, 1]
+    assert [by_n[n]["lanes_per_agent"] for n in ("1", "2", "4", "8")] == [16, 32, 64, 64]            # pick_lpa per per-GPU load
+    assert [len(by_n[n]["per_rank_ms_per_tick"]) for n in ("1", "2", "4", "8")] == [1, 2, 4, 8]      # every rank's share was run
+    ms = [by_n[n]["ms_per_tick"] for n in ("1", "2", "4", "8")]
+    assert ms[0] > ms[1] > ms[2] > ms[3] > 0.15                                                       # ... and floors on one chain
+    assert all(by_n[n]["h_eff_min"] == 200.0 for n in by_n)                                           # full-horizon rollouts only
+    eff = [by_n[n]["efficiency_vs_1gpu"] for n in ("1", "2", "4", "8")]
+    assert eff[0] == 1.0 and eff[0] > eff[1] > eff[2] > eff[3] > 0.2
+    assert abs(by_n["8"]["speedup_vs_1gpu"] - ms[0] / ms[3]) < 1e-9 and 2.0 < by_n["8"]["speedup_vs_1gpu"] < 4.0
+    # the emulated one-GPU point IS the measured sub-record's workload: the two agree
+    assert abs(sc5["measured"]["vs_predicted_ms_per_tick"] - 1.0) < 0.08
+
+
+@pytest.mark.timeout(600)
 def test_bench_rccl_bootstrap_failure_falls_back_to_host_transport():
     """if the library's RCCL communicator cannot be built, every rank switches to the host transport over a gloo
     side group and the run still measures the exchange (and says so)"""

@@ -198,6 +198,44 @@ def test_contracted_policy_within_north_star_tolerance(pmaf, oracle, scenes, cfg
     hip.close()
 
 
+def test_contracted_policy_on_the_sliced_wave_per_agent_kernel(pmaf, oracle, scenes):
+    """k_rollout_w64_sliced<3>: the contracted arithmetic policy with two waves per SIMD (BASELINE C5's per-GPU load at 4 GPUs,
+    scenes 0 and 2 -- scene 1 is the chaotic one, CONTRACTED_EXCEEDS). The slices are scheduling only: the contracted results of
+    this launch must equal, bit for bit, those of the SAME populations run one per handle (1 024 waves, one per SIMD, no
+    slicing), and stay within the policy's tolerance contract against the libm oracle."""
+    oracle.set_exp_mode(0)
+    scs = [scenes.config_scene("C5", scene_id=s) for s in (0, 2)]
+    hip, oras = _build(pmaf, oracle, scs, contracted=True)
+    lc = hip.launch_config()
+    assert (lc["lanes_per_agent"], lc["priority_slices"]) == (64, True), lc
+    singles = []
+    for q in scs:
+        h1, _ = _build(pmaf, oracle, [q], contracted=True)
+        assert not h1.launch_config()["priority_slices"]
+        singles.append(h1)
+    sc = scs[0]
+    obs = np.stack([q["obstacles"] for q in scs])
+    for t in range(5):
+        bh = hip.tick(obs, sc["dt"], sc["cost_gains"], sc["ws_limits"])
+        for i, h1 in enumerate(singles):
+            assert h1.tick(obs[i], sc["dt"], sc["cost_gains"], sc["ws_limits"]) == bh[i]
+    hip.stop()
+    ph, nh = hip.paths()
+    for i, h1 in enumerate(singles):
+        h1.stop()
+        p1, n1 = h1.paths()
+        np.testing.assert_array_equal(nh[i], n1)
+        np.testing.assert_array_equal(ph[i], p1)
+        np.testing.assert_array_equal(hip.costs()[i], h1.costs())
+        h1.close()
+    hip.close()
+    hip, oras = _build(pmaf, oracle, scs, contracted=True)
+    st = lockstep(hip, oras, scs, 20, None)
+    report("C5x2", "contracted", st)
+    check(st)
+    hip.close()
+
+
 def _task_records():
     return json.load(open(os.path.join(os.path.dirname(__file__), "golden", "task_scenes.json")))
 

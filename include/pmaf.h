@@ -175,7 +175,7 @@ int pmaf_stop(pmaf_planner *h);
  * ONE manager launch whose result the host takes from the mailbox in pinned memory (no stream synchronisation); obstacle
  * lists are handed over through the mapped pinned buffer -- not at all when bit-identical to the resident one -- and
  * agent indices / reset states by value in the kernel arguments for <= 4 populations: the five-call tick costs ~33 us at
- * the C++ boundary, pmaf_tick ~13 us (profiles/r5_facade_latency.txt). */
+ * the C++ boundary, pmaf_tick ~13 us (profiles/r6_facade_latency.txt). */
 /* CfManager::evaluateAgents, B/src/cf_manager.cpp:293-356.
  * cost_gains = {k_goal_dist,k_path_len,k_safe_dist,k_workspace},
  * ws = {xmax,xmin,ymax,ymin,zmax,zmin}; best_idx [P] out. */

@@ -27,7 +27,7 @@
 
 // -DPMAF_DEBUG_BOUNDS (tools/asan.sh; never in the product build): every index into a path, a list in LDS or a slot
 // table is checked against its capacity and the wave traps (the launch fails with an exception the host reports) instead
-// of writing out of bounds. The parity suite runs once through such a build per round (profiles/r3_asan.txt).
+// of writing out of bounds. The parity suite runs once through such a build per round (profiles/r6_asan.txt).
 #ifdef PMAF_DEBUG_BOUNDS
 #define PMAF_BOUND(c) do { if (!(c)) __builtin_trap(); } while (0)
 #else

@@ -59,7 +59,7 @@ __device__ __forceinline__ void rollout_grp_body(const DevView &D, const CostPar
 #endif
   // STATIC body (round 4): the obstacles' velocities no longer hold registers, so the population constants are pinned in
   // VGPRs (as in the wave-per-agent kernel): left in the SGPR file they are spilled to VGPR lanes and reloaded by
-  // v_readlane in the step loop -- VALU instructions, which bound this kernel (profiles/r5_c5_strict_steploop.txt)
+  // v_readlane in the step loop -- VALU instructions, which bound this kernel (profiles/r6_c5_strict_steploop.txt)
   if (STATIC && PMAF_GRP_PIN) {
     double *f = reinterpret_cast<double *>(&C);
     for (int i = 0; i < (int)(sizeof(PopConst) / sizeof(double)); i++) asm volatile("" : "+v"(f[i]));

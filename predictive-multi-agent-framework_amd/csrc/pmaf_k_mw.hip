@@ -4,7 +4,7 @@
 //
 // Why: with 61..256 field obstacles the wave-per-agent kernel holds 2 or 4 obstacle slots per lane and its lone wave
 // issues the per-obstacle instructions of every slot (C3: 769 instructions per step against the one-slot kernel's 447,
-// profiles/r5_c3_strict_steploop.txt) while three quarters of the chip's 1024 SIMDs idle. Here an agent is a BLOCK of
+// profiles/r6_c3_strict_steploop.txt) while three quarters of the chip's 1024 SIMDs idle. Here an agent is a BLOCK of
 // W = ceil(M / 64) waves on W SIMDs of one CU and every wave runs the ONE-slot step on its own <= 64 obstacles (<= 61:
 // lanes 61..63 stay the tail's riders and the sweep's norms ride in the tail's sequence, pmaf_k_w64.hip; 62..64: the
 // sweep takes its own). What an agent-step needs from ALL obstacles is exchanged ONCE per step through LDS with a

@@ -55,7 +55,7 @@ def oracle(pmaf):
 # Tolerance tests of the CONTRACTED policy against the oracle's libm-exp mode rest on last-bit differences NOT being
 # amplified past 1e-5 m. On chaotic rollouts (long horizons through moving spheres, C3's 500-step chains) whether they are
 # depends on the evaluation order AND on every other last bit: with the round-4 exp the two cases below exceeded the
-# tolerance under the right-associated pair (profiles/r5_gpu_tests_rassoc.log of that build); with glibc's exp they happen
+# tolerance under the right-associated pair (profiles/r6_gpu_tests_rassoc.log of that build); with glibc's exp they happen
 # to hold (6 xpassed -> 2). Kept as NON-strict expected failures there: per-scene luck, not a contract. The strict kernels'
 # comparisons (libm:* / task_libm:* / strict_libm:*) are exact under either association since round 5 and are not listed.
 CHAOTIC_VS_LIBM = {

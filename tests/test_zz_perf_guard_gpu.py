@@ -1,6 +1,6 @@
 """Coarse performance guards (MI355X; the file sorts last so that under `pytest -x` a timing failure cannot hide a functional one): rollout-kernel time per launch, from HIP events on the kernel's own dispatch
 (pmaf_set_profiling -- the device's clock, independent of the box's launch latency), against bounds ~20 % above the
-records of rounds 5 / 6 (profiles/r5_bench_*.json, r5_regime.txt, r6_lpa_grid.txt, r6_lpa_band.txt). Not a benchmark: they
+records of rounds 5 / 6 (profiles/r6_bench_*.json, r6_regime.txt, r6_lpa_grid.txt, r6_lpa_band.txt). Not a benchmark: they
 exist because round 5 lost 45 % on one kernel family to an LDS-occupancy cliff that no parity test could see (NOTES.md) -- a
 launch that drops a block per CU, spills to scratch or falls to the generic kernel trips these.
 

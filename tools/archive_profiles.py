@@ -20,7 +20,7 @@ TOKEN = re.compile(r"(?<![A-Za-z0-9_])((?:r[1-9]_|traffic)[A-Za-z0-9_*{},\-]*(?:
 def sources():
     out = subprocess.run(["git", "ls-files"], cwd=ROOT, capture_output=True, text=True, check=True).stdout.split("\n")
     for f in out:
-        if not f or f.startswith("profiles/") or f in ("VERDICT.md", "ADVICE.md", "SURVEY.md", "PAPERS.md", "SNIPPETS.md", "BASELINE.md"):
+        if not f or f.startswith("profiles/") or f == "tools/archive_profiles.py" or f in ("VERDICT.md", "ADVICE.md", "SURVEY.md", "PAPERS.md", "SNIPPETS.md", "BASELINE.md"):
             continue
         if f.endswith((".md", ".py", ".sh", ".h", ".hpp", ".cpp", ".hip", ".c", ".txt")):
             yield f

@@ -27,7 +27,7 @@ export UBSAN_OPTIONS=print_stacktrace=1:log_path=/tmp/ubsan_log
   echo "== host-heavy GPU tests (C-ABI validation, checkpoint, stepping API, attached exchange, peer mailboxes, failure detection,"
   echo "== winner path); every test named with its outcome, no -x; tests that need torch.cuda skip / fail to initialise torch under a"
   echo "== preloaded libasan and are deselected by name (the two *_does_not_leak tests read torch.cuda.mem_get_info: under LD_PRELOAD=libasan"
-  echo "== torch fails with 'Error in dlopen: libcaffe2_nvrtc.so' -- the one failure of profiles/r3_asan.txt; test_no_kernel_touches_scratch_memory"
+  echo "== torch fails with 'Error in dlopen: libcaffe2_nvrtc.so' -- the one failure of round 3's record; test_no_kernel_touches_scratch_memory"
   echo "== inspects the product build's object files, not this library; the facade driver is linked against the product library)"
   PMAF_LIB_PATH=$R/predictive-multi-agent-framework_amd/lib_asan/libpmaf_hip.so LD_PRELOAD="$ASAN_SO $UBSAN_SO" \
     python -m pytest tests/test_abi.py tests/test_peer_gpu.py tests/test_shard_gpu.py tests/test_parity_gpu.py tests/test_failure_detection_gpu.py tests/test_boundary_gpu.py \

@@ -8,7 +8,7 @@ as its longest chain while every wave has a SIMD of its own, so kernel_us / H is
 CPU: the oracle (TEST INFRASTRUCTURE, used here as the stated baseline only) on ONE pinned core: seconds per
 agent-step; a host with C cores running one agent per core needs ceil(N / C) x H x that per tick.
 Writes a JSON record and prints the table DESIGN.md quotes.
-usage: python tools/regime.py [--out profiles/r5_regime.json] [--horizon 200]"""
+usage: python tools/regime.py [--out profiles/r6_regime.json] [--horizon 200]"""
 import argparse
 import json
 import math

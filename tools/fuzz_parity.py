@@ -1,5 +1,5 @@
 """randomised parity run: random scenes (agent / obstacle counts, heuristic mixes, moving obstacles, gains, horizons,
-lanes-per-agent mappings) through the HIP path and the CPU oracle (portable-exp mode), every result compared bit for bit.
+lanes-per-agent mappings; PMAF_FUZZ_MANY=1: 900 ... 4 600 agents per population, the mappings the measured table chooses) through the HIP path and the CPU oracle (portable-exp mode), every result compared bit for bit.
 usage: python tools/fuzz_parity.py [n_trials] [seed] [only_trial]   (only_trial: replay the generator, run and
 diff that one trial in detail)"""
 import os, sys, time
@@ -12,6 +12,7 @@ orc.set_exp_mode(1)
 n_trials = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 only = int(sys.argv[3]) if len(sys.argv) > 3 else -1
+MANY = os.environ.get("PMAF_FUZZ_MANY") == "1"
 bad = 0
 t0 = time.time()
 for trial in range(n_trials):
@@ -19,6 +20,10 @@ for trial in range(n_trials):
     H = int(rng.integers(5, 160)); dyn = bool(rng.integers(0, 2))
     if rng.integers(0, 25) == 0:   # a large population (multi-block launches of the group kernels), short horizon
         N = int(rng.integers(200, 1500)); H = int(rng.integers(5, 30)); M = int(rng.choice([3, 17, 32, 40]))
+    if MANY:   # PMAF_FUZZ_MANY=1 (round 6): every trial is a many-agent population -- the shapes pick_lpa's measured table decides
+        # (16 / 32 / 64 lanes per agent, the wave per agent's priority-slicing loop between 1 025 and 2 048 agents), short horizons
+        N = int(rng.choice([rng.integers(1025, 2049), rng.integers(2049, 4600), rng.integers(900, 1100)]))
+        H = int(rng.integers(4, 22)); M = int(rng.choice([0, 3, 9, 16, 17, 32, 33, 48, 59, 60, 61, 64, 65, 100]))
     types = rng.integers(1, 7, N).astype(np.int32) if rng.integers(0, 2) else None
     sc = pm.scenes.synthetic_scene(N, H, M, 11, trial, dynamic=dyn, agent_types=types)
     if rng.integers(0, 3) == 0:   # denser clutter around the path
@@ -40,8 +45,10 @@ for trial in range(n_trials):
         if rng.integers(0, 3) == 0 and M > 0: sc["start"] = sc["obstacles"][0, :3] + rng.uniform(-0.02, 0.02, 3)  # inside an obstacle
         if rng.integers(0, 4) == 0 and M > 2: sc["obstacles"][1, :3] = sc["obstacles"][0, :3]       # coincident obstacles
     lpa = int(rng.choice([0, 0, 64, 32, 16, 8, 4, 1]))
+    if MANY and rng.integers(0, 4): lpa = 0   # mostly the library's own choice
     if lpa and (M + lpa - 1) // max(lpa, 1) > 64: lpa = 0
     ticks = int(rng.integers(1, 6)) if rng.integers(0, 8) else int(rng.integers(10, 40))
+    if MANY: ticks = min(ticks, 4)
     ieee = bool(rng.integers(0, 6) == 0)
     # 62..256 obstacles: the split kernel with the fewest waves (default), with more waves than needed, or the one-wave kernels
     os.environ["PMAF_MW"] = str(rng.choice(["", "", "0", "3", "4"]))

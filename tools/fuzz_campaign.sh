@@ -7,4 +7,4 @@ echo "# randomised parity campaigns against the oracle, tolerance 0 (fuzz_api al
 for args in "fuzz_parity.py 8000 $SEED" "fuzz_api.py 6000 $((SEED+2))"; do
   echo "== tools/$args"; python tools/$args 2>&1 | tail -1
 done
-echo "== PMAF_FUZZ_MANY=1 tools/fuzz_parity.py 500 $((SEED+5))"; PMAF_FUZZ_MANY=1 python tools/fuzz_parity.py 500 $((SEED+5)) 2>&1 | tail -1
+echo "== PMAF_FUZZ_MANY=1 tools/fuzz_parity.py 1500 $((SEED+5))"; PMAF_FUZZ_MANY=1 python tools/fuzz_parity.py 1500 $((SEED+5)) 2>&1 | tail -1

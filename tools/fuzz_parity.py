@@ -14,6 +14,7 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 only = int(sys.argv[3]) if len(sys.argv) > 3 else -1
 MANY = os.environ.get("PMAF_FUZZ_MANY") == "1"
 bad = 0
+kinds = {}   # (lanes per agent, waves per agent, priority slices) -> trials
 t0 = time.time()
 for trial in range(n_trials):
     N = int(rng.integers(1, 40)); M = int(rng.choice([0, 1, 2, 5, 9, 17, 32, 33, 58, 59, 60, 61, 62, 63, 64, 65, 100, 122, 123, 128, 129, 150, 192, 200, 256]))
@@ -57,6 +58,7 @@ for trial in range(n_trials):
         hip = pm.PmafPlanner(sc, device=0, mgr_init_pos=sc["start"], lanes_per_agent=lpa, ieee_sequences=ieee)
     except pm.PmafError as e:
         print("trial", trial, "create refused:", e); continue
+    cfg_ = hip.launch_config(); kinds[(cfg_["lanes_per_agent"], cfg_["waves_per_agent"], cfg_.get("priority_slices", False))] = kinds.get((cfg_["lanes_per_agent"], cfg_["waves_per_agent"], cfg_.get("priority_slices", False)), 0) + 1
     ora = orc.OraclePlanner(sc, mgr_init_pos=sc["start"])
     hip.set_initial_position(sc["start"]); ora.set_initial_position(sc["start"])
     obs = sc["obstacles"].copy(); ok = True
@@ -87,5 +89,6 @@ for trial in range(n_trials):
         bad += 1
         print("MISMATCH trial", trial, dict(N=N, M=M, H=H, dyn=dyn, lpa=lpa, ticks=ticks, wild=bool(wild), ieee=ieee, cfg=hip.launch_config()), flush=True)
     hip.close(); ora.close()
+print("kernels run (lanes per agent, waves per agent, priority slices): trials", dict(sorted(kinds.items())))
 print("trials", n_trials, "mismatches", bad, "in %.0f s" % (time.time() - t0))
 sys.exit(1 if bad else 0)

@@ -867,8 +867,8 @@ int pmaf_create(const pmaf_params *prm, pmaf_planner **out) {
     // The arithmetic and its order are the same instructions: bit-identical results (tests/test_parity_gpu.py runs these shapes).
     // PMAF_W64_SLICE=0|1, PMAF_W64_SLICE_LOG2, PMAF_W64_SLICE_YOUNGER in the environment: timing experiments.
     { const char *e = getenv("PMAF_W64_SLICE"); h->w64_slice = e ? (e[0] == '1') : PMAF_W64_SLICE_DEFAULT; }
-    { const char *e = getenv("PMAF_W64_SLICE_LOG2"); D.prio_slice_log2 = e ? atoi(e) : 9; }
-    { const char *e = getenv("PMAF_W64_SLICE_YOUNGER"); D.prio_younger_of_8 = e ? atoi(e) : 5; }
+    { const char *e = getenv("PMAF_W64_SLICE_LOG2"); D.prio_slice_log2 = std::min(20, std::max(4, e ? atoi(e) : 9)); }       // (a shift count on the device)
+    { const char *e = getenv("PMAF_W64_SLICE_YOUNGER"); D.prio_younger_of_8 = std::min(7, std::max(1, e ? atoi(e) : 5)); }
     { const char *ab = getenv("PMAF_ABLATE"); D.ablate = ab ? atoi(ab) : 0; }
     { const char *to = getenv("PMAF_EXCHANGE_TIMEOUT_S"); if (to && atof(to) > 0.0) h->exchange_timeout_s = atof(to); }
     { const char *to = getenv("PMAF_TICK_TIMEOUT_S"); if (to && atof(to) > 0.0) h->tick_timeout_s = atof(to); }

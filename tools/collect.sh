@@ -7,11 +7,11 @@ O=gpurun_out/$R
 PARTS=${@:-prof bench misc}
 for part in $PARTS; do case $part in
 prof)
-  for c in c2 c3 c5; do
+  for c in c2 c3 c5 c5x2; do
     [ -f gpurun_out/prof_${R}_$c/trace_summary.txt ] && cp gpurun_out/prof_${R}_$c/trace_summary.txt profiles/${R}_${c}_trace.txt
     for i in 1 2 3 4 5; do [ -f gpurun_out/prof_${R}_$c/pmc${i}_summary.txt ] && cp gpurun_out/prof_${R}_$c/pmc${i}_summary.txt profiles/${R}_${c}_pmc$i.txt; done
   done
-  python tools/traffic_from_pmc.py C2=${R}_c2 C3=${R}_c3 C5x8=${R}_c5 > /dev/null
+  python tools/traffic_from_pmc.py C2=${R}_c2 C3=${R}_c3 C5x8=${R}_c5 C5x2=${R}_c5x2 > /dev/null
   ;;
 bench)
   for f in $O/bench_*.json; do [ -s "$f" ] && cp "$f" profiles/${R}_$(basename $f); done

@@ -15,6 +15,7 @@ bench)
   python bench.py --config C3 --steps 400 --only-headline --cpu-seconds 6 > $O/bench_c3.json 2>> $O/bench.err
   python bench.py --config C5 --populations 8 --steps 400 --only-headline --cpu-seconds 6 --flop-ticks 2 > $O/bench_c5x8.json 2>> $O/bench.err
   python bench.py --dynamic --only-headline --cpu-seconds 0 > $O/bench_c2_dynamic.json 2>> $O/bench.err
+  python bench.py --config C5 --populations 2 --steps 400 --only-headline --cpu-seconds 0 --flop-ticks 2 > $O/bench_c5x2.json 2>> $O/bench.err
   PMAF_BENCH_BACKEND=gloo PMAF_BENCH_SINGLE_DEVICE=1 python bench.py --gpus 2 --cpu-seconds 0 --flop-ticks 0 2>> $O/bench.err | grep "^{" | tail -1 > $O/bench_2ranks_1gpu_selfspawn.json
   PMAF_BENCH_BACKEND=gloo PMAF_BENCH_SINGLE_DEVICE=1 PMAF_BENCH_C4_HOST_COUPLED=1 python bench.py --gpus 2 --config C4 --cpu-seconds 0 --flop-ticks 0 2>> $O/bench.err | grep "^{" | tail -1 > $O/bench_c4_2ranks_host_coupled.json
   PMAF_BENCH_FORCE_DIST=1 MASTER_PORT=29531 python bench.py --only-headline --cpu-seconds 0 --flop-ticks 0 2>> $O/bench.err | grep "^{" | tail -1 > $O/bench_c2_rccl_1rank.json
@@ -34,6 +35,7 @@ prof)
   bash tools/gpu_prof.sh ${R}_c2 > /dev/null 2>&1
   bash tools/gpu_prof.sh ${R}_c3 --config C3 --steps 400 > /dev/null 2>&1
   bash tools/gpu_prof.sh ${R}_c5 --config C5 --populations 8 --steps 400 > /dev/null 2>&1
+  bash tools/gpu_prof.sh ${R}_c5x2 --config C5 --populations 2 --steps 400 > /dev/null 2>&1   # two scenes per GPU: k_rollout_w64_sliced
   ;;
 misc)
   python tools/regime.py --out $O/regime.json > $O/regime.txt 2>&1

@@ -60,6 +60,13 @@ rows = [
     ("C4 dual arm 2 × 256 × 200 × 32, one GPU, peer mailboxes", cf["C4"]["rollouts_per_s"], cf["C4"]["ms_per_tick"], "`k_rollout_w64<1,2,true,true>` %.1f; header wait %.2f µs median / %.2f p99, publish %.2f µs" % (
         cf["C4"]["avg_kernel_us"], cf["C4"]["header_exchange_us"]["wait_median"], cf["C4"]["header_exchange_us"]["wait_p99"], cf["C4"]["header_exchange_us"]["publish_median"])),
 ]
+try:   # BASELINE C5's per-GPU load at 4 GPUs: two scenes in one handle = two wave-per-agent rollouts per SIMD
+    c52 = load("%s_bench_c5x2.json" % R)
+    t52, n52 = trace_avg("c5x2", "k_rollout_w64_sliced<2>")
+    rows.append(("C5, two scenes per GPU: 2 × 1024 × 200 × 32 (own run; priority slices)", c52["value"], c52["ms_per_step"],
+                 "`k_rollout_w64_sliced<2>` %.1f / %.1f (%d calls)" % (c52["roofline"]["avg_kernel_us"], t52, n52)))
+except (OSError, ValueError, KeyError):
+    pass
 ts = cf.get("task_static1") or {}
 if "rollouts_per_s" in ts:
     rows.append(("`task_static1`: 10 agents × ≤ 1499 steps × 9 (the shipped task; h_eff %.0f)" % ts["h_eff"], ts["rollouts_per_s"], ts["ms_per_tick"],

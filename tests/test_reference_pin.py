@@ -154,9 +154,16 @@ def test_pin_recipe_skips_without_real_eigen_and_dqrobotics_or_writes_fixtures()
 @pytest.mark.skipif(not REFS, reason="no tests/golden/ref_*.json yet: run `bash oracle/pin/make_pin.sh <reference checkout>` on a machine "
                                      "with Eigen3 + dqrobotics (cannot be produced in this image; PARITY UNPINNED until then)")
 def test_oracle_is_held_to_the_reference_fixtures():
+    hold_oracle_to(REFS)
+
+
+def hold_oracle_to(refs):
+    """the body of test_oracle_is_held_to_the_reference_fixtures for any list of fixture files (the tool-validation tests
+    below run it on oracle-made fixtures in a temporary directory, so that no line of it is first executed on a
+    maintainer's machine); returns the associations ("" = left, "rassoc" = right) that reproduce EVERY fixture"""
     matched = {}
-    for ref in REFS:
-        name = os.path.basename(ref)[4:-5]
+    for ref in refs:
+        name = json.load(open(ref))["scenario"]
         scn = os.path.join(PIN, "scenarios", name + ".txt")
         assert os.path.exists(scn), "fixture without its scenario: " + name
         meta = json.load(open(ref))["meta"]
@@ -178,6 +185,7 @@ def test_oracle_is_held_to_the_reference_fixtures():
     print("the reference build evaluates the %s association -> use %s" % (
         "RIGHT (a0 b0 + (a1 b1 + a2 b2))" if "rassoc" in common and "" not in common else "LEFT ((a0 b0 + a1 b1) + a2 b2)",
         "lib_rassoc/libpmaf_hip.so (PMAF_VARIANT=rassoc)" if "rassoc" in common and "" not in common else "lib/libpmaf_hip.so (the default)"))
+    return common
 
 
 class LockStep:
@@ -266,14 +274,19 @@ def test_hip_path_is_held_to_the_reference_fixtures(pmaf, oracle):
          then; scenarios where that alone is amplified past 1e-5 m -- the flow check with the round-4 exp found the second
          leg of dyn1_two_goals and the lagged closed loop on static1 -- are reported, not failed: a property of the scene
          and of the two libms, which no implementation escapes."""
+    hold_hip_to(REFS, pmaf, oracle)
+
+
+def hold_hip_to(refs, pmaf, oracle):
+    """the body of test_hip_path_is_held_to_the_reference_fixtures for any list of fixture files (see hold_oracle_to)"""
     sys.path.insert(0, PIN)
     import replay
     order = pmaf.load_library().pmaf_eval_order()
     sensitive = []
-    for ref_path in REFS:
-        name = os.path.basename(ref_path)[4:-5]
-        scn = replay.load_scenario(os.path.join(PIN, "scenarios", name + ".txt"))
+    for ref_path in refs:
         ref = json.load(open(ref_path))
+        name = ref["scenario"]
+        scn = replay.load_scenario(os.path.join(PIN, "scenarios", name + ".txt"))
         exact = replay.replay(scn, ref)                      # the oracle of THIS variant with libm exp, bit for bit
         if not exact["match"]:
             pytest.skip("evaluation order %d is not the reference build's (oracle differs on %s: %s) -- run with the other PMAF_VARIANT"
@@ -288,6 +301,46 @@ def test_hip_path_is_held_to_the_reference_fixtures(pmaf, oracle):
             assert res["match"] and res["max_abs_diff"] == 0, (name, res["first"])
         if not res["match"]:
             sensitive.append(name)
-    assert len(sensitive) < len(REFS), "every scenario deviates from the reference: not an exp effect"
+    assert len(sensitive) < len(refs), "every scenario deviates from the reference: not an exp effect"
     # the well-conditioned core must hold: BASELINE C1 / C2, the shipped static1 / dyn1 / trap tasks
     assert not {"c1_static1_n16_h100", "c2_64x200x32", "static1_shipped", "dyn1_shipped", "trap_shipped"} & set(sensitive), sensitive
+    return sensitive
+
+
+ALL_SCENARIOS = ["static1_n10_h100", "c1_static1_n16_h100", "static1_shipped", "dyn1_shipped", "trap_shipped", "dyn1_h300_hysteresis",
+                 "c2_64x200x32", "static1_closed_loop_lag30", "dyn1_two_goals", "dyn1_freq2"]
+
+
+def _record_files(tmp_path, names, variant):
+    """oracle-made fixtures (replay.py --record in a process of its own, so that PMAF_VARIANT picks the oracle build) -> paths"""
+    out = []
+    for n in names:
+        f = os.path.join(str(tmp_path), "oraclemade_%s_%s.json" % (variant or "left", n))
+        r = subprocess.run([sys.executable, os.path.join(PIN, "replay.py"), "--record", os.path.join(PIN, "scenarios", n + ".txt"), f],
+                           env=dict(os.environ, PMAF_VARIANT=variant), capture_output=True, text=True, timeout=1200)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out.append(f)
+    return out
+
+
+@pytest.mark.parametrize("variant", ["", "rassoc"])
+def test_tool_validation_the_oracle_fixture_test_runs_and_names_the_association(tmp_path, variant, capsys):
+    """TOOL VALIDATION, not parity evidence: the whole body of test_oracle_is_held_to_the_reference_fixtures on fixtures
+    recorded from the oracle under ONE association -- it must find them reproduced under that association only and tell the
+    maintainer which library that is (the decision the real fixtures exist for)"""
+    files = _record_files(tmp_path, ["c1_static1_n16_h100", "dyn1_two_goals", "static1_closed_loop_lag30", "dyn1_freq2"], variant)
+    assert hold_oracle_to(files) == {variant}
+    said = capsys.readouterr().out
+    assert ("lib_rassoc/libpmaf_hip.so" in said) == (variant == "rassoc") and said.count("MATCH") == 4
+
+
+@pytest.mark.gpu
+def test_tool_validation_the_hip_fixture_test_runs_on_all_ten_scenarios(tmp_path, pmaf, oracle):
+    """TOOL VALIDATION, not parity evidence: the whole body of test_hip_path_is_held_to_the_reference_fixtures on oracle-made
+    fixtures of all ten pin scenarios (this build's association): the shipped static1 / dyn1 / trap tasks to `reached` at a
+    1 500-step horizon, the hysteresis case, two goals, closed loop, freq multiple -- HIP == oracle call by call on every one,
+    and no scenario reported as sensitive on a host whose libm is the restated exp"""
+    files = _record_files(tmp_path, ALL_SCENARIOS, os.environ.get("PMAF_VARIANT", ""))
+    sensitive = hold_hip_to(files, pmaf, oracle)
+    if conftest.libm_is_restated(oracle):
+        assert sensitive == []

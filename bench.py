@@ -1087,7 +1087,11 @@ def main():
                    "workload": c5["workload"], "scaling": "strong", "n_gpus": world,
                    "measured": {"rollouts_per_s": c5["rollouts_per_s"], "ms_per_tick": c5["ms_per_tick"],
                                 "avg_kernel_us": c5["avg_kernel_us"], "populations_per_gpu": c5["populations_per_gpu"],
-                                "lanes_per_agent": c5["lanes_per_agent"], "allgather_us": c5.get("allgather_us")},
+                                "lanes_per_agent": c5["lanes_per_agent"], "allgather_us": c5.get("allgather_us"),
+                                # SURVEY 8(e)'s scaling report in one place: aggregate rollouts/s and ms per tick above, the
+                                # all-gather beside them, per-GPU tick latency and kernel time here, efficiency below
+                                "per_gpu_tick_us": c5["tick_latency_us"]["per_rank_median"],
+                                "per_gpu_kernel_us": c5["per_rank_kernel_us"]},
                    "reason": C5_SCALING_REASON}
             one = subs.get("C5_one_gpu")
             if one and "rollouts_per_s" in one:

@@ -604,6 +604,7 @@ def test_bench_self_spawns_its_ranks_and_reports_every_config():
     sc5 = out["scaling_c5"]
     assert sc5["n_gpus"] == 2 and sc5["scaling"] == "strong" and "weak" in sc5["read_this_for_scaling"]
     assert sc5["measured"]["rollouts_per_s"] == cfgs["C5_sharded"]["rollouts_per_s"]
+    assert len(sc5["measured"]["per_gpu_tick_us"]) == 2 and len(sc5["measured"]["per_gpu_kernel_us"]) == 2     # per-GPU figures
     assert sc5["one_gpu_same_job"]["rollouts_per_s"] == cfgs["C5_one_gpu"]["rollouts_per_s"]
     assert abs(sc5["measured"]["speedup_vs_one_gpu_same_job"] - cfgs["C5_sharded"]["rollouts_per_s"] / cfgs["C5_one_gpu"]["rollouts_per_s"]) < 1e-12
     assert abs(sc5["measured"]["efficiency_vs_one_gpu_same_job"] * 2 - sc5["measured"]["speedup_vs_one_gpu_same_job"]) < 1e-12
